@@ -1,0 +1,78 @@
+"""Pins oracle/lm_oracle.py against golden vectors produced by the reference itself
+(tests/golden/make_golden_lm.py, run in the authoring container)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.lm_oracle import Stage3Oracle, run_decode_loop, shapes_from_configs
+from toy_configs import TOY_LM, TOY_MODEL_ARGS
+from weights import checksum, seeded_state_dict
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "lm_toy_fp32.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "lm_toy_fp32.json")))
+    return d, meta
+
+
+@pytest.fixture(scope="module")
+def toy_sd(golden):
+    _, meta = golden
+    shapes = {k: tuple(s) for k, s in meta["keys"]}
+    sd = seeded_state_dict(shapes, meta["seed"])
+    cs = checksum(sd)
+    assert np.allclose(cs, meta["checksum"], rtol=1e-12), "seeded weight generator drifted"
+    return sd
+
+
+def make_oracle(sd, mode="fp32", batch=1):
+    m = Stage3Oracle(sd, shapes_from_configs(TOY_LM), TOY_MODEL_ARGS["audio_semantic_vocab_size"],
+                     TOY_MODEL_ARGS["audio_reason_vocab_size"], TOY_MODEL_ARGS["audio_num_codebooks"], mode=mode)
+    m.setup_caches(batch)
+    return m
+
+
+CASES = [("tts1", 24, "audio", 9), ("asr1", 10, "text", None), ("tts2", 12, "audio", 5)]
+
+
+@pytest.mark.parametrize("case,frames,feedback,switch", CASES)
+def test_oracle_matches_reference_ids_and_logits(golden, toy_sd, case, frames, feedback, switch):
+    d, meta = golden
+    assert not meta["any_ties"]
+    tokens = torch.from_numpy(d[f"{case}_tokens"]).long()
+    mask = torch.from_numpy(d[f"{case}_mask"]).bool()
+    if tokens.dim() == 2:
+        tokens, mask = tokens[None], mask[None]
+    m = make_oracle(toy_sd, "fp32", tokens.size(0))
+    r = run_decode_loop(m, tokens, mask, frames, feedback, forbid_switch=switch,
+                        reason_card=TOY_MODEL_ARGS["audio_reason_vocab_size"], collect_logits=True)
+    assert np.array_equal(r["samples"].numpy(), d[f"{case}_samples"]), "greedy ids differ from the reference"
+    # logits: same algorithm, fp32, different op order only
+    np.testing.assert_allclose(r["text_logits"].numpy(), d[f"{case}_text_logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(r["audio_logits"].numpy(), d[f"{case}_audio_logits"], atol=2e-5, rtol=0)
+
+
+def test_oracle_batch_rows_equal_single_runs(golden, toy_sd):
+    """Per-sequence positions: each row of a B=2 run equals its own B=1 run (batch invariance
+    the product must also have; the reference can only batch aligned rows)."""
+    d, _ = golden
+    tokens = torch.from_numpy(d["tts2_tokens"]).long()
+    mask = torch.from_numpy(d["tts2_mask"]).bool()
+    both = run_decode_loop(make_oracle(toy_sd, "fp32", 2), tokens, mask, 6, "audio")["samples"]
+    for b in range(2):
+        one = run_decode_loop(make_oracle(toy_sd, "fp32", 1), tokens[b:b + 1], mask[b:b + 1], 6, "audio")["samples"]
+        assert torch.equal(one[:, 0], both[:, b])
+
+
+def test_oracle_bf16_contract_runs_and_stays_close(golden, toy_sd):
+    d, _ = golden
+    tokens = torch.from_numpy(d["tts1_tokens"]).long()[None]
+    mask = torch.from_numpy(d["tts1_mask"]).bool()[None]
+    r = run_decode_loop(make_oracle(toy_sd, "bf16"), tokens, mask, 4, "audio", collect_logits=True)
+    # teacher-forced only on frame 0 (free-running ids may diverge later)
+    ref = d["tts1_text_logits"][0]
+    assert np.abs(r["text_logits"][0].numpy() - ref).max() < 0.05
