@@ -1,0 +1,227 @@
+/*
+ * ua2hip.h — C ABI of libua2hip.so: the MI355X (gfx950) kernels behind UniAudio 2.0's
+ * audio-token generation hot path (BASELINE.json north_star).
+ *
+ * The reference (yangdongchao/UniAudio2) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md §8b): each entry point below replaces a *PyTorch call site* of the reference,
+ * cited as file:line relative to the reference root.  The binding a maintainer of the
+ * reference would add is a ctypes stub; uniaudio2_amd/_lib.py is that stub.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (void*), explicit sizes, a hipStream_t passed as void*.
+ *   - every function returns 0 on success, negative on error; ua2_last_error() gives text.
+ *   - the caller owns every buffer; the library owns only the handles it returns.
+ *   - stream-ordered, no hidden synchronisation, no device allocation inside calls.
+ *   - dtype = storage/compute type of weights, embedding tables and the KV cache:
+ *       UA2_F32  exact-fp32 path (f32-input MFMA), for id-level parity with the fp32 reference
+ *       UA2_BF16 bf16 operands, fp32 accumulate (MFMA 16x16x32 bf16), fp32 residual stream
+ *     Activations between kernels are always fp32.
+ */
+#ifndef UA2HIP_H
+#define UA2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UA2_VERSION 1
+
+enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
+
+/* A-operand producer fused into the GEMM (what the reference does right before the Linear). */
+enum ua2_prologue {
+  UA2_PRO_CAST = 0, /* x as is                                   (lit_model.py:511,595; model_new.py:617,631) */
+  UA2_PRO_NORM = 1, /* RMSNorm(x)*w, fp32 math                    (lit_model.py:883-890 before :424 / :591)    */
+  UA2_PRO_ATTN = 2  /* merge of the per-page attention partials   (softmax tail of lit_model.py:529-531)        */
+};
+
+/* What happens to the GEMM result (the ops the reference runs right after the Linear). */
+enum ua2_epilogue {
+  UA2_EPI_STORE = 0,    /* y = xW^T; optional per-tile (max,idx) partials for greedy sampling (model_new.py:146-187) */
+  UA2_EPI_RESIDUAL = 1, /* y = resid + xW^T                          (lit_model.py:345,349)                    */
+  UA2_EPI_SWIGLU = 2,   /* y = silu(xW1^T) * (xW2^T)                 (lit_model.py:592-594)                    */
+  UA2_EPI_QKV_ROPE = 3  /* split q|k|v, half-split RoPE on q,k, append k,v to the paged cache
+                           (lit_model.py:431, 458-461, 778-807, 831-856)                                       */
+};
+
+const char* ua2_last_error(void);
+int ua2_version(void);
+
+/* Number of elements (of `dtype`) in the packed form of an [N,K] Linear weight. */
+size_t ua2_packed_elems(int dtype, int64_t N, int64_t K);
+
+/* Re-tile a Linear weight into MFMA B-fragment order so that every wave load is one
+ * contiguous 1 KiB line burst: out[N/16][K/KC][64 lanes][16 B].  `src` is [N,K] row-major
+ * (nn.Linear.weight, lit_model.py:356-360) or, with transposed=1, [K,N] (audio_head[i],
+ * model_new.py:349,632).  src_dtype is the dtype of `src`; dst dtype is `dtype`
+ * (fp32 -> bf16 rounds to nearest even, as torch .to(bfloat16)). */
+int ua2_pack_linear(const void* src, int src_dtype, int transposed, int64_t N, int64_t K,
+                    void* out, int dtype, void* stream);
+
+/* Geometry of the paged KV cache shared by the QKV epilogue and the attention kernel.
+ * Pool layout (per layer): [n_pages][n_kv][UA2_PAGE][head_size] of `dtype`, K and V separate.
+ * page_table[seq*max_pages + p] = page id holding positions [p*UA2_PAGE, (p+1)*UA2_PAGE). */
+#define UA2_PAGE 64
+
+typedef struct ua2_kv_geom {
+  void* k_pool;
+  void* v_pool;
+  const int32_t* page_table;
+  int32_t max_pages; /* per sequence */
+  int32_t n_kv;      /* n_query_groups */
+  int32_t n_head;
+  int32_t head_size;
+} ua2_kv_geom;
+
+typedef struct ua2_linear_args {
+  int32_t dtype, prologue, epilogue;
+  int32_t M, N, K;        /* rows, out features, in features */
+  const float* x;         /* CAST/NORM: [M, ldx] fp32 */
+  int32_t ldx;
+  const float* norm_w;    /* NORM: [K] fp32 */
+  float eps;
+  const float* attn_o;    /* ATTN: [M, n_head, max_pages, head_size] fp32 un-normalised partial outputs */
+  const float* attn_ml;   /* ATTN: [M, n_head, max_pages, 2] (max, sum) */
+  const void* w0;         /* packed weight */
+  const void* w1;         /* SWIGLU: packed fc_2 */
+  float* y;               /* STORE/RESIDUAL/SWIGLU: [M, ldy] fp32 (STORE: may be NULL if only partials wanted) */
+  int32_t ldy;
+  const float* resid;     /* RESIDUAL: [M, ldr], may alias y */
+  int32_t ldr;
+  float* part_max;        /* STORE, optional: [M, ceil(N/16)] */
+  int32_t* part_idx;
+  const int32_t* forbid;  /* optional [M]: columns < forbid[m] are excluded from the partial arg-max */
+  const int32_t* row_pos; /* ATTN, QKV_ROPE: [M] absolute position of each row */
+  const int32_t* row_seq; /* QKV_ROPE: [M] sequence (page-table row) of each row */
+  const float* rope_cos;  /* QKV_ROPE: [max_pos, head_size/2] */
+  const float* rope_sin;
+  float* q_out;           /* QKV_ROPE: [M, n_head*head_size] fp32, rotated */
+  ua2_kv_geom kv;         /* ATTN (n_head, head_size, max_pages), QKV_ROPE (all) */
+} ua2_linear_args;
+
+int ua2_linear(const ua2_linear_args* a, void* stream);
+
+/* Decode/prefill attention over the paged cache: one query row per (row, head); each
+ * (row, kv-head, page) workgroup writes un-normalised partials that UA2_PRO_ATTN merges.
+ * Replaces repeat_interleave + masked SDPA (lit_model.py:478-481, 529-531): GQA without
+ * materialising K/V per query head, causal mask = "positions <= row_pos". */
+typedef struct ua2_attn_args {
+  int32_t dtype;
+  int32_t R;              /* query rows */
+  const float* q;         /* [R, n_head*head_size] fp32 */
+  const int32_t* row_pos; /* [R] */
+  const int32_t* row_seq; /* [R] */
+  float* attn_o;          /* [R, n_head, max_pages, head_size] */
+  float* attn_ml;         /* [R, n_head, max_pages, 2] */
+  int32_t grid_pages;     /* pages to launch (>= max(row_pos)/UA2_PAGE + 1); <=0 means kv.max_pages */
+  ua2_kv_geom kv;
+} ua2_attn_args;
+
+int ua2_attn(const ua2_attn_args* a, void* stream);
+
+/* Frame embedding (model_new.py:594-600, 604, 665-673): for each row,
+ * audio_sum = sum_i mask[i] * audio_emb[tok[i] + i*V_a]  (i = 0..n_cb-1, in order), text = wte[tok[n_cb]]. */
+int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, int32_t va,
+                    const int32_t* tokens /* [M, n_cb+1] */, const uint8_t* mask /* [M, n_cb+1] */,
+                    const void* audio_emb, const void* wte, float* audio_sum /* [M,C] */, float* text /* [M,C] */,
+                    void* stream);
+
+/* Final RMSNorm of a GPT + the step-mask blends (lit_model.py:164; model_new.py:607,610,613):
+ *   n = RMSNorm(x)*w ; out1 = n*fa + other*fb ; out2 = n (optional)
+ * fa = mask[m, col_a] if col_a >= 0 else 1 ; fb = mask[m, col_b] if other else 0. */
+int ua2_rmsnorm_blend(int32_t M, int32_t C, const float* x, const float* w, float eps,
+                      const float* other, const uint8_t* mask, int32_t mask_ld, int32_t col_a, int32_t col_b,
+                      float* out1, float* out2, void* stream);
+
+/* Greedy sampling tail (model_new.py:146-187 with topk=1; lowest index wins ties) fused with
+ * the next-step embedding gather (model_new.py:640,662-663):
+ *   tok = argmax over the per-tile partials; out_tokens[m*out_ld + out_col] = tok;
+ *   if emb: next_h[m,:] = emb[tok + emb_row_offset, :]  */
+int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const float* part_max, const int32_t* part_idx,
+                     int32_t* out_tokens, int32_t out_ld, int32_t out_col,
+                     const void* emb, int32_t emb_row_offset, int32_t C, float* next_h, void* stream);
+
+/* ---- whole-frame executor -------------------------------------------------------------- */
+
+typedef struct ua2_gpt_desc {
+  int32_t n_layer, n_embd, n_head, n_kv, head_size, inter;
+  float eps;
+  /* per layer arrays of device pointers (host arrays of length n_layer) */
+  const void* const* qkv;    /* packed [ (n_head+2*n_kv)*hs, n_embd ] */
+  const void* const* proj;   /* packed [ n_embd, n_head*hs ] */
+  const void* const* fc1;    /* packed [ inter, n_embd ] */
+  const void* const* fc2;
+  const void* const* mlp_proj; /* packed [ n_embd, inter ] */
+  const float* const* norm1;
+  const float* const* norm2;
+  const float* ln_f;
+  const float* rope_cos;     /* [max_pos, hs/2] */
+  const float* rope_sin;
+  void* const* k_pool;       /* per layer */
+  void* const* v_pool;
+  const int32_t* page_table;
+  int32_t max_pages;
+} ua2_gpt_desc;
+
+typedef struct ua2_stage3_desc {
+  int32_t dtype;
+  int32_t n_cb;         /* audio_num_codebooks (8) */
+  int32_t va;           /* audio_semantic_vocab_size + audio_reason_vocab_size */
+  int32_t vt;           /* text vocab (lm_head rows) */
+  int32_t max_rows;     /* capacity in rows of the trunk (prefill chunk / decode batch) */
+  int32_t max_batch;    /* capacity in rows of the heads (lm_head + local decoder), <= max_rows */
+  ua2_gpt_desc und, backbone, gen, decoder;
+  const void* wte;      /* [vt, C] */
+  const void* audio_emb;/* [va*n_cb, C] */
+  const void* lm_head;  /* packed [vt, C] */
+  const void* projection; /* packed [Cd, C] */
+  const void* const* audio_head; /* n_cb packed [va, Cd] */
+  /* sequence state (device) */
+  int32_t* tokens;      /* [max_rows, n_cb+1] current input frame(s) */
+  uint8_t* mask;        /* [max_rows, n_cb+1] */
+  int32_t* row_pos;     /* [max_rows] */
+  int32_t* row_seq;     /* [max_rows] */
+  int32_t* dec_pos;     /* [n_cb, max_rows]: row i filled with i — positions of the local decoder's step i */
+  int32_t* dec_seq;     /* [max_rows] = 0,1,2,...: page-table rows of the local decoder's 8-slot caches */
+  int32_t* forbid;      /* [max_rows] forbid_prefix per row */
+  int32_t* out_tokens;  /* [max_rows, n_cb+1] sampled [text, a0..a7] */
+  int32_t* frame_log;   /* [log_frames, max_rows, n_cb+1] */
+  int32_t* counters;    /* [4]: frame index, ... */
+  int32_t log_frames;
+  /* scratch (device, fp32 unless noted) — sizes in ua2_stage3_scratch_floats() */
+  float* scratch;
+  size_t scratch_floats;
+} ua2_stage3_desc;
+
+typedef struct ua2_stage3 ua2_stage3;
+
+size_t ua2_stage3_scratch_floats(const ua2_stage3_desc* d);
+int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out);
+void ua2_stage3_destroy(ua2_stage3* h);
+/* Number of KV pages the attention grid covers (>= max position / UA2_PAGE + 1). Default: max_pages. */
+int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages);
+
+/* model_new.py:594-613 (embed-merge -> U-expert -> backbone -> G-expert -> blend) for R rows
+ * described by tokens/mask/row_pos/row_seq.  Used for prefill (forward_prefix, :456-497; the
+ * discarded lm_head/local-decoder work :498-506 is skipped) and as the first half of a frame. */
+int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream);
+/* model_new.py:617-641: lm_head + greedy text sample, then the 8-step local decoder. */
+int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream);
+/* Feedback for the next frame, on device (evaluation/tts_task.py:259-280 mode 0 "audio";
+ * evaluation/asr_task.py:668-682 mode 1 "text"): logs out_tokens, builds the next input frame,
+ * row_pos += 1, applies the reason_eos -> forbid_prefix switch (tts_task.py:263-266). */
+int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card, void* stream);
+/* trunk + heads + feedback (mode < 0: no feedback), captured once into a hipGraph and replayed
+ * (use_graph != 0). */
+int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
+                     int32_t use_graph, void* stream);
+/* Expose intermediate buffers for tests: name in {"h_final","text_logits","audio_logits"}. */
+float* ua2_stage3_buffer(ua2_stage3* h, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UA2HIP_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libua2hip.so — the stub a maintainer of the reference would add
+(INTEGRATION.md).  Mirrors include/ua2hip.h one to one; no torch types cross the boundary.
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing
+this module raises (the product must fail loudly, never silently run something else).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libua2hip.so")
+
+UA2_F32, UA2_BF16 = 0, 1
+PRO_CAST, PRO_NORM, PRO_ATTN = 0, 1, 2
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE = 0, 1, 2, 3
+UA2_PAGE = 64
+
+vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+
+
+class KvGeom(C.Structure):
+    _fields_ = [("k_pool", vp), ("v_pool", vp), ("page_table", vp), ("max_pages", i32), ("n_kv", i32),
+                ("n_head", i32), ("head_size", i32)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("prologue", i32), ("epilogue", i32), ("M", i32), ("N", i32), ("K", i32),
+                ("x", vp), ("ldx", i32), ("norm_w", vp), ("eps", f32), ("attn_o", vp), ("attn_ml", vp),
+                ("w0", vp), ("w1", vp), ("y", vp), ("ldy", i32), ("resid", vp), ("ldr", i32),
+                ("part_max", vp), ("part_idx", vp), ("forbid", vp), ("row_pos", vp), ("row_seq", vp),
+                ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("attn_o", vp),
+                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom)]
+
+
+class GptDesc(C.Structure):
+    _fields_ = [("n_layer", i32), ("n_embd", i32), ("n_head", i32), ("n_kv", i32), ("head_size", i32),
+                ("inter", i32), ("eps", f32),
+                ("qkv", C.POINTER(vp)), ("proj", C.POINTER(vp)), ("fc1", C.POINTER(vp)), ("fc2", C.POINTER(vp)),
+                ("mlp_proj", C.POINTER(vp)), ("norm1", C.POINTER(vp)), ("norm2", C.POINTER(vp)),
+                ("ln_f", vp), ("rope_cos", vp), ("rope_sin", vp),
+                ("k_pool", C.POINTER(vp)), ("v_pool", C.POINTER(vp)), ("page_table", vp), ("max_pages", i32)]
+
+
+class Stage3Desc(C.Structure):
+    _fields_ = [("dtype", i32), ("n_cb", i32), ("va", i32), ("vt", i32), ("max_rows", i32), ("max_batch", i32),
+                ("und", GptDesc), ("backbone", GptDesc), ("gen", GptDesc), ("decoder", GptDesc),
+                ("wte", vp), ("audio_emb", vp), ("lm_head", vp), ("projection", vp), ("audio_head", C.POINTER(vp)),
+                ("tokens", vp), ("mask", vp), ("row_pos", vp), ("row_seq", vp), ("dec_pos", vp), ("dec_seq", vp),
+                ("forbid", vp), ("out_tokens", vp), ("frame_log", vp), ("counters", vp), ("log_frames", i32),
+                ("scratch", vp), ("scratch_floats", C.c_size_t)]
+
+
+_EXPORTS = {
+    "ua2_last_error": (C.c_char_p, []),
+    "ua2_version": (C.c_int, []),
+    "ua2_packed_elems": (C.c_size_t, [C.c_int, i64, i64]),
+    "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, vp]),
+    "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
+    "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),
+    "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
+    "ua2_stage3_scratch_floats": (C.c_size_t, [C.POINTER(Stage3Desc)]),
+    "ua2_stage3_create": (C.c_int, [C.POINTER(Stage3Desc), C.POINTER(vp)]),
+    "ua2_stage3_destroy": (None, [vp]),
+    "ua2_stage3_set_grid_pages": (C.c_int, [vp, i32]),
+    "ua2_stage3_trunk": (C.c_int, [vp, i32, vp]),
+    "ua2_stage3_heads": (C.c_int, [vp, i32, vp]),
+    "ua2_stage3_feedback": (C.c_int, [vp, i32, i32, i32, i32, vp]),
+    "ua2_stage3_frame": (C.c_int, [vp, i32, i32, i32, i32, i32, vp]),
+    "ua2_stage3_buffer": (C.POINTER(C.c_float), [vp, C.c_char_p]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/ua2hip.h declares (checked by the CPU test-suite)."""
+    return sorted(_EXPORTS)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m uniaudio2_amd.build or "
+            "__graft_entry__.build()).  uniaudio2_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _EXPORTS.items():
+        fn = getattr(lib, name)           # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class Ua2Error(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise Ua2Error(f"{what} failed ({rc}): {lib.ua2_last_error().decode(errors='replace')}")

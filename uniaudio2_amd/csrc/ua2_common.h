@@ -1,0 +1,81 @@
+// Internal helpers shared by the gfx950 kernels of libua2hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ua2hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define UA2_WAVE 64
+
+void ua2_set_error(const char* fmt, ...);
+
+#define UA2_CHECK(cond, ...)                 \
+  do {                                       \
+    if (!(cond)) {                           \
+      ua2_set_error(__VA_ARGS__);            \
+      return -1;                             \
+    }                                        \
+  } while (0)
+
+#define UA2_HIP(call)                                                          \
+  do {                                                                         \
+    hipError_t _e = (call);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      ua2_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -2;                                                               \
+    }                                                                          \
+  } while (0)
+
+#define UA2_LAUNCH_CHECK()                                                     \
+  do {                                                                         \
+    hipError_t _e = hipGetLastError();                                         \
+    if (_e != hipSuccess) {                                                    \
+      ua2_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -3;                                                               \
+    }                                                                          \
+  } while (0)
+
+// Per-dtype tiling constants.  One wave-level "chunk" = one 16-byte load per lane of the
+// packed weight = KC values of K for 16 output columns.
+template <int DT> struct Elem;
+template <> struct Elem<UA2_BF16> {
+  static constexpr int KC = 32;   // K per chunk (one mfma_f32_16x16x32_bf16)
+  static constexpr int EPL = 8;   // elements per lane per chunk
+  static constexpr int BYTES = 2;
+};
+template <> struct Elem<UA2_F32> {
+  static constexpr int KC = 16;   // four mfma_f32_16x16x4_f32
+  static constexpr int EPL = 4;
+  static constexpr int BYTES = 4;
+};
+
+// fp32 -> bf16 bits, round to nearest even (same as torch's .to(torch.bfloat16)).
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+
+template <int DT> __device__ __forceinline__ float load_elem(const void* p, size_t i);
+template <> __device__ __forceinline__ float load_elem<UA2_F32>(const void* p, size_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float load_elem<UA2_BF16>(const void* p, size_t i) {
+  return bf2f(((const unsigned short*)p)[i]);
+}
+template <int DT> __device__ __forceinline__ void store_elem(void* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_elem<UA2_F32>(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void store_elem<UA2_BF16>(void* p, size_t i, float v) {
+  ((unsigned short*)p)[i] = f2bf(v);
+}
+
+static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// internal launchers used by both the op-level ABI and the frame executor
+int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);
+int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s);

@@ -1,0 +1,423 @@
+// Skinny-M weight-streaming GEMM for the decode loop:  Y[M,N] = epilogue( prologue(X)[M,K] * W[N,K]^T )
+//
+// Replaces the nn.Linear call sites of the reference's decode frame together with the op
+// right before and right after each of them (include/ua2hip.h
+// lists the file:line of every fused piece).
+//
+// MI355X design:
+//   * the weight is the only HBM stream that matters (M <= 16 per workgroup row-tile), so it is
+//     pre-tiled into MFMA B-fragment order (ua2_pack_linear): every wave load is one contiguous
+//     1 KiB burst (64 lanes x 16 B), issued non-temporal straight into VGPRs (no LDS round trip —
+//     the operand is streamed once and not shared between waves);
+//   * one workgroup = 8 waves = one 16-column output tile (two tiles for the fused SwiGLU / RoPE
+//     epilogues); the 8 waves split K, keep 2 x UB KiB of weight in flight each, and meet in
+//     LDS for a fixed-order reduction (deterministic, batch-size independent);
+//   * M rows ride in the 16-row A operand of mfma_f32_16x16x32_bf16 (bf16 operands, fp32
+//     accumulate) or mfma_f32_16x16x4_f32 (exact fp32): the matrix pipe is idle-cheap at this
+//     shape and the same instruction stream serves M = 1 and M = 16, so a row's result does not
+//     depend on how many other rows are in flight;
+//   * RMSNorm / attention-merge prologues and residual / SwiGLU / RoPE+KV-append / arg-max
+//     epilogues run inside the kernel: activations never round-trip HBM in bf16.
+#include "ua2_common.h"
+
+namespace {
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * UA2_WAVE;
+constexpr int UB = 4;  // chunks per software-pipelined batch
+
+// ---- packing ------------------------------------------------------------------------------
+
+template <int SRC, int DST>
+__global__ void pack_kernel(const void* __restrict__ src, void* __restrict__ out, int transposed, int64_t N, int64_t K,
+                            int64_t total) {
+  constexpr int KC = Elem<DST>::KC, EPL = Elem<DST>::EPL;
+  const int64_t nchunks = (K + KC - 1) / KC;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx % EPL);
+    const int lane = (int)((idx / EPL) % 64);
+    const int64_t chunk = (idx / (EPL * 64)) % nchunks;
+    const int64_t tile = idx / (EPL * 64 * nchunks);
+    const int64_t n = tile * 16 + (lane & 15);
+    const int64_t k = chunk * KC + (lane >> 4) * EPL + e;
+    float v = 0.f;
+    if (n < N && k < K) v = load_elem<SRC>(src, transposed ? (size_t)(k * N + n) : (size_t)(n * K + k));
+    store_elem<DST>(out, (size_t)idx, v);
+  }
+}
+
+// ---- fragments ----------------------------------------------------------------------------
+
+template <int DT> struct AFrag;
+template <> struct AFrag<UA2_BF16> {
+  u32x4 v;
+  __device__ __forceinline__ void set(const float (&f)[8]) {
+    v[0] = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+    v[1] = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+    v[2] = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+    v[3] = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+  }
+  __device__ __forceinline__ void mma(const u32x4& w, f32x4& acc) const {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, w), acc, 0,
+                                                  0, 0);
+  }
+};
+template <> struct AFrag<UA2_F32> {
+  f32x4 v;
+  __device__ __forceinline__ void set(const float (&f)[4]) {
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+  }
+  __device__ __forceinline__ void mma(const u32x4& w, f32x4& acc) const {
+    const f32x4 b = __builtin_bit_cast(f32x4, w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], b[e], acc, 0, 0, 0);
+  }
+};
+
+// ---- A-operand producers (row m, K offset k0, EPL consecutive values) -----------------------
+
+template <int EPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&f)[EPL]) {
+#pragma unroll
+  for (int q = 0; q < EPL / 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+    f[4 * q + 0] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+  }
+}
+
+template <int DT, int PRO>
+__device__ __forceinline__ void make_a(const ua2_linear_args& a, int m, bool valid, int k0, float rstd,
+                                       AFrag<DT>& out) {
+  constexpr int EPL = Elem<DT>::EPL;
+  float f[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) f[e] = 0.f;
+  if (valid && k0 < a.K) {
+    if constexpr (PRO == UA2_PRO_CAST) {
+      load_row<EPL>(a.x + (size_t)m * a.ldx + k0, f);
+    } else if constexpr (PRO == UA2_PRO_NORM) {
+      float w[EPL];
+      load_row<EPL>(a.x + (size_t)m * a.ldx + k0, f);
+      load_row<EPL>(a.norm_w + k0, w);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] = __fmul_rn(__fmul_rn(f[e], rstd), w[e]);  // (x*rstd)*w, lit_model.py:887-889
+    } else {  // UA2_PRO_ATTN: merge the per-page partials of head h
+      const int hs = a.kv.head_size, mp = a.kv.max_pages;
+      const int h = k0 / hs, d = k0 - h * hs;
+      const int nsp = a.row_pos[m] / UA2_PAGE + 1;
+      const float* ml = a.attn_ml + ((size_t)m * a.kv.n_head + h) * mp * 2;
+      const float* po = a.attn_o + (((size_t)m * a.kv.n_head + h) * mp) * hs + d;
+      float mx = -INFINITY;
+      for (int s = 0; s < nsp; ++s) mx = fmaxf(mx, ml[2 * s]);
+      float den = 0.f;
+      for (int s = 0; s < nsp; ++s) {
+        const float wgt = expf(ml[2 * s] - mx);
+        den += wgt * ml[2 * s + 1];
+        float t[EPL];
+        load_row<EPL>(po + (size_t)s * hs, t);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) f[e] += wgt * t[e];
+      }
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] *= inv;
+    }
+  }
+  out.set(f);
+}
+
+// ---- the kernel ---------------------------------------------------------------------------
+
+template <int DT, int PRO, int EPI>
+__global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args a) {
+  constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_QKV_ROPE) ? 2 : 1;
+  __shared__ float red[kWaves][NT][256];
+  __shared__ float ssq[kWaves][16];
+  __shared__ float rstd_s[16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int m = blockIdx.y * 16 + i;
+  const bool mvalid = m < a.M;
+
+  const int nchunks = (a.K + KC - 1) / KC;
+  int tile[NT];
+  const u32x4* wp[NT];
+  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    const int hst = a.kv.head_size / 16, half = hst / 2;
+    const int h = blockIdx.x / half, r = blockIdx.x - h * half;
+    tile[0] = h * hst + r;
+    tile[1] = tile[0] + half;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
+    wp[1] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[1] * nchunks * 64 + lane;
+  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+    tile[0] = tile[1] = blockIdx.x;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
+    wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)tile[0] * nchunks * 64 + lane;
+  } else {
+    tile[0] = blockIdx.x;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
+  }
+  const int c0 = (wave * nchunks) / kWaves, c1 = ((wave + 1) * nchunks) / kWaves;
+
+  // first weight batch goes out before anything else so HBM latency overlaps the prologue
+  u32x4 wf[NT][UB];
+  const bool full0 = c0 + UB <= c1;
+  if (full0) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(c0 + u) * 64);
+  }
+
+  float rstd = 1.f;
+  if constexpr (PRO == UA2_PRO_NORM) {
+    float ss = 0.f;
+    if (mvalid) {
+      for (int c = c0; c < c1; ++c) {
+        const int k0 = c * KC + g * EPL;
+        if (k0 < a.K) {
+          float f[EPL];
+          load_row<EPL>(a.x + (size_t)m * a.ldx + k0, f);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) ss += f[e] * f[e];
+        }
+      }
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    if (g == 0) ssq[wave][i] = ss;
+    __syncthreads();
+    if (tid < 16) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) t += ssq[w][tid];
+      rstd_s[tid] = 1.0f / sqrtf(t / (float)a.K + a.eps);  // torch.rsqrt(mean(x*x) + eps), lit_model.py:886-887
+    }
+    __syncthreads();
+    rstd = rstd_s[i];
+  }
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int c = c0;
+  if (full0) {
+    // steady state: A for batch b, prefetch W for batch b+1, then the MFMAs of batch b
+    for (; c + UB <= c1; c += UB) {
+      AFrag<DT> af[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) make_a<DT, PRO>(a, m, mvalid, (c + u) * KC + g * EPL, rstd, af[u]);
+      u32x4 wn[NT][UB];
+      const bool more = c + 2 * UB <= c1;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wn[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(c + UB + u) * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) af[u].mma(wf[t][u], acc[t]);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wf[t][u] = wn[t][u];
+      }
+    }
+  }
+  for (; c < c1; ++c) {  // remainder chunks (K not a multiple of 8*UB*KC)
+    AFrag<DT> af;
+    make_a<DT, PRO>(a, m, mvalid, c * KC + g * EPL, rstd, af);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const u32x4 w = __builtin_nontemporal_load(wp[t] + (size_t)c * 64);
+      af.mma(w, acc[t]);
+    }
+  }
+
+  // fixed-order cross-wave reduction through LDS
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane * 4]) = acc[t];
+  __syncthreads();
+  if (tid >= 256) return;
+  const int row = tid >> 4, col = tid & 15;
+  const int src = (((row >> 2) << 4) + col) * 4 + (row & 3);  // C/D layout: lane=(row/4)*16+col, reg=row%4
+  float v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += red[w][t][src];
+    v[t] = s;
+  }
+  const int mr = blockIdx.y * 16 + row;
+  const bool rvalid = mr < a.M;
+
+  if constexpr (EPI == UA2_EPI_STORE) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N && a.y) a.y[(size_t)mr * a.ldy + n] = v[0];
+    if (a.part_max) {
+      const int fb = (a.forbid && rvalid) ? a.forbid[mr] : 0;
+      float bv = (n < a.N && n >= fb) ? v[0] : -INFINITY;
+      int bi = n;
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {  // 16-lane groups; ties -> lowest index
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (col == 0 && rvalid) {
+        const int nb = gridDim.x;
+        a.part_max[(size_t)mr * nb + blockIdx.x] = bv;
+        a.part_idx[(size_t)mr * nb + blockIdx.x] = bi;
+      }
+    }
+  } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = v[0] + a.resid[(size_t)mr * a.ldr + n];
+  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N) {
+      const float gte = v[0];
+      const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
+      a.y[(size_t)mr * a.ldy + n] = sg * v[1];
+    }
+  } else {  // UA2_EPI_QKV_ROPE
+    if (!rvalid) return;
+    const int hs = a.kv.head_size, half = hs / 2;
+    const int n0 = tile[0] * 16 + col;  // column in the fused qkv output
+    const int h = n0 / hs, d = n0 - h * hs;  // d < half
+    const int pos = a.row_pos[mr];
+    const float x1 = v[0], x2 = v[1];
+    if (h < a.kv.n_head + a.kv.n_kv) {
+      const float cs = a.rope_cos[(size_t)pos * half + d], sn = a.rope_sin[(size_t)pos * half + d];
+      // roped = x*cos + rotate_half(x)*sin  (lit_model.py:795-806), products rounded separately
+      const float lo = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn));
+      const float hi = __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
+      if (h < a.kv.n_head) {
+        float* q = a.q_out + (size_t)mr * a.kv.n_head * hs + (size_t)h * hs;
+        q[d] = lo;
+        q[d + half] = hi;
+      } else {
+        const int kvh = h - a.kv.n_head;
+        const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
+        const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
+        store_elem<DT>(a.kv.k_pool, base + d, lo);
+        store_elem<DT>(a.kv.k_pool, base + d + half, hi);
+      }
+    } else {
+      const int kvh = h - a.kv.n_head - a.kv.n_kv;
+      const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
+      const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
+      store_elem<DT>(a.kv.v_pool, base + d, x1);
+      store_elem<DT>(a.kv.v_pool, base + d + half, x2);
+    }
+  }
+}
+
+template <int DT, int PRO>
+int launch_epi(const ua2_linear_args& a, hipStream_t s) {
+  const int ntiles = ua2_ceil_div(a.N, 16);
+  const dim3 block(kThreads);
+  const int mtiles = ua2_ceil_div(a.M, 16);
+  switch (a.epilogue) {
+    case UA2_EPI_STORE:
+      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_STORE>), dim3(ntiles, mtiles), block, 0, s, a);
+      break;
+    case UA2_EPI_RESIDUAL:
+      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_RESIDUAL>), dim3(ntiles, mtiles), block, 0, s, a);
+      break;
+    case UA2_EPI_SWIGLU:
+      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_SWIGLU>), dim3(ntiles, mtiles), block, 0, s, a);
+      break;
+    case UA2_EPI_QKV_ROPE:
+      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_QKV_ROPE>), dim3(ntiles / 2, mtiles), block, 0, s, a);
+      break;
+    default:
+      ua2_set_error("ua2_linear: bad epilogue %d", a.epilogue);
+      return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DT>
+int launch_pro(const ua2_linear_args& a, hipStream_t s) {
+  switch (a.prologue) {
+    case UA2_PRO_CAST: return launch_epi<DT, UA2_PRO_CAST>(a, s);
+    case UA2_PRO_NORM: return launch_epi<DT, UA2_PRO_NORM>(a, s);
+    case UA2_PRO_ATTN: return launch_epi<DT, UA2_PRO_ATTN>(a, s);
+  }
+  ua2_set_error("ua2_linear: bad prologue %d", a.prologue);
+  return -1;
+}
+
+}  // namespace
+
+int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
+  UA2_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "ua2_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  UA2_CHECK(a.w0 != nullptr, "ua2_linear: w0 is NULL");
+  const int epl = a.dtype == UA2_BF16 ? 8 : 4;
+  UA2_CHECK(a.K % epl == 0, "ua2_linear: K=%d must be a multiple of %d", a.K, epl);
+  if (a.prologue != UA2_PRO_ATTN) {
+    UA2_CHECK(a.x != nullptr && a.ldx % 4 == 0, "ua2_linear: x NULL or ldx %% 4 != 0");
+  } else {
+    UA2_CHECK(a.attn_o && a.attn_ml && a.row_pos && a.kv.head_size % 16 == 0 &&
+                  a.K == a.kv.n_head * a.kv.head_size,
+              "ua2_linear: bad ATTN prologue arguments");
+  }
+  if (a.prologue == UA2_PRO_NORM) UA2_CHECK(a.norm_w != nullptr, "ua2_linear: norm_w is NULL");
+  if (a.epilogue == UA2_EPI_SWIGLU) UA2_CHECK(a.w1 != nullptr && a.y != nullptr, "ua2_linear: SWIGLU needs w1, y");
+  if (a.epilogue == UA2_EPI_RESIDUAL) UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
+  if (a.epilogue == UA2_EPI_STORE) UA2_CHECK(a.y != nullptr || a.part_max != nullptr, "ua2_linear: STORE needs y or part_max");
+  if (a.epilogue == UA2_EPI_QKV_ROPE) {
+    UA2_CHECK(a.kv.head_size % 32 == 0 && a.N == (a.kv.n_head + 2 * a.kv.n_kv) * a.kv.head_size,
+              "ua2_linear: QKV_ROPE needs head_size %% 32 == 0 and N == (n_head+2*n_kv)*head_size");
+    UA2_CHECK(a.row_pos && a.row_seq && a.rope_cos && a.rope_sin && a.q_out && a.kv.k_pool && a.kv.v_pool &&
+                  a.kv.page_table,
+              "ua2_linear: QKV_ROPE pointer arguments missing");
+  }
+  if (a.dtype == UA2_BF16) return launch_pro<UA2_BF16>(a, s);
+  if (a.dtype == UA2_F32) return launch_pro<UA2_F32>(a, s);
+  ua2_set_error("ua2_linear: bad dtype %d", a.dtype);
+  return -1;
+}
+
+extern "C" int ua2_linear(const ua2_linear_args* a, void* stream) {
+  UA2_CHECK(a != nullptr, "ua2_linear: NULL args");
+  return ua2_linear_launch(*a, (hipStream_t)stream);
+}
+
+extern "C" size_t ua2_packed_elems(int dtype, int64_t N, int64_t K) {
+  const int kc = dtype == UA2_BF16 ? 32 : 16, epl = dtype == UA2_BF16 ? 8 : 4;
+  return (size_t)((N + 15) / 16) * (size_t)((K + kc - 1) / kc) * 64 * epl;
+}
+
+extern "C" int ua2_pack_linear(const void* src, int src_dtype, int transposed, int64_t N, int64_t K, void* out,
+                               int dtype, void* stream) {
+  UA2_CHECK(src && out && N > 0 && K > 0, "ua2_pack_linear: bad arguments");
+  const int64_t total = (int64_t)ua2_packed_elems(dtype, N, K);
+  const int threads = 256;
+  const int blocks = (int)((total + threads - 1) / threads < 65535 * 16 ? (total + threads - 1) / threads : 65535 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == UA2_F32 && dtype == UA2_F32)
+    hipLaunchKernelGGL((pack_kernel<UA2_F32, UA2_F32>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+  else if (src_dtype == UA2_F32 && dtype == UA2_BF16)
+    hipLaunchKernelGGL((pack_kernel<UA2_F32, UA2_BF16>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+  else if (src_dtype == UA2_BF16 && dtype == UA2_BF16)
+    hipLaunchKernelGGL((pack_kernel<UA2_BF16, UA2_BF16>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+  else if (src_dtype == UA2_BF16 && dtype == UA2_F32)
+    hipLaunchKernelGGL((pack_kernel<UA2_BF16, UA2_F32>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+  else {
+    ua2_set_error("ua2_pack_linear: bad dtypes %d -> %d", src_dtype, dtype);
+    return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}

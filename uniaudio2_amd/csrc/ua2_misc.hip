@@ -1,0 +1,150 @@
+// Small row-wise kernels of the decode frame: embedding merge, final-norm + step-mask blends,
+// greedy sampling tail + next-step embedding gather.  All are a few KB of traffic; what matters
+// is that each replaces a chain of 5-10 tiny PyTorch launches in the reference with one.
+#include <stdarg.h>
+
+#include "ua2_common.h"
+
+static thread_local char g_err[512] = "";
+
+void ua2_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ua2_last_error(void) { return g_err; }
+extern "C" int ua2_version(void) { return UA2_VERSION; }
+
+namespace {
+
+// model_new.py:594-600 (_embed_audio_tokens + masked sum over the 8 streams), :604 (wte)
+template <int DT>
+__global__ void embed_frame_kernel(int C, int ncb, int va, const int32_t* __restrict__ tokens,
+                                   const uint8_t* __restrict__ mask, const void* __restrict__ audio_emb,
+                                   const void* __restrict__ wte, float* __restrict__ audio_sum,
+                                   float* __restrict__ text) {
+  const int m = blockIdx.x;
+  const int32_t* tk = tokens + (size_t)m * (ncb + 1);
+  const uint8_t* mk = mask + (size_t)m * (ncb + 1);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < ncb; ++i) {  // (audio_embeds * mask).sum(dim=2): i = 0..7 in order
+      const float e = load_elem<DT>(audio_emb, ((size_t)tk[i] + (size_t)i * va) * C + c);
+      s += mk[i] ? e : 0.f;
+    }
+    audio_sum[(size_t)m * C + c] = s;
+    text[(size_t)m * C + c] = load_elem<DT>(wte, (size_t)tk[ncb] * C + c);
+  }
+}
+
+// lit_model.py:883-890 (ln_f, :164) + model_new.py:607,610,613 blends
+__global__ void rmsnorm_blend_kernel(int C, const float* __restrict__ x, const float* __restrict__ w, float eps,
+                                     const float* __restrict__ other, const uint8_t* __restrict__ mask, int mask_ld,
+                                     int col_a, int col_b, float* __restrict__ out1, float* __restrict__ out2) {
+  __shared__ float part[4];
+  const int m = blockIdx.x;
+  const float* xr = x + (size_t)m * C;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) ss += xr[c] * xr[c];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = ((part[0] + part[1]) + part[2]) + part[3];
+  const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+  const float fa = (col_a >= 0) ? (float)mask[(size_t)m * mask_ld + col_a] : 1.f;
+  const float fb = other ? (float)mask[(size_t)m * mask_ld + col_b] : 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float n = __fmul_rn(__fmul_rn(xr[c], rstd), w[c]);
+    float o1 = __fmul_rn(n, fa);
+    if (other) o1 = __fadd_rn(o1, __fmul_rn(other[(size_t)m * C + c], fb));
+    out1[(size_t)m * C + c] = o1;
+    if (out2) out2[(size_t)m * C + c] = n;
+  }
+}
+
+// model_new.py:146-187 at topk=1 (masked arg-max; lowest index on ties) + :640,662-663 (_embed_audio)
+template <int DT>
+__global__ void argmax_embed_kernel(int n_part, const float* __restrict__ pmax, const int32_t* __restrict__ pidx,
+                                    int32_t* __restrict__ out_tokens, int out_ld, int out_col,
+                                    const void* __restrict__ emb, int emb_off, int C, float* __restrict__ next_h) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int tok_s;
+  const int m = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int p = threadIdx.x; p < n_part; p += blockDim.x) {
+    const float v = pmax[(size_t)m * n_part + p];
+    const int i = pidx[(size_t)m * n_part + p];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    tok_s = bi;
+    out_tokens[(size_t)m * out_ld + out_col] = bi;
+  }
+  __syncthreads();
+  if (emb) {
+    const size_t row = (size_t)tok_s + (size_t)emb_off;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) next_h[(size_t)m * C + c] = load_elem<DT>(emb, row * C + c);
+  }
+}
+
+}  // namespace
+
+extern "C" int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, int32_t va, const int32_t* tokens,
+                               const uint8_t* mask, const void* audio_emb, const void* wte, float* audio_sum,
+                               float* text, void* stream) {
+  UA2_CHECK(M > 0 && C > 0 && tokens && mask && audio_emb && wte && audio_sum && text, "ua2_embed_frame: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UA2_BF16)
+    hipLaunchKernelGGL((embed_frame_kernel<UA2_BF16>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+  else if (dtype == UA2_F32)
+    hipLaunchKernelGGL((embed_frame_kernel<UA2_F32>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+  else {
+    ua2_set_error("ua2_embed_frame: bad dtype %d", dtype);
+    return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ua2_rmsnorm_blend(int32_t M, int32_t C, const float* x, const float* w, float eps, const float* other,
+                                 const uint8_t* mask, int32_t mask_ld, int32_t col_a, int32_t col_b, float* out1,
+                                 float* out2, void* stream) {
+  UA2_CHECK(M > 0 && C > 0 && x && w && out1, "ua2_rmsnorm_blend: bad arguments");
+  UA2_CHECK((col_a < 0 && !other) || mask, "ua2_rmsnorm_blend: mask needed");
+  hipLaunchKernelGGL(rmsnorm_blend_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, C, x, w, eps, other, mask,
+                     mask_ld, col_a, col_b, out1, out2);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const float* part_max, const int32_t* part_idx,
+                                int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb,
+                                int32_t emb_row_offset, int32_t C, float* next_h, void* stream) {
+  UA2_CHECK(M > 0 && n_part > 0 && part_max && part_idx && out_tokens, "ua2_argmax_embed: bad arguments");
+  UA2_CHECK(!emb || next_h, "ua2_argmax_embed: next_h is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UA2_BF16)
+    hipLaunchKernelGGL((argmax_embed_kernel<UA2_BF16>), dim3(M), dim3(256), 0, s, n_part, part_max, part_idx, out_tokens, out_ld, out_col, emb, emb_row_offset, C, next_h);
+  else if (dtype == UA2_F32)
+    hipLaunchKernelGGL((argmax_embed_kernel<UA2_F32>), dim3(M), dim3(256), 0, s, n_part, part_max, part_idx, out_tokens, out_ld, out_col, emb, emb_row_offset, C, next_h);
+  else {
+    ua2_set_error("ua2_argmax_embed: bad dtype %d", dtype);
+    return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}

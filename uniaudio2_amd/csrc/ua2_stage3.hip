@@ -1,0 +1,286 @@
+// Whole-frame executor for Model_stage3's inference methods (llm_models/model_new.py:456-507
+// forward_prefix, :568-645 generate_frame) and the generators' per-frame feedback
+// (evaluation/tts_task.py:259-280, evaluation/asr_task.py:668-682).
+//
+// One C call issues every kernel of a frame on the caller's stream; all per-frame state
+// (input tokens, step masks, positions, forbid_prefix, sampled ids, the frame log) lives in
+// device memory, so the launch sequence is identical from frame to frame and is captured once
+// into a hipGraph and replayed: no host round trip between the 350-odd kernels of a frame and
+// none between frames (the reference synchronises twice per frame, tts_task.py:261,263).
+#include <map>
+#include <string.h>
+#include <tuple>
+#include <vector>
+
+#include "ua2_common.h"
+
+struct ua2_stage3 {
+  ua2_stage3_desc d;
+  // deep copies of the per-layer pointer arrays
+  std::vector<const void*> ptrs[4][5];
+  std::vector<const float*> norms[4][2];
+  std::vector<void*> pools[4][2];
+  std::vector<const void*> audio_head;
+  // scratch carve
+  float *xa, *text, *xb, *hbuf, *xg, *hfin, *q, *act, *attn_o, *attn_ml, *xd, *curr_h;
+  float *text_logits, *audio_logits, *pmax_t, *pmax_a;
+  int32_t *pidx_t, *pidx_a;
+  int32_t npart_t, npart_a;
+  int32_t grid_pages;
+  std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+};
+
+namespace {
+
+size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+struct Carve {
+  size_t xa, text, xb, hbuf, xg, hfin, q, act, attn_o, attn_ml, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
+      pmax_a, pidx_a, total;
+};
+
+Carve carve(const ua2_stage3_desc& d) {
+  Carve c;
+  const size_t R = d.max_rows;
+  const ua2_gpt_desc* gs[4] = {&d.und, &d.backbone, &d.gen, &d.decoder};
+  size_t C = d.backbone.n_embd, Cd = d.decoder.n_embd, qmax = 0, actmax = 0, ao = 0, aml = 0;
+  for (auto g : gs) {
+    qmax = std::max(qmax, (size_t)g->n_head * g->head_size);
+    actmax = std::max(actmax, (size_t)g->inter);
+    ao = std::max(ao, (size_t)g->n_head * g->max_pages * g->head_size);
+    aml = std::max(aml, (size_t)g->n_head * g->max_pages * 2);
+  }
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
+  c.xa = take(R * C); c.text = take(R * C); c.xb = take(R * C); c.hbuf = take(R * C); c.xg = take(R * C);
+  c.hfin = take(R * C); c.q = take(R * qmax); c.act = take(R * actmax); c.attn_o = take(R * ao);
+  c.attn_ml = take(R * aml); c.xd = take(d.max_batch * Cd); c.curr_h = take(d.max_batch * C);
+  const size_t npt = (d.vt + 15) / 16, npa = (d.va + 15) / 16, Bm = d.max_batch;
+  c.text_logits = take(Bm * d.vt); c.audio_logits = take(Bm * d.n_cb * d.va);
+  c.pmax_t = take(Bm * npt); c.pidx_t = take(Bm * npt); c.pmax_a = take(Bm * npa); c.pidx_a = take(Bm * npa);
+  c.total = off;
+  return c;
+}
+
+int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
+            const int32_t* row_seq, int grid_pages, hipStream_t s) {
+  const int dt = h->d.dtype;
+  const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
+  for (int l = 0; l < g.n_layer; ++l) {
+    ua2_kv_geom kv;
+    kv.k_pool = h->pools[gi][0][l]; kv.v_pool = h->pools[gi][1][l]; kv.page_table = g.page_table;
+    kv.max_pages = g.max_pages; kv.n_kv = g.n_kv; kv.n_head = g.n_head; kv.head_size = g.head_size;
+
+    ua2_linear_args a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_QKV_ROPE;
+    a.M = R; a.N = nqkv; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][0][l]; a.eps = g.eps;
+    a.w0 = h->ptrs[gi][0][l]; a.row_pos = row_pos; a.row_seq = row_seq; a.rope_cos = g.rope_cos;
+    a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
+    if (int rc = ua2_linear_launch(a, s)) return rc;
+
+    ua2_attn_args at;
+    memset(&at, 0, sizeof(at));
+    at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.attn_o = h->attn_o;
+    at.attn_ml = h->attn_ml; at.grid_pages = std::min(grid_pages, g.max_pages); at.kv = kv;
+    if (int rc = ua2_attn_launch(at, s)) return rc;
+
+    memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.prologue = UA2_PRO_ATTN; a.epilogue = UA2_EPI_RESIDUAL;
+    a.M = R; a.N = C; a.K = qn; a.attn_o = h->attn_o; a.attn_ml = h->attn_ml; a.row_pos = row_pos; a.kv = kv;
+    a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
+    if (int rc = ua2_linear_launch(a, s)) return rc;
+
+    memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_SWIGLU;
+    a.M = R; a.N = g.inter; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][1][l]; a.eps = g.eps;
+    a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.y = h->act; a.ldy = g.inter;
+    if (int rc = ua2_linear_launch(a, s)) return rc;
+
+    memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
+    a.M = R; a.N = C; a.K = g.inter; a.x = h->act; a.ldx = g.inter; a.w0 = h->ptrs[gi][4][l];
+    a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
+    if (int rc = ua2_linear_launch(a, s)) return rc;
+  }
+  return 0;
+}
+
+__global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int reason_card, int log_frames,
+                                int max_rows, int32_t* __restrict__ tokens, uint8_t* __restrict__ mask,
+                                int32_t* __restrict__ row_pos, int32_t* __restrict__ forbid,
+                                const int32_t* __restrict__ out, int32_t* __restrict__ log, int32_t* counters) {
+  const int frame = counters[0];
+  const int w = ncb + 1;
+  for (int m = threadIdx.x; m < R; m += blockDim.x) {
+    const int32_t* o = out + (size_t)m * w;
+    if (frame < log_frames)
+      for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = o[j];
+    bool all_reason_eos = true;
+    for (int i = 0; i < ncb; ++i) {
+      all_reason_eos = all_reason_eos && (o[1 + i] == reason_eos);
+      tokens[(size_t)m * w + i] = (mode == 0) ? o[1 + i] : 0;
+      mask[(size_t)m * w + i] = (mode == 0) ? 1 : 0;
+    }
+    tokens[(size_t)m * w + ncb] = o[0];
+    mask[(size_t)m * w + ncb] = (mode == 0) ? 0 : 1;
+    row_pos[m] += 1;
+    if (mode == 0 && all_reason_eos) forbid[m] = reason_card;  // tts_task.py:263-266
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counters[0] = frame + 1;
+}
+
+}  // namespace
+
+extern "C" size_t ua2_stage3_scratch_floats(const ua2_stage3_desc* d) { return d ? carve(*d).total : 0; }
+
+extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
+  UA2_CHECK(d && out, "ua2_stage3_create: NULL argument");
+  const Carve c = carve(*d);
+  UA2_CHECK(d->scratch && d->scratch_floats >= c.total, "ua2_stage3_create: scratch too small (%zu < %zu floats)",
+            d->scratch_floats, c.total);
+  UA2_CHECK(d->max_batch > 0 && d->max_batch <= d->max_rows, "ua2_stage3_create: need 0 < max_batch <= max_rows");
+  UA2_CHECK(d->und.n_embd == d->backbone.n_embd && d->gen.n_embd == d->backbone.n_embd,
+            "ua2_stage3_create: expert width must equal backbone width (model_new.py:607,613)");
+  ua2_stage3* h = new ua2_stage3();
+  h->d = *d;
+  const ua2_gpt_desc* gs[4] = {&d->und, &d->backbone, &d->gen, &d->decoder};
+  ua2_gpt_desc* hs[4] = {&h->d.und, &h->d.backbone, &h->d.gen, &h->d.decoder};
+  for (int gi = 0; gi < 4; ++gi) {
+    const ua2_gpt_desc& g = *gs[gi];
+    const void* const* src[5] = {g.qkv, g.proj, g.fc1, g.fc2, g.mlp_proj};
+    for (int k = 0; k < 5; ++k) h->ptrs[gi][k].assign(src[k], src[k] + g.n_layer);
+    h->norms[gi][0].assign(g.norm1, g.norm1 + g.n_layer);
+    h->norms[gi][1].assign(g.norm2, g.norm2 + g.n_layer);
+    h->pools[gi][0].assign(g.k_pool, g.k_pool + g.n_layer);
+    h->pools[gi][1].assign(g.v_pool, g.v_pool + g.n_layer);
+    hs[gi]->qkv = hs[gi]->proj = hs[gi]->fc1 = hs[gi]->fc2 = hs[gi]->mlp_proj = nullptr;  // use the copies
+  }
+  h->audio_head.assign(d->audio_head, d->audio_head + d->n_cb);
+  float* b = d->scratch;
+  h->xa = b + c.xa; h->text = b + c.text; h->xb = b + c.xb; h->hbuf = b + c.hbuf; h->xg = b + c.xg;
+  h->hfin = b + c.hfin; h->q = b + c.q; h->act = b + c.act; h->attn_o = b + c.attn_o; h->attn_ml = b + c.attn_ml;
+  h->xd = b + c.xd; h->curr_h = b + c.curr_h; h->text_logits = b + c.text_logits;
+  h->audio_logits = b + c.audio_logits; h->pmax_t = b + c.pmax_t; h->pidx_t = (int32_t*)(b + c.pidx_t);
+  h->pmax_a = b + c.pmax_a; h->pidx_a = (int32_t*)(b + c.pidx_a);
+  h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
+  h->grid_pages = d->backbone.max_pages;
+  *out = h;
+  return 0;
+}
+
+extern "C" void ua2_stage3_destroy(ua2_stage3* h) {
+  if (!h) return;
+  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  delete h;
+}
+
+extern "C" int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages) {
+  UA2_CHECK(h && pages > 0 && pages <= h->d.backbone.max_pages, "ua2_stage3_set_grid_pages: bad value %d", pages);
+  h->grid_pages = pages;
+  return 0;
+}
+
+extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
+  UA2_CHECK(h && R > 0 && R <= h->d.max_rows, "ua2_stage3_trunk: R=%d out of range", R);
+  hipStream_t s = (hipStream_t)stream;
+  const ua2_stage3_desc& d = h->d;
+  const int C = d.backbone.n_embd, w = d.n_cb + 1;
+  if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, s)) return rc;
+  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
+  // backbone_input = h_audio*audio_step + text_embeds*text_step   (model_new.py:607)
+  if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, s)) return rc;
+  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
+  // h = ln_f(x); generation_input = h*audio_step                   (model_new.py:609-610)
+  if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, s)) return rc;
+  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
+  // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
+  if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, s)) return rc;
+  return 0;
+}
+
+extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
+  UA2_CHECK(h && R > 0 && R <= h->d.max_batch, "ua2_stage3_heads: R=%d out of range", R);
+  hipStream_t s = (hipStream_t)stream;
+  const ua2_stage3_desc& d = h->d;
+  const int C = d.backbone.n_embd, Cd = d.decoder.n_embd, w = d.n_cb + 1;
+  ua2_linear_args a;
+  // text_logits = lm_head(last_h); greedy text sample             (model_new.py:617,623)
+  memset(&a, 0, sizeof(a));
+  a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
+  a.M = R; a.N = d.vt; a.K = C; a.x = h->hfin; a.ldx = C; a.w0 = d.lm_head; a.y = h->text_logits; a.ldy = d.vt;
+  a.part_max = h->pmax_t; a.part_idx = h->pidx_t;
+  if (int rc = ua2_linear_launch(a, s)) return rc;
+  if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr, s)) return rc;
+  const float* curr = h->hfin;
+  for (int i = 0; i < d.n_cb; ++i) {                               // model_new.py:630-641
+    memset(&a, 0, sizeof(a));
+    a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
+    a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
+    if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, d.dec_seq, 1, s)) return rc;
+    memset(&a, 0, sizeof(a));
+    a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
+    a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
+    a.w0 = h->audio_head[i]; a.y = h->audio_logits + (size_t)i * d.va; a.ldy = d.n_cb * d.va;
+    a.part_max = h->pmax_a; a.part_idx = h->pidx_a; a.forbid = d.forbid;
+    if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
+                                  i * d.va, C, h->curr_h, s)) return rc;
+    curr = h->curr_h;
+  }
+  return 0;
+}
+
+extern "C" int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
+                                   void* stream) {
+  UA2_CHECK(h && R > 0 && R <= h->d.max_rows && (mode == 0 || mode == 1), "ua2_stage3_feedback: bad arguments");
+  const ua2_stage3_desc& d = h->d;
+  hipLaunchKernelGGL(feedback_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, R, d.n_cb, mode, reason_eos,
+                     reason_card, d.log_frames, d.max_rows, d.tokens, d.mask, d.row_pos, d.forbid, d.out_tokens,
+                     d.frame_log, d.counters);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
+                                int32_t use_graph, void* stream) {
+  UA2_CHECK(h != nullptr, "ua2_stage3_frame: NULL handle");
+  hipStream_t s = (hipStream_t)stream;
+  auto body = [&]() -> int {
+    if (int rc = ua2_stage3_trunk(h, R, s)) return rc;
+    if (int rc = ua2_stage3_heads(h, R, s)) return rc;
+    if (mode < 0) return 0;
+    return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, s);
+  };
+  if (!use_graph) return body();
+  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages);
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    UA2_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) return rc;
+    if (e != hipSuccess) {
+      ua2_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      return -2;
+    }
+    hipGraphExec_t exec = nullptr;
+    UA2_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    it = h->graphs.emplace(key, exec).first;
+  }
+  UA2_HIP(hipGraphLaunch(it->second, s));
+  return 0;
+}
+
+extern "C" float* ua2_stage3_buffer(ua2_stage3* h, const char* name) {
+  if (!h || !name) return nullptr;
+  if (!strcmp(name, "h_final")) return h->hfin;
+  if (!strcmp(name, "text_logits")) return h->text_logits;
+  if (!strcmp(name, "audio_logits")) return h->audio_logits;
+  if (!strcmp(name, "h")) return h->hbuf;
+  return nullptr;
+}

@@ -1,0 +1,264 @@
+"""Audio-text LM of the decode loop, host side.
+
+Mirror of the reference's llm_models/model_new.py `Model_stage3` (:334-687) for its inference
+methods: `setup_caches` (:554-565), `reset_caches` (:647-651), `forward_prefix` (:456-507),
+`generate_frame` (:568-645) keep their signatures, the state-dict keys are identical
+(`backbone.*`, `decoder.*`, `audio_understanding_expert.*`, `audio_generation_expert.*`,
+`audio_embeddings.weight`, `projection.weight`, `audio_head`), so a reference checkpoint loads
+with `load_state_dict`.
+
+All arithmetic runs in libua2hip.so through the frame executor (include/ua2hip.h
+ua2_stage3_*): one C call per prefill chunk / per frame, hipGraph replay for the frame.
+`generate_frames` is the MI355X-native fast path the generators use: N frames back to back
+with the sample -> next-input feedback, forbid_prefix switch and frame log all on device.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import Stage3Desc, check, lib, vp
+from .config import Config as gpt_config
+from .lit_model import GPT
+
+
+@dataclass
+class ModelArgs:
+    llm_name: str
+    decoder_name: str
+    llm_pretrained_model: str
+    audio_embeddings_path: str
+    audio_understanding_expert_path: str
+    audio_semantic_vocab_size: int
+    audio_reason_vocab_size: int
+    audio_num_codebooks: int
+
+
+class Model_stage3(nn.Module):
+    """Stage 3: text-audio joint model (inference)."""
+
+    def __init__(self, config: ModelArgs, device=None):
+        super().__init__()
+        self.config = config
+        self.backbone = GPT(gpt_config.from_name(config.llm_name), device=device)
+        backbone_dim = self.backbone.config.n_embd
+        self.decoder = GPT(gpt_config.from_name(config.decoder_name), device=device, with_embeddings=False)
+        decoder_dim = self.decoder.config.n_embd
+        va = config.audio_semantic_vocab_size + config.audio_reason_vocab_size
+        self.audio_embeddings = nn.Embedding(va * config.audio_num_codebooks, backbone_dim, device=device)
+        self.projection = nn.Linear(backbone_dim, decoder_dim, bias=False, device=device)
+        self.audio_head = nn.Parameter(torch.empty(config.audio_num_codebooks, decoder_dim, va, device=device))
+        self.audio_understanding_expert = GPT(gpt_config.from_name("meta-llama/Llama-3.2-Understanding"),
+                                              device=device, with_embeddings=False)
+        self.audio_generation_expert = GPT(gpt_config.from_name("meta-llama/Llama-3.2-Generation"),
+                                           device=device, with_embeddings=False)
+        self._h = None
+        self._st = None
+
+    # ---- caches / device plan ----------------------------------------------------------------
+    def setup_caches(self, max_batch_size: int, dtype: Optional[torch.dtype] = None, max_seq_length: int = 2048,
+                     max_rows: Optional[int] = None, log_frames: int = 512):
+        """model_new.py:554-565: 2048-slot caches for the three 3072-d GPTs, `audio_num_codebooks`
+        slots for the local decoder.  `dtype` selects the kernel precision (default: the
+        parameters' dtype, as in the reference where `.to(dtype)` decides)."""
+        p0 = self.projection.weight
+        device, dtype = p0.device, (dtype or p0.dtype)
+        if device.type != "cuda":
+            raise RuntimeError("uniaudio2_amd runs on a ROCm device only (no CPU fallback); call model.to('cuda')")
+        cfg = self.config
+        ncb, va = cfg.audio_num_codebooks, cfg.audio_semantic_vocab_size + cfg.audio_reason_vocab_size
+        B = max_batch_size
+        max_rows = max(max_rows or 64, B)
+        self._destroy()
+        for g in (self.audio_understanding_expert, self.backbone, self.audio_generation_expert):
+            g.set_kv_cache(B, max_seq_length=max_seq_length, device=device, dtype=dtype)
+        self.decoder.set_kv_cache(B, max_seq_length=ncb, device=device, dtype=dtype)
+        st = dict(dtype=dtype, device=device, B=B, max_rows=max_rows, log_frames=log_frames, ncb=ncb, va=va)
+        cast = lambda t: t.detach().to(device=device, dtype=dtype).contiguous()
+        st["wte"] = cast(self.backbone.transformer.wte.weight)
+        st["audio_emb"] = cast(self.audio_embeddings.weight)
+        st["lm_head"] = ops.pack_linear(self.backbone.lm_head.weight.detach(), dtype)
+        st["projection"] = ops.pack_linear(self.projection.weight.detach(), dtype)
+        st["audio_head"] = [ops.pack_linear(self.audio_head[i].detach(), dtype, transposed=True) for i in range(ncb)]
+        i32 = dict(dtype=torch.int32, device=device)
+        st["tokens"] = torch.zeros(max_rows, ncb + 1, **i32)
+        st["mask"] = torch.zeros(max_rows, ncb + 1, dtype=torch.uint8, device=device)
+        st["row_pos"] = torch.zeros(max_rows, **i32)
+        st["row_seq"] = torch.zeros(max_rows, **i32)
+        st["dec_pos"] = torch.arange(ncb, **i32).unsqueeze(1).expand(ncb, max_rows).contiguous()
+        st["dec_seq"] = torch.arange(max_rows, **i32)
+        st["forbid"] = torch.zeros(max_rows, **i32)
+        st["out_tokens"] = torch.zeros(max_rows, ncb + 1, **i32)
+        st["frame_log"] = torch.zeros(log_frames, max_rows, ncb + 1, **i32)
+        st["counters"] = torch.zeros(4, **i32)
+
+        d = Stage3Desc()
+        d.dtype, d.n_cb, d.va, d.vt = ops.dtype_code(dtype), ncb, va, self.backbone.config.padded_vocab_size
+        d.max_rows, d.max_batch = max_rows, B
+        gd = [self.audio_understanding_expert.desc(), self.backbone.desc(), self.audio_generation_expert.desc(),
+              self.decoder.desc()]
+        d.und, d.backbone, d.gen, d.decoder = gd
+        d.wte, d.audio_emb = st["wte"].data_ptr(), st["audio_emb"].data_ptr()
+        d.lm_head, d.projection = st["lm_head"].data_ptr(), st["projection"].data_ptr()
+        ah = (vp * ncb)(*[t.data_ptr() for t in st["audio_head"]])
+        d.audio_head = ah
+        for k in ("tokens", "mask", "row_pos", "row_seq", "dec_pos", "dec_seq", "forbid", "out_tokens", "frame_log",
+                  "counters"):
+            setattr(d, k, st[k].data_ptr())
+        d.log_frames = log_frames
+        n = lib.ua2_stage3_scratch_floats(C.byref(d))
+        st["scratch"] = torch.empty(n, dtype=torch.float32, device=device)
+        d.scratch, d.scratch_floats = st["scratch"].data_ptr(), n
+        h = vp()
+        check(lib.ua2_stage3_create(C.byref(d), C.byref(h)), "ua2_stage3_create")
+        st["keep"] = (d, gd, ah)
+        self._h, self._st = h, st
+        self._grid_pages = None
+
+    def _destroy(self):
+        if self._h is not None:
+            lib.ua2_stage3_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def reset_caches(self):
+        """model_new.py:647-651."""
+        self._need()
+        st = self._st
+        st["counters"].zero_()
+        st["forbid"].zero_()
+
+    def _need(self):
+        if self._h is None:
+            raise TypeError("You need to call `model.setup_caches()`")
+
+    def _set_grid_pages(self, max_pos: int):
+        pages = min(self.backbone.kv_cache.max_pages, max_pos // ops.UA2_PAGE + 1)
+        if pages != self._grid_pages:
+            check(lib.ua2_stage3_set_grid_pages(self._h, pages), "ua2_stage3_set_grid_pages")
+            self._grid_pages = pages
+
+    def _load_rows(self, tokens, tokens_mask, pos, seq):
+        """tokens (R, 9) any int dtype, mask (R, 9) bool, pos (R,), seq (R,) -> device state."""
+        st = self._st
+        R = tokens.shape[0]
+        st["tokens"][:R].copy_(tokens)
+        st["mask"][:R].copy_(tokens_mask)
+        st["row_pos"][:R].copy_(pos)
+        st["row_seq"][:R].copy_(seq)
+        return R
+
+    # ---- reference-compatible methods ---------------------------------------------------------
+    @torch.inference_mode()
+    def forward_prefix(self, tokens: torch.Tensor, labels: torch.Tensor = None, tokens_mask: torch.Tensor = None,
+                       loss_mask: torch.Tensor = None, input_pos=None, input_pos_maxp1=None):
+        """model_new.py:456-507 — fills the KV caches of the three trunk GPTs for `tokens`
+        (B, S, 9) at `input_pos` (B, S).  `tokens_mask` is (B, S+1, 9) as the generators pass it
+        (evaluation/tts_task.py:244); only [:, :-1] is used (:476-480).  The reference's lm_head /
+        local-decoder pass over the prefix (:498-506) produces values every caller discards and is
+        skipped; returns None."""
+        self._need()
+        st = self._st
+        B, S, W = tokens.shape
+        if input_pos is None:
+            input_pos = torch.arange(S, device=tokens.device).unsqueeze(0).expand(B, S)
+        mask = tokens_mask[:, :S]
+        seq = torch.arange(B, device=tokens.device).unsqueeze(1).expand(B, S)
+        tk, mk = tokens.reshape(B * S, W), mask.reshape(B * S, W)
+        ps, sq = input_pos.reshape(-1), seq.reshape(-1)
+        # time-major chunks so every chunk only needs KV of earlier chunks
+        order = torch.argsort(ps, stable=True)
+        tk, mk, ps, sq = tk[order], mk[order], ps[order], sq[order]
+        self._set_grid_pages(int(ps.max().item()))
+        R, mr = B * S, st["max_rows"]
+        for s0 in range(0, R, mr):
+            n = self._load_rows(tk[s0:s0 + mr], mk[s0:s0 + mr], ps[s0:s0 + mr], sq[s0:s0 + mr])
+            check(lib.ua2_stage3_trunk(self._h, n, ops.stream()), "ua2_stage3_trunk")
+        return None
+
+    @torch.inference_mode()
+    def generate_frame(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, input_pos: torch.Tensor,
+                       input_pos_maxp1=None, temperature: float = 1.0, topk: int = 1, forbid_prefix: int = 0,
+                       cfg_scale: float = 1.0) -> torch.Tensor:
+        """model_new.py:568-645.  tokens (B, 1, 9), tokens_mask (B, 1, 9), input_pos (1,) shared
+        or (B,) per sequence.  Returns (B, 9) int32 [text, a0..a7] on device."""
+        self._need()
+        if topk != 1:
+            raise NotImplementedError("only greedy decoding (topk=1, BASELINE.json metric) is built in this round")
+        if cfg_scale > 1.0 and tokens.size(0) > 1:
+            raise NotImplementedError("classifier-free guidance logit mixing (model_new.py:618-622) is not built yet")
+        if temperature <= 0:
+            raise ValueError("temperature must be > 0")
+        st = self._st
+        B, S, W = tokens.shape
+        assert S == 1 and W == st["ncb"] + 1, "last stream must be text"
+        pos = input_pos.reshape(-1)
+        if pos.numel() == 1:
+            pos = pos.expand(B)
+        seq = torch.arange(B, device=tokens.device)
+        self._load_rows(tokens.reshape(B, W), tokens_mask.reshape(B, W), pos, seq)
+        st["forbid"][:B].fill_(int(forbid_prefix))
+        self._set_grid_pages(int(input_pos_maxp1) if input_pos_maxp1 is not None else int(pos.max().item()) + 1)
+        check(lib.ua2_stage3_frame(self._h, B, -1, 0, 0, 1, ops.stream()), "ua2_stage3_frame")
+        return st["out_tokens"][:B].clone()
+
+    # ---- MI355X-native fast path ---------------------------------------------------------------
+    @torch.inference_mode()
+    def generate_frames(self, n_frames: int, batch: int, mode: int, reason_eos: int = -1, reason_card: int = 0,
+                        max_pos: Optional[int] = None, use_graph: bool = True) -> torch.Tensor:
+        """Runs `n_frames` frames back to back from the state left by the previous frame (first
+        call: after `begin_decode`).  mode 0 = audio feedback (evaluation/tts_task.py:259-280),
+        1 = text feedback (evaluation/asr_task.py:668-682).  Returns the log slice
+        (n_frames, batch, 9) int32 (device)."""
+        self._need()
+        st = self._st
+        start = int(st["counters"][0].item())
+        if start + n_frames > st["log_frames"]:
+            raise ValueError("frame log too small: raise log_frames in setup_caches")
+        if max_pos is None:
+            max_pos = int(st["row_pos"][:batch].max().item()) + n_frames
+        self._set_grid_pages(max_pos)
+        s = ops.stream()
+        for _ in range(n_frames):
+            check(lib.ua2_stage3_frame(self._h, batch, mode, reason_eos, reason_card, int(use_graph), s),
+                  "ua2_stage3_frame")
+        return st["frame_log"][start:start + n_frames, :batch]
+
+    def begin_decode(self, tokens, tokens_mask, input_pos, forbid_prefix=0):
+        """Loads the first decode frame (the last prompt frame, tts_task.py:253-255) into the device state."""
+        self._need()
+        B, W = tokens.shape[0], tokens.shape[-1]
+        pos = input_pos.reshape(-1)
+        if pos.numel() == 1:
+            pos = pos.expand(B)
+        self._load_rows(tokens.reshape(B, W), tokens_mask.reshape(B, W), pos, torch.arange(B, device=tokens.device))
+        self._st["forbid"][:B].fill_(int(forbid_prefix))
+
+    def buffer(self, name: str, rows: int):
+        """Intermediate buffers for tests: 'h_final' (rows, C), 'text_logits' (rows, Vt), 'audio_logits' (rows, 8, Va)."""
+        self._need()
+        st = self._st
+        p = lib.ua2_stage3_buffer(self._h, name.encode())
+        if not p:
+            raise KeyError(name)
+        Cb = self.backbone.config.n_embd
+        shape = {"h_final": (rows, Cb), "h": (rows, Cb), "text_logits": (rows, self.backbone.config.padded_vocab_size),
+                 "audio_logits": (rows, st["ncb"], st["va"])}[name]
+        base = st["scratch"]
+        off = (C.cast(p, C.c_void_p).value - base.data_ptr()) // 4
+        n = 1
+        for s_ in shape:
+            n *= s_
+        return base[off:off + n].view(shape)
+
+    def get_fsdp_wrap_module_list(self) -> List[nn.Module]:
+        return (list(self.backbone.transformer.h) + list(self.audio_understanding_expert.transformer.h) +
+                list(self.audio_generation_expert.transformer.h))

@@ -1,0 +1,111 @@
+"""Op-level Python wrappers over the C ABI (torch is only the owner of device memory and the
+stream).  Each wrapper names the reference call site it stands in for; the arithmetic lives in
+csrc/*.hip.  Used by the parity tests and by the module mirrors in llm_models/.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_ATTN, PRO_CAST, PRO_NORM, UA2_BF16,
+                   UA2_F32, UA2_PAGE, AttnArgs, KvGeom, LinearArgs, check, lib)
+
+_CODES = {torch.float32: UA2_F32, torch.bfloat16: UA2_BF16}
+
+
+def dtype_code(dt):
+    try:
+        return _CODES[dt]
+    except KeyError:
+        raise ValueError(f"uniaudio2_amd supports torch.float32 and torch.bfloat16 weights, got {dt}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor expected"
+    return t.data_ptr()
+
+
+def packed_elems(dtype, N, K):
+    return lib.ua2_packed_elems(dtype_code(dtype), N, K)
+
+
+def pack_linear(weight, dtype, transposed=False):
+    """nn.Linear.weight [N,K] (or [K,N] with transposed=True) -> MFMA-fragment-ordered buffer of `dtype`."""
+    assert weight.dim() == 2 and weight.is_cuda
+    w = weight.contiguous()
+    if w.dtype not in _CODES:
+        w = w.float()
+    N, K = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    out = torch.empty(packed_elems(dtype, N, K), dtype=dtype, device=w.device)
+    check(lib.ua2_pack_linear(ptr(w), dtype_code(w.dtype), int(transposed), N, K, ptr(out), dtype_code(dtype),
+                              stream()), "ua2_pack_linear")
+    return out
+
+
+def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
+    g = KvGeom()
+    g.k_pool, g.v_pool, g.page_table = ptr(k_pool), ptr(v_pool), ptr(page_table)
+    g.max_pages = page_table.shape[-1] if page_table is not None else 0
+    g.n_kv, g.n_head, g.head_size = n_kv, n_head, head_size
+    return g
+
+
+def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None, ldx=None, norm_w=None, eps=1e-5,
+           attn_o=None, attn_ml=None, w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
+           forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None):
+    a = LinearArgs()
+    a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
+    a.M, a.N, a.K = M, N, K
+    a.x, a.ldx = ptr(x), (ldx if ldx is not None else (x.shape[-1] if x is not None else 0))
+    a.norm_w, a.eps = ptr(norm_w), eps
+    a.attn_o, a.attn_ml = ptr(attn_o), ptr(attn_ml)
+    a.w0, a.w1 = ptr(w0), ptr(w1)
+    a.y, a.ldy = ptr(y), (ldy if ldy is not None else (y.shape[-1] if y is not None else 0))
+    a.resid, a.ldr = ptr(resid), (ldr if ldr is not None else (resid.shape[-1] if resid is not None else 0))
+    a.part_max, a.part_idx, a.forbid = ptr(part_max), ptr(part_idx), ptr(forbid)
+    a.row_pos, a.row_seq = ptr(row_pos), ptr(row_seq)
+    a.rope_cos, a.rope_sin, a.q_out = ptr(rope_cos), ptr(rope_sin), ptr(q_out)
+    if kv is not None:
+        a.kv = kv
+    check(lib.ua2_linear(C.byref(a), stream()), "ua2_linear")
+
+
+def attn(*, dtype, R, q, row_pos, row_seq, attn_o, attn_ml, kv, grid_pages=0):
+    a = AttnArgs()
+    a.dtype, a.R = dtype_code(dtype), R
+    a.q, a.row_pos, a.row_seq = ptr(q), ptr(row_pos), ptr(row_seq)
+    a.attn_o, a.attn_ml, a.grid_pages, a.kv = ptr(attn_o), ptr(attn_ml), grid_pages, kv
+    check(lib.ua2_attn(C.byref(a), stream()), "ua2_attn")
+
+
+def embed_frame(dtype, tokens, mask, audio_emb, wte, va):
+    M, w = tokens.shape
+    Cc = audio_emb.shape[1]
+    a = torch.empty(M, Cc, dtype=torch.float32, device=tokens.device)
+    t = torch.empty_like(a)
+    check(lib.ua2_embed_frame(dtype_code(dtype), M, Cc, w - 1, va, ptr(tokens), ptr(mask), ptr(audio_emb), ptr(wte),
+                              ptr(a), ptr(t), stream()), "ua2_embed_frame")
+    return a, t
+
+
+def rmsnorm_blend(x, w, eps, other=None, mask=None, col_a=-1, col_b=-1, want_n=False):
+    M, Cc = x.shape
+    o1 = torch.empty_like(x)
+    o2 = torch.empty_like(x) if want_n else None
+    check(lib.ua2_rmsnorm_blend(M, Cc, ptr(x), ptr(w), eps, ptr(other), ptr(mask),
+                                mask.shape[1] if mask is not None else 0, col_a, col_b, ptr(o1), ptr(o2), stream()),
+          "ua2_rmsnorm_blend")
+    return (o1, o2) if want_n else o1
+
+
+def argmax_embed(dtype, part_max, part_idx, out_tokens, out_col, emb=None, emb_row_offset=0, next_h=None):
+    M, n_part = part_max.shape
+    check(lib.ua2_argmax_embed(dtype_code(dtype), M, n_part, ptr(part_max), ptr(part_idx), ptr(out_tokens),
+                               out_tokens.shape[1], out_col, ptr(emb), emb_row_offset,
+                               emb.shape[1] if emb is not None else 0, ptr(next_h), stream()), "ua2_argmax_embed")
