@@ -104,6 +104,11 @@ typedef struct ua2_linear_args {
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
 
+/* Measurement helper (bench.py roofline leg): launches args[0..n) back to back `iters` times on
+ * `stream`, bracketed by hipEvents recorded on that same stream, waits for the stop event and
+ * returns the elapsed milliseconds in *ms_out.  No other work is enqueued in between. */
+int ua2_linear_chain_timed(const ua2_linear_args* args, int32_t n, int32_t iters, void* stream, float* ms_out);
+
 /* Decode/prefill attention over the paged cache: one query row per (row, head); each
  * (row, kv-head, page) workgroup writes un-normalised partials that UA2_PRO_ATTN merges.
  * Replaces repeat_interleave + masked SDPA (lit_model.py:478-481, 529-531): GQA without

@@ -60,6 +60,7 @@ _EXPORTS = {
     "ua2_packed_elems": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
+    "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
     "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -394,6 +394,25 @@ extern "C" int ua2_linear(const ua2_linear_args* a, void* stream) {
   return ua2_linear_launch(*a, (hipStream_t)stream);
 }
 
+extern "C" int ua2_linear_chain_timed(const ua2_linear_args* args, int32_t n, int32_t iters, void* stream,
+                                      float* ms_out) {
+  UA2_CHECK(args && n > 0 && iters > 0 && ms_out, "ua2_linear_chain_timed: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  UA2_HIP(hipEventCreate(&e0));
+  UA2_HIP(hipEventCreate(&e1));
+  UA2_HIP(hipEventRecord(e0, s));
+  for (int it = 0; it < iters; ++it)
+    for (int i = 0; i < n; ++i)
+      if (int rc = ua2_linear_launch(args[i], s)) return rc;
+  UA2_HIP(hipEventRecord(e1, s));
+  UA2_HIP(hipEventSynchronize(e1));
+  UA2_HIP(hipEventElapsedTime(ms_out, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
+}
+
 extern "C" size_t ua2_packed_elems(int dtype, int64_t N, int64_t K) {
   const int kc = dtype == UA2_BF16 ? 32 : 16, epl = dtype == UA2_BF16 ? 8 : 4;
   return (size_t)((N + 15) / 16) * (size_t)((K + kc - 1) / kc) * 64 * epl;

@@ -27,6 +27,7 @@ struct ua2_stage3 {
   int32_t *pidx_t, *pidx_a;
   int32_t npart_t, npart_a;
   int32_t grid_pages;
+  hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
 };
 
@@ -172,7 +173,8 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
 
 extern "C" void ua2_stage3_destroy(ua2_stage3* h) {
   if (!h) return;
-  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   delete h;
 }
 
@@ -248,20 +250,21 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
                                 int32_t use_graph, void* stream) {
   UA2_CHECK(h != nullptr, "ua2_stage3_frame: NULL handle");
   hipStream_t s = (hipStream_t)stream;
-  auto body = [&]() -> int {
-    if (int rc = ua2_stage3_trunk(h, R, s)) return rc;
-    if (int rc = ua2_stage3_heads(h, R, s)) return rc;
+  auto body = [&](hipStream_t st) -> int {
+    if (int rc = ua2_stage3_trunk(h, R, st)) return rc;
+    if (int rc = ua2_stage3_heads(h, R, st)) return rc;
     if (mode < 0) return 0;
-    return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, s);
+    return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, st);
   };
-  if (!use_graph) return body();
+  if (!use_graph) return body(s);
   const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;
-    UA2_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    const int rc = body();
-    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (!h->cap_stream) UA2_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    UA2_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = body(h->cap_stream);
+    const hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
     if (rc) return rc;
     if (e != hipSuccess) {
       ua2_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -269,7 +272,7 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
     }
     hipGraphExec_t exec = nullptr;
     UA2_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     it = h->graphs.emplace(key, exec).first;
   }
   UA2_HIP(hipGraphLaunch(it->second, s));

@@ -58,7 +58,7 @@ def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
 
 def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None, ldx=None, norm_w=None, eps=1e-5,
            attn_o=None, attn_ml=None, w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
-           forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None):
+           forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True):
     a = LinearArgs()
     a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
     a.M, a.N, a.K = M, N, K
@@ -73,7 +73,17 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
     a.rope_cos, a.rope_sin, a.q_out = ptr(rope_cos), ptr(rope_sin), ptr(q_out)
     if kv is not None:
         a.kv = kv
+    if not launch:
+        return a
     check(lib.ua2_linear(C.byref(a), stream()), "ua2_linear")
+
+
+def linear_chain_timed(args_list, iters):
+    """Average milliseconds per launch of the given ua2_linear launches, back to back, HIP-event timed."""
+    arr = (LinearArgs * len(args_list))(*args_list)
+    ms = C.c_float(0.0)
+    check(lib.ua2_linear_chain_timed(arr, len(args_list), iters, stream(), C.byref(ms)), "ua2_linear_chain_timed")
+    return ms.value / (len(args_list) * iters)
 
 
 def attn(*, dtype, R, q, row_pos, row_seq, attn_o, attn_ml, kv, grid_pages=0):
