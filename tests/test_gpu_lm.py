@@ -57,59 +57,64 @@ def test_fp32_ids_equal_reference_golden(golden, sd, case, frames, feedback, swi
     assert np.array_equal(r["samples"].numpy(), d[f"{case}_samples"])
 
 
-def _tokens_defined(ref_text_logits, ref_audio_logits, forbid, eps, b):
-    """Number of leading tokens of row b (generation order: text, a0..a7, frame after frame) whose
-    oracle top-2 margin is >= eps.  Past the first low-margin token the arg-max — and everything
-    generated after it — is not defined by the contract."""
-    F = ref_text_logits.shape[0]
-    n = 0
-    for f in range(F):
-        tl = ref_text_logits[f, b].sort(-1).values
-        if float(tl[-1] - tl[-2]) < eps:
-            return n
-        n += 1
-        for i in range(ref_audio_logits.shape[2]):
-            al = ref_audio_logits[f, b, i].clone()
-            if forbid[f] > 0:
-                al[:forbid[f]] = float("-inf")
-            s = al.sort(-1).values
-            if float(s[-1] - s[-2]) < eps:
-                return n
-            n += 1
-    return n
+def _margin(logits, forbid=0):
+    l = logits.clone()
+    if forbid > 0:
+        l[:forbid] = float("-inf")
+    s = l.sort(-1).values
+    return float(s[-1] - s[-2])
 
 
 @pytest.mark.parametrize("case,frames,feedback,switch", CASES)
-def test_bf16_ids_equal_oracle_bf16_contract(golden, sd, case, frames, feedback, switch):
-    """bf16 kernels (MFMA 16x16x32, fp32 accumulate) vs the oracle restating the same contract.
-    Under this contract an fp32 summation-order difference can flip a bf16 rounding (1 ulp = 0.4 %
-    of an activation) and the flip propagates: measured on this toy model (|w| ~ 0.05, K = 128..512)
-    the oracle itself moves by up to 7e-3 when only its GEMMs are evaluated in fp64 instead of fp32.
-    Per sequence, every token generated before the first one whose oracle top-2 margin is below
-    2.5e-2 must be identical, and the logits of the frames completed before that point must agree
-    within 2.5e-2 (99 % of them within 5e-3)."""
+def test_bf16_teacher_forced_vs_oracle_bf16_contract(golden, sd, case, frames, feedback, switch):
+    """bf16 kernels (MFMA 16x16x32, fp32 accumulate) vs the oracle restating the same contract
+    (DESIGN.md §numerics).  Under this contract an fp32 summation-order difference can flip a bf16
+    rounding (1 ulp = 0.4 % of an activation) and the flip propagates: on this toy model
+    (|w| ~ 0.05, K = 128..512) the oracle itself moves by up to 7e-3 when only its GEMMs are
+    evaluated in fp64 instead of fp32.  So the check is teacher-forced per frame: the kernels get
+    the oracle's previous frame as input; logits must agree within 2.5e-2, and every token must be
+    identical as long as the oracle's top-2 margin is >= 2.5e-2 (inside a frame the comparison stops
+    at the first token below that margin, because later local-decoder steps depend on it)."""
     d, _ = golden
     tokens, mask = _case(d, case)
-    B = tokens.size(0)
+    B, L, _ = tokens.shape
     o = run_decode_loop(build_oracle(sd, "bf16", B), tokens, mask, frames, feedback, forbid_switch=switch,
                         reason_card=RC, collect_logits=True)
     m = build_product_model(sd, torch.bfloat16, batch=B)
-    r = product_decode_loop(m, tokens, mask, frames, feedback, forbid_switch=switch, reason_card=RC, collect_logits=True)
-    forbid = [0 if (switch is None or f < switch) else RC for f in range(frames)]
-    total = 0
-    for b in range(B):
-        n = _tokens_defined(o["text_logits"], o["audio_logits"], forbid, 2.5e-2, b)
-        got = r["samples"][:, b].reshape(-1)[:n].int()
-        ref = o["samples"][:, b].reshape(-1)[:n].int()
-        assert torch.equal(got, ref), f"row {b}: ids differ within the first {n} well-defined tokens"
-        nf = n // 9
-        for key in ("text_logits", "audio_logits"):
-            g_, o_ = r[key][:nf, b].numpy(), o[key][:nf, b].numpy()
-            np.testing.assert_allclose(g_, o_, atol=2.5e-2, rtol=0)
-            if g_.size:
-                assert (np.abs(g_ - o_) < 5e-3).mean() > 0.9
-        total += n
-    assert total >= 9, f"only {total} tokens were well defined: the case does not test anything"
+    dev = "cuda"
+    tk, mk = tokens.to(dev), mask.to(dev)
+    m.reset_caches()
+    pos = torch.arange(0, L, device=dev).unsqueeze(0).repeat(B, 1)
+    m.forward_prefix(tk[:, :-1], labels=tk[:, 1:, :-1], tokens_mask=mk, loss_mask=mk, input_pos=pos[:, :-1])
+    ct, cm = tk[:, -1:], mk[:, -1:]
+    compared = total = 0
+    for f in range(frames):
+        forbid = 0 if (switch is None or f < switch) else RC
+        s = m.generate_frame(ct, cm, input_pos=torch.tensor([L - 1 + f], device=dev), input_pos_maxp1=L + f,
+                             forbid_prefix=forbid).cpu()
+        tl, al = m.buffer("text_logits", B).cpu(), m.buffer("audio_logits", B).cpu()
+        np.testing.assert_allclose(tl.numpy(), o["text_logits"][f].numpy(), atol=2.5e-2, rtol=0)
+        for b in range(B):
+            total += 9
+            if _margin(o["text_logits"][f, b]) >= 2.5e-2:
+                assert int(s[b, 0]) == int(o["samples"][f, b, 0]), f"text id differs at frame {f}"
+                compared += 1
+            for i in range(8):
+                np.testing.assert_allclose(al[b, i].numpy(), o["audio_logits"][f, b, i].numpy(), atol=2.5e-2, rtol=0)
+                if _margin(o["audio_logits"][f, b, i], forbid) < 2.5e-2:
+                    break
+                assert int(s[b, 1 + i]) == int(o["samples"][f, b, 1 + i]), f"audio id {i} differs at frame {f}"
+                compared += 1
+        # teacher forcing: next input = the ORACLE's sample of this frame
+        so = o["samples"][f].to(dev)
+        text_tok, audio = so[:, 0:1].long(), so[:, 1:].long()
+        if feedback == "audio":
+            ct = torch.cat([audio, text_tok], dim=-1).unsqueeze(1)
+            cm = torch.cat([torch.ones_like(audio).bool(), torch.zeros(B, 1, device=dev).bool()], dim=1).unsqueeze(1)
+        else:
+            ct = torch.cat([torch.zeros_like(audio), text_tok], dim=-1).unsqueeze(1)
+            cm = torch.cat([torch.zeros_like(audio).bool(), torch.ones(B, 1, device=dev).bool()], dim=1).unsqueeze(1)
+    assert compared >= total // 3, f"only {compared}/{total} tokens had a defined arg-max"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
