@@ -103,6 +103,9 @@ typedef struct ua2_linear_args {
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
+/* Test hook: route every ua2_linear through the general-M kernel (1) or let the launcher pick the
+ * decode-regime kernel when it applies (0, default).  Returns the previous setting. */
+int ua2_debug_force_general_linear(int on);
 
 /* Measurement helper (bench.py roofline leg): launches args[0..n) back to back `iters` times on
  * `stream`, bracketed by hipEvents recorded on that same stream, waits for the stop event and
@@ -123,6 +126,9 @@ typedef struct ua2_attn_args {
   float* attn_ml;         /* [R, n_head, max_pages, 2] */
   int32_t grid_pages;     /* pages to launch (>= max(row_pos)/UA2_PAGE + 1); <=0 means kv.max_pages */
   ua2_kv_geom kv;
+  float* y;               /* if non-NULL: single-pass mode — one workgroup per (row, kv-head) walks all pages
+                             (waves own pages, online softmax, merge in LDS) and writes the normalised
+                             output [R, n_head*head_size]; attn_o / attn_ml / grid_pages are unused */
 } ua2_attn_args;
 
 int ua2_attn(const ua2_attn_args* a, void* stream);

@@ -33,7 +33,7 @@ class LinearArgs(C.Structure):
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("attn_o", vp),
-                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom)]
+                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp)]
 
 
 class GptDesc(C.Structure):
@@ -60,6 +60,7 @@ _EXPORTS = {
     "ua2_packed_elems": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
+    "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
     "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

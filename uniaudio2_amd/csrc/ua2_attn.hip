@@ -165,6 +165,189 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const ua2_attn_args 
   }
 }
 
+
+// ---- single-pass variant: one workgroup per (row, kv-head), waves own pages ---------------------
+// After the first profile (profiles/r1_a): the split kernel above + the merge in the O-projection
+// prologue cost two dependent launches and re-read every partial in each of the O-projection's
+// workgroups.  Here the 8 waves of a workgroup take pages w, w+8, ... of the row's cache, keep
+// all K (then V) loads of a 64-position page in flight at once (16 x 16 B per lane), run an online
+// softmax per wave, and merge the <= 8 wave states through LDS in wave order (deterministic,
+// depends only on the position).  Output is the normalised attention row in fp32.
+constexpr int kFusedWaves = 8;
+
+template <int DT, int HS>
+__global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_attn_args a) {
+  constexpr int EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
+  constexpr int LPR = HS / EPL, RPW = 64 / LPR, ITS = UA2_PAGE / RPW, GRP = ITS < 16 ? ITS : 16;
+  __shared__ float w_m[kFusedWaves][kMaxG], w_l[kFusedWaves][kMaxG];
+  __shared__ float w_o[kFusedWaves][kMaxG][HS];
+
+  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int pos = a.row_pos[r];
+  const int npages = pos / UA2_PAGE + 1;
+  const int G = a.kv.n_head / a.kv.n_kv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPR, rin = lane / LPR;
+  const float scale = 1.0f / sqrtf((float)HS);
+  const int32_t* ptab = a.kv.page_table + (size_t)a.row_seq[r] * a.kv.max_pages;
+
+  float q[kMaxG][EPL];
+#pragma unroll
+  for (int h = 0; h < kMaxG; ++h) {
+    const float* qp = a.q + ((size_t)r * a.kv.n_head + (size_t)kvh * G + (h < G ? h : 0)) * HS + sub * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[h][e] = (h < G) ? qp[e] : 0.f;
+  }
+  float m_run[kMaxG], l_run[kMaxG], o_run[kMaxG][EPL];
+#pragma unroll
+  for (int h = 0; h < kMaxG; ++h) {
+    m_run[h] = -INFINITY;
+    l_run[h] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o_run[h][e] = 0.f;
+  }
+
+  for (int pg = wave; pg < npages; pg += kFusedWaves) {
+    const int nvalid = min(UA2_PAGE, pos + 1 - pg * UA2_PAGE);
+    const size_t pbase = ((size_t)ptab[pg] * a.kv.n_kv + kvh) * UA2_PAGE * HS;
+    const char* kp = (const char*)a.kv.k_pool + (pbase + (size_t)sub * EPL) * BYTES;
+    const char* vp_ = (const char*)a.kv.v_pool + (pbase + (size_t)sub * EPL) * BYTES;
+#pragma unroll
+    for (int g0 = 0; g0 < ITS; g0 += GRP) {
+      if (g0 * RPW >= nvalid) break;
+      u32x4 kraw[GRP], vraw[GRP];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int j = (g0 + u) * RPW + rin;
+        kraw[u] = u32x4{0u, 0u, 0u, 0u};
+        if (j < nvalid) kraw[u] = *reinterpret_cast<const u32x4*>(kp + (size_t)j * HS * BYTES);
+      }
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int j = (g0 + u) * RPW + rin;
+        vraw[u] = u32x4{0u, 0u, 0u, 0u};
+        if (j < nvalid) vraw[u] = *reinterpret_cast<const u32x4*>(vp_ + (size_t)j * HS * BYTES);
+      }
+      float s[GRP][kMaxG];
+      float gmax[kMaxG];
+#pragma unroll
+      for (int h = 0; h < kMaxG; ++h) gmax[h] = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int j = (g0 + u) * RPW + rin;
+        float kf[EPL];
+        if constexpr (DT == UA2_BF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            kf[2 * e] = __uint_as_float(kraw[u][e] << 16);
+            kf[2 * e + 1] = __uint_as_float(kraw[u][e] & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) kf[e] = __uint_as_float(kraw[u][e]);
+        }
+#pragma unroll
+        for (int h = 0; h < kMaxG; ++h) {
+          float d = 0.f;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) d += q[h][e] * kf[e];
+#pragma unroll
+          for (int o = LPR / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+          s[u][h] = (j < nvalid) ? d * scale : -INFINITY;
+          gmax[h] = fmaxf(gmax[h], s[u][h]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < kMaxG; ++h) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) gmax[h] = fmaxf(gmax[h], __shfl_xor(gmax[h], o));
+        const float m_new = fmaxf(m_run[h], gmax[h]);   // finite: row 0 of the group is valid
+        const float resc = expf(m_run[h] - m_new);      // exp(-inf) = 0 on the first group
+        m_run[h] = m_new;
+        l_run[h] *= resc;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o_run[h][e] *= resc;
+      }
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        float vf[EPL];
+        if constexpr (DT == UA2_BF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vf[2 * e] = __uint_as_float(vraw[u][e] << 16);
+            vf[2 * e + 1] = __uint_as_float(vraw[u][e] & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vf[e] = __uint_as_float(vraw[u][e]);
+        }
+#pragma unroll
+        for (int h = 0; h < kMaxG; ++h) {
+          const float p = expf(s[u][h] - m_run[h]);     // 0 for masked rows
+          if (sub == 0) l_run[h] += p;                  // one lane per row counts it
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) o_run[h][e] += p * vf[e];
+        }
+      }
+    }
+  }
+  // fold the RPW row groups of the wave, publish the wave state
+#pragma unroll
+  for (int h = 0; h < kMaxG; ++h) {
+    float l = l_run[h];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+    l_run[h] = l;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      float t = o_run[h][e];
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o);
+      o_run[h][e] = t;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < kMaxG; ++h) {
+    if (h < G) {
+      if (lane == 0) { w_m[wave][h] = m_run[h]; w_l[wave][h] = l_run[h]; }
+      if (rin == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) w_o[wave][h][sub * EPL + e] = o_run[h][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * HS; idx += kFusedWaves * 64) {
+    const int h = idx / HS, d = idx - h * HS;
+    float mx = w_m[0][h];
+#pragma unroll
+    for (int w = 1; w < kFusedWaves; ++w) mx = fmaxf(mx, w_m[w][h]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFusedWaves; ++w) {
+      const float f = expf(w_m[w][h] - mx);
+      num += f * w_o[w][h][d];
+      den += f * w_l[w][h];
+    }
+    a.y[((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + d] = num / den;
+  }
+}
+
+template <int DT>
+int launch_fused(const ua2_attn_args& a, hipStream_t s) {
+  const dim3 grid(a.R, a.kv.n_kv), block(kFusedWaves * 64);
+  switch (a.kv.head_size) {
+    case 32: hipLaunchKernelGGL((attn_fused_kernel<DT, 32>), grid, block, 0, s, a); break;
+    case 64: hipLaunchKernelGGL((attn_fused_kernel<DT, 64>), grid, block, 0, s, a); break;
+    case 128: hipLaunchKernelGGL((attn_fused_kernel<DT, 128>), grid, block, 0, s, a); break;
+    default:
+      ua2_set_error("ua2_attn: head_size %d not supported (32, 64, 128)", a.kv.head_size);
+      return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DT>
 int launch_hs(const ua2_attn_args& a, hipStream_t s) {
   const int gp = a.grid_pages > 0 ? a.grid_pages : a.kv.max_pages;
@@ -185,11 +368,16 @@ int launch_hs(const ua2_attn_args& a, hipStream_t s) {
 
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
   UA2_CHECK(a.R > 0, "ua2_attn: R=%d", a.R);
-  UA2_CHECK(a.q && a.row_pos && a.row_seq && a.attn_o && a.attn_ml && a.kv.k_pool && a.kv.v_pool && a.kv.page_table,
+  UA2_CHECK(a.q && a.row_pos && a.row_seq && (a.y || (a.attn_o && a.attn_ml)) && a.kv.k_pool && a.kv.v_pool &&
+                a.kv.page_table,
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
   UA2_CHECK(a.grid_pages <= a.kv.max_pages, "ua2_attn: grid_pages > max_pages");
+  if (a.y) {
+    if (a.dtype == UA2_BF16) return launch_fused<UA2_BF16>(a, s);
+    if (a.dtype == UA2_F32) return launch_fused<UA2_F32>(a, s);
+  }
   if (a.dtype == UA2_BF16) return launch_hs<UA2_BF16>(a, s);
   if (a.dtype == UA2_F32) return launch_hs<UA2_F32>(a, s);
   ua2_set_error("ua2_attn: bad dtype %d", a.dtype);

@@ -79,3 +79,5 @@ static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) 
 // internal launchers used by both the op-level ABI and the frame executor
 int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s);
+// decode-regime specialisation; returns 1 when the problem is outside its regime
+int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s);

@@ -1,0 +1,254 @@
+// Decode-regime weight-streaming GEMM (M <= 16 rows per tile, activations small enough for LDS).
+//
+// Same contract and epilogues as ua2_linear.hip (include/ua2hip.h ua2_linear), restructured after
+// the first rocprof pass (profiles/r1_a_*): at B = 1 every kernel of the frame was bound by
+// dependent-load latency, not bandwidth.  What changed, and why it maps to CDNA4:
+//   * every wave issues ALL of its weight loads (CPW x NT non-temporal 1 KiB bursts) as its first
+//     instructions; nothing in the prologue is ordered before them, so up to 16 waves x 16 KiB of
+//     HBM traffic per CU is in flight while the activations are prepared;
+//   * the activation rows are staged once per workgroup: coalesced float4 loads by all threads,
+//     RMSNorm statistics by a workgroup reduction, normalised values written to LDS in the MFMA
+//     operand dtype; A fragments are then ds_read_b128 (one per chunk) instead of per-wave
+//     global loads that serialised behind the weight stream;
+//   * the wave count (8-16) and chunks-per-wave (CPW) are chosen by the launcher so that
+//     waves x CPW tiles K exactly for the model's shapes: no tail, no predicated loads.
+#include "ua2_common.h"
+#include "ua2_linear_common.h"
+
+namespace {
+
+constexpr int kMaxWaves = 16;
+
+template <int DT, int PRO, int EPI, int CPW>
+__global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
+                                                              const int red_off) {
+  constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_QKV_ROPE) ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* a_lds = smem;                                        // [rows][a_stride] of T
+  float* red = reinterpret_cast<float*>(smem + red_off);     // [nw][NT][256]
+  float* ssq = red + kMaxWaves * NT * 256;                   // [nw][16]
+  float* rstd_s = ssq + kMaxWaves * 16;                      // [16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nw = nthreads >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.y * 16;
+  const int rows = min(16, a.M - m0);
+
+  const int nchunks = (a.K + KC - 1) / KC;
+  int tile[NT];
+  const u32x4* wp[NT];
+  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    const int hst = a.kv.head_size / 16, half = hst / 2;
+    const int h = blockIdx.x / half, r = blockIdx.x - h * half;
+    tile[0] = h * hst + r;
+    tile[1] = tile[0] + half;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
+    wp[1] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[1] * nchunks * 64 + lane;
+  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+    tile[0] = tile[1] = blockIdx.x;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
+    wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)tile[0] * nchunks * 64 + lane;
+  } else {
+    tile[0] = blockIdx.x;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
+  }
+  // chunk range of this wave; rounds of CPW chunks (exactly one round for the model's shapes)
+  const int c0 = (wave * nchunks) / nw, c1 = ((wave + 1) * nchunks) / nw;
+  const int last = max(c1 - 1, 0);
+
+  u32x4 wf[NT][CPW];
+#pragma unroll
+  for (int u = 0; u < CPW; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(c0 + u, last) * 64);
+
+  // ---- stage the activation rows into LDS (operand dtype) ----
+  if constexpr (PRO == UA2_PRO_NORM) {
+    // pass 1: sum of squares per row
+    for (int r0 = 0; r0 < rows; ++r0) {
+      const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
+      float ss = 0.f;
+      for (int k = tid * 4; k < a.K; k += nthreads * 4) {
+        const float4 t = *reinterpret_cast<const float4*>(xr + k);
+        ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+      if (lane == 0) ssq[wave * 16 + r0] = ss;
+    }
+    __syncthreads();
+    if (tid < rows) {
+      float t = 0.f;
+      for (int w = 0; w < nw; ++w) t += ssq[w * 16 + tid];
+      rstd_s[tid] = 1.0f / sqrtf(t / (float)a.K + a.eps);  // torch.rsqrt(mean(x*x) + eps), lit_model.py:886-887
+    }
+    __syncthreads();
+  }
+  for (int r0 = 0; r0 < rows; ++r0) {
+    const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
+    float rs = 1.f;
+    if constexpr (PRO == UA2_PRO_NORM) rs = rstd_s[r0];
+    for (int k = tid * 4; k < a.K; k += nthreads * 4) {
+      float4 t = *reinterpret_cast<const float4*>(xr + k);
+      if constexpr (PRO == UA2_PRO_NORM) {
+        const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
+        t.x = __fmul_rn(__fmul_rn(t.x, rs), w.x);  // (x*rstd)*w, lit_model.py:887-889
+        t.y = __fmul_rn(__fmul_rn(t.y, rs), w.y);
+        t.z = __fmul_rn(__fmul_rn(t.z, rs), w.z);
+        t.w = __fmul_rn(__fmul_rn(t.w, rs), w.w);
+      }
+      char* dst = a_lds + ((size_t)r0 * a_stride + k) * BYTES;
+      if constexpr (DT == UA2_BF16) {
+        uint2 p;
+        p.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
+        p.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
+        *reinterpret_cast<uint2*>(dst) = p;
+      } else {
+        *reinterpret_cast<float4*>(dst) = t;
+      }
+    }
+    // zero the K padding of the last chunk (K is a multiple of EPL, the padded tail is whole lanes)
+    for (int k = a.K + tid * 4; k < nchunks * KC; k += nthreads * 4) {
+      char* dst = a_lds + ((size_t)r0 * a_stride + k) * BYTES;
+      if constexpr (DT == UA2_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);
+      else *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA over this wave's chunks ----
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool arow = i < rows;
+  const char* abase = a_lds + ((size_t)i * a_stride + g * EPL) * BYTES;
+  for (int cb = c0; cb < c1; cb += CPW) {
+    if (cb != c0) {  // further rounds (fp32 / unusual K): reload
+#pragma unroll
+      for (int u = 0; u < CPW; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(cb + u, last) * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      const int c = cb + u;
+      AFrag<DT> af;
+      u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+      if (arow && c < c1) raw = *reinterpret_cast<const u32x4*>(abase + (size_t)c * KC * BYTES);
+      af.v = __builtin_bit_cast(decltype(af.v), raw);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af.mma(wf[t][u], acc[t]);
+    }
+  }
+
+  // ---- fixed-order cross-wave reduction, epilogue ----
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(&red[(wave * NT + t) * 256 + lane * 4]) = acc[t];
+  __syncthreads();
+  if (tid >= 256) return;
+  const int row = tid >> 4, col = tid & 15;
+  const int src = (((row >> 2) << 4) + col) * 4 + (row & 3);
+  float v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[(w * NT + t) * 256 + src];
+    v[t] = s;
+  }
+  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col);
+}
+
+struct Geometry {
+  int waves, cpw;
+};
+
+// waves x cpw == nchunks when possible (no tail); prefer many waves for small grids (latency),
+// fewer + deeper for large grids (two workgroups per CU overlap each other's prologue/epilogue).
+Geometry pick_geometry(int nchunks, int blocks, int nt) {
+  const int cap = (nt == 2) ? 8 : 16;
+  const int cpws[3] = {4, 8, 16};
+  Geometry best{0, 0};
+  int best_score = -1;
+  for (int w = 4; w <= kMaxWaves; ++w) {
+    for (int ci = 0; ci < 3; ++ci) {
+      const int c = cpws[ci];
+      if (c > cap || w * c != nchunks) continue;
+      int score = (blocks <= 320) ? w * 4 + c : (w >= 8 && w <= 12 ? 100 : 0) + c;
+      if (score > best_score) { best_score = score; best = Geometry{w, c}; }
+    }
+  }
+  if (best.waves) return best;
+  // no exact tiling: 16 waves (or fewer if K is tiny), rounds of `cap` chunks with clamped loads
+  int w = kMaxWaves;
+  while (w > 4 && nchunks < w) w >>= 1;
+  int per = (nchunks + w - 1) / w;
+  int c = per <= 4 ? 4 : (per <= 8 ? 8 : cap);
+  return Geometry{w, c};
+}
+
+template <int DT, int PRO, int EPI, int CPW>
+void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, int red_off, size_t smem, hipStream_t s) {
+  auto kern = gemv_kernel<DT, PRO, EPI, CPW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(waves * 64), smem, s, a, a_stride, red_off);
+}
+
+template <int DT, int PRO, int EPI>
+int launch_cpw(const ua2_linear_args& a, hipStream_t s) {
+  constexpr int KC = Elem<DT>::KC, BYTES = Elem<DT>::BYTES;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_QKV_ROPE) ? 2 : 1;
+  const int nchunks = ua2_ceil_div(a.K, KC);
+  const int ntiles = ua2_ceil_div(a.N, 16);
+  const int gx = (EPI == UA2_EPI_QKV_ROPE) ? ntiles / 2 : ntiles;
+  const int mtiles = ua2_ceil_div(a.M, 16);
+  const Geometry geo = pick_geometry(nchunks, gx * mtiles, NT);
+  const int rows = a.M < 16 ? a.M : 16;
+  // +16 B per row: breaks the power-of-two row stride (LDS bank conflicts across rows)
+  const int a_stride = nchunks * KC + 16 / BYTES;
+  const int red_off = (int)(((size_t)rows * a_stride * BYTES + 255) & ~(size_t)255);
+  const size_t smem = (size_t)red_off + (size_t)(kMaxWaves * NT * 256 + kMaxWaves * 16 + 16) * sizeof(float);
+  const dim3 grid(gx, mtiles);
+  switch (geo.cpw) {
+    case 4: launch_one<DT, PRO, EPI, 4>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
+    case 8: launch_one<DT, PRO, EPI, 8>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
+    default:
+      if constexpr (NT == 1) launch_one<DT, PRO, EPI, 16>(a, grid, geo.waves, a_stride, red_off, smem, s);
+      else launch_one<DT, PRO, EPI, 8>(a, grid, geo.waves, a_stride, red_off, smem, s);
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DT>
+int launch_dt(const ua2_linear_args& a, hipStream_t s) {
+  if (a.prologue == UA2_PRO_NORM) {
+    if (a.epilogue == UA2_EPI_QKV_ROPE) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_QKV_ROPE>(a, s);
+    if (a.epilogue == UA2_EPI_SWIGLU) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_SWIGLU>(a, s);
+    if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_STORE>(a, s);
+  } else if (a.prologue == UA2_PRO_CAST) {
+    if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_RESIDUAL>(a, s);
+    if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_STORE>(a, s);
+  }
+  return 1;  // combination not specialised here: the caller falls back to the general kernel
+}
+
+}  // namespace
+
+// Returns 0 if launched, 1 if this problem is outside the decode regime (caller uses the general
+// kernel), negative on error.
+int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s) {
+  if (a.prologue == UA2_PRO_ATTN) return 1;
+  const int kc = a.dtype == UA2_BF16 ? 32 : 16, bytes = a.dtype == UA2_BF16 ? 2 : 4;
+  const int rows = a.M < 16 ? a.M : 16;
+  const size_t a_bytes = (size_t)rows * ((size_t)ua2_ceil_div(a.K, kc) * kc + 16 / bytes) * bytes;
+  if (a_bytes > 96 * 1024) return 1;
+  if (a.dtype == UA2_BF16) return launch_dt<UA2_BF16>(a, s);
+  if (a.dtype == UA2_F32) return launch_dt<UA2_F32>(a, s);
+  return 1;
+}

@@ -19,6 +19,7 @@
 //   * RMSNorm / attention-merge prologues and residual / SwiGLU / RoPE+KV-append / arg-max
 //     epilogues run inside the kernel: activations never round-trip HBM in bf16.
 #include "ua2_common.h"
+#include "ua2_linear_common.h"
 
 namespace {
 
@@ -44,45 +45,6 @@ __global__ void pack_kernel(const void* __restrict__ src, void* __restrict__ out
     float v = 0.f;
     if (n < N && k < K) v = load_elem<SRC>(src, transposed ? (size_t)(k * N + n) : (size_t)(n * K + k));
     store_elem<DST>(out, (size_t)idx, v);
-  }
-}
-
-// ---- fragments ----------------------------------------------------------------------------
-
-template <int DT> struct AFrag;
-template <> struct AFrag<UA2_BF16> {
-  u32x4 v;
-  __device__ __forceinline__ void set(const float (&f)[8]) {
-    v[0] = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-    v[1] = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-    v[2] = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-    v[3] = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
-  }
-  __device__ __forceinline__ void mma(const u32x4& w, f32x4& acc) const {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, w), acc, 0,
-                                                  0, 0);
-  }
-};
-template <> struct AFrag<UA2_F32> {
-  f32x4 v;
-  __device__ __forceinline__ void set(const float (&f)[4]) {
-    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
-  }
-  __device__ __forceinline__ void mma(const u32x4& w, f32x4& acc) const {
-    const f32x4 b = __builtin_bit_cast(f32x4, w);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], b[e], acc, 0, 0, 0);
-  }
-};
-
-// ---- A-operand producers (row m, K offset k0, EPL consecutive values) -----------------------
-
-template <int EPL>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&f)[EPL]) {
-#pragma unroll
-  for (int q = 0; q < EPL / 4; ++q) {
-    const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
-    f[4 * q + 0] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
   }
 }
 
@@ -256,69 +218,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
     for (int w = 0; w < kWaves; ++w) s += red[w][t][src];
     v[t] = s;
   }
-  const int mr = blockIdx.y * 16 + row;
-  const bool rvalid = mr < a.M;
-
-  if constexpr (EPI == UA2_EPI_STORE) {
-    const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N && a.y) a.y[(size_t)mr * a.ldy + n] = v[0];
-    if (a.part_max) {
-      const int fb = (a.forbid && rvalid) ? a.forbid[mr] : 0;
-      float bv = (n < a.N && n >= fb) ? v[0] : -INFINITY;
-      int bi = n;
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) {  // 16-lane groups; ties -> lowest index
-        const float ov = __shfl_xor(bv, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if (col == 0 && rvalid) {
-        const int nb = gridDim.x;
-        a.part_max[(size_t)mr * nb + blockIdx.x] = bv;
-        a.part_idx[(size_t)mr * nb + blockIdx.x] = bi;
-      }
-    }
-  } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
-    const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = v[0] + a.resid[(size_t)mr * a.ldr + n];
-  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
-    const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) {
-      const float gte = v[0];
-      const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
-      a.y[(size_t)mr * a.ldy + n] = sg * v[1];
-    }
-  } else {  // UA2_EPI_QKV_ROPE
-    if (!rvalid) return;
-    const int hs = a.kv.head_size, half = hs / 2;
-    const int n0 = tile[0] * 16 + col;  // column in the fused qkv output
-    const int h = n0 / hs, d = n0 - h * hs;  // d < half
-    const int pos = a.row_pos[mr];
-    const float x1 = v[0], x2 = v[1];
-    if (h < a.kv.n_head + a.kv.n_kv) {
-      const float cs = a.rope_cos[(size_t)pos * half + d], sn = a.rope_sin[(size_t)pos * half + d];
-      // roped = x*cos + rotate_half(x)*sin  (lit_model.py:795-806), products rounded separately
-      const float lo = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn));
-      const float hi = __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
-      if (h < a.kv.n_head) {
-        float* q = a.q_out + (size_t)mr * a.kv.n_head * hs + (size_t)h * hs;
-        q[d] = lo;
-        q[d + half] = hi;
-      } else {
-        const int kvh = h - a.kv.n_head;
-        const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
-        const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
-        store_elem<DT>(a.kv.k_pool, base + d, lo);
-        store_elem<DT>(a.kv.k_pool, base + d + half, hi);
-      }
-    } else {
-      const int kvh = h - a.kv.n_head - a.kv.n_kv;
-      const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
-      const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
-      store_elem<DT>(a.kv.v_pool, base + d, x1);
-      store_elem<DT>(a.kv.v_pool, base + d + half, x2);
-    }
-  }
+  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col);
 }
 
 template <int DT, int PRO>
@@ -360,6 +260,8 @@ int launch_pro(const ua2_linear_args& a, hipStream_t s) {
 
 }  // namespace
 
+static int g_force_general = 0;
+
 int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
   UA2_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "ua2_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   UA2_CHECK(a.w0 != nullptr, "ua2_linear: w0 is NULL");
@@ -383,10 +285,22 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
                   a.kv.page_table,
               "ua2_linear: QKV_ROPE pointer arguments missing");
   }
+  if (a.dtype != UA2_BF16 && a.dtype != UA2_F32) {
+    ua2_set_error("ua2_linear: bad dtype %d", a.dtype);
+    return -1;
+  }
+  if (!g_force_general) {
+    const int rc = ua2_gemv_try_launch(a, s);  // decode regime: LDS-staged activations, all loads up front
+    if (rc <= 0) return rc;
+  }
   if (a.dtype == UA2_BF16) return launch_pro<UA2_BF16>(a, s);
-  if (a.dtype == UA2_F32) return launch_pro<UA2_F32>(a, s);
-  ua2_set_error("ua2_linear: bad dtype %d", a.dtype);
-  return -1;
+  return launch_pro<UA2_F32>(a, s);
+}
+
+extern "C" int ua2_debug_force_general_linear(int on) {
+  const int old = g_force_general;
+  g_force_general = on;
+  return old;
 }
 
 extern "C" int ua2_linear(const ua2_linear_args* a, void* stream) {

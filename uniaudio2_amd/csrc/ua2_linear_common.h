@@ -1,0 +1,120 @@
+// Pieces shared by the two weight-streaming GEMM kernels (ua2_linear.hip: general M;
+// ua2_gemv.hip: the decode regime).  Internal, not part of the C ABI.
+#pragma once
+#include "ua2_common.h"
+
+// ---- fragments ----------------------------------------------------------------------------
+
+template <int DT> struct AFrag;
+template <> struct AFrag<UA2_BF16> {
+  u32x4 v;
+  __device__ __forceinline__ void set(const float (&f)[8]) {
+    v[0] = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+    v[1] = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+    v[2] = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+    v[3] = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+  }
+  __device__ __forceinline__ void mma(const u32x4& w, f32x4& acc) const {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, w), acc, 0,
+                                                  0, 0);
+  }
+};
+template <> struct AFrag<UA2_F32> {
+  f32x4 v;
+  __device__ __forceinline__ void set(const float (&f)[4]) {
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+  }
+  __device__ __forceinline__ void mma(const u32x4& w, f32x4& acc) const {
+    const f32x4 b = __builtin_bit_cast(f32x4, w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], b[e], acc, 0, 0, 0);
+  }
+};
+
+// ---- A-operand producers (row m, K offset k0, EPL consecutive values) -----------------------
+
+template <int EPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&f)[EPL]) {
+#pragma unroll
+  for (int q = 0; q < EPL / 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+    f[4 * q + 0] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+  }
+}
+
+
+// ---- epilogues (thread = one (row, col) of the 16 x 16 output tile; v[t] = reduced sums) ----
+// NOTE: uses 16-lane shuffles for the arg-max partials: call with all 256 epilogue threads.
+template <int DT, int EPI, int NT>
+__device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, const float (&v)[NT],
+                                                     const int (&tile)[NT], int row, int col) {
+  const int mr = blockIdx.y * 16 + row;
+  const bool rvalid = mr < a.M;
+
+  if constexpr (EPI == UA2_EPI_STORE) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N && a.y) a.y[(size_t)mr * a.ldy + n] = v[0];
+    if (a.part_max) {
+      const int fb = (a.forbid && rvalid) ? a.forbid[mr] : 0;
+      float bv = (n < a.N && n >= fb) ? v[0] : -INFINITY;
+      int bi = n;
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {  // 16-lane groups; ties -> lowest index
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (col == 0 && rvalid) {
+        const int nb = gridDim.x;
+        a.part_max[(size_t)mr * nb + blockIdx.x] = bv;
+        a.part_idx[(size_t)mr * nb + blockIdx.x] = bi;
+      }
+    }
+  } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = v[0] + a.resid[(size_t)mr * a.ldr + n];
+  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N) {
+      const float gte = v[0];
+      const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
+      a.y[(size_t)mr * a.ldy + n] = sg * v[1];
+    }
+  } else {  // UA2_EPI_QKV_ROPE
+    if (!rvalid) return;
+    const int hs = a.kv.head_size, half = hs / 2;
+    const int n0 = tile[0] * 16 + col;  // column in the fused qkv output
+    const int h = n0 / hs, d = n0 - h * hs;  // d < half
+    const int pos = a.row_pos[mr];
+    const float x1 = v[0], x2 = v[1];
+    if (h < a.kv.n_head + a.kv.n_kv) {
+      const float cs = a.rope_cos[(size_t)pos * half + d], sn = a.rope_sin[(size_t)pos * half + d];
+      // roped = x*cos + rotate_half(x)*sin  (lit_model.py:795-806), products rounded separately
+      const float lo = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn));
+      const float hi = __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
+      if (h < a.kv.n_head) {
+        float* q = a.q_out + (size_t)mr * a.kv.n_head * hs + (size_t)h * hs;
+        q[d] = lo;
+        q[d + half] = hi;
+      } else {
+        const int kvh = h - a.kv.n_head;
+        const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
+        const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
+        store_elem<DT>(a.kv.k_pool, base + d, lo);
+        store_elem<DT>(a.kv.k_pool, base + d + half, hi);
+      }
+    } else {
+      const int kvh = h - a.kv.n_head - a.kv.n_kv;
+      const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
+      const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
+      store_elem<DT>(a.kv.v_pool, base + d, x1);
+      store_elem<DT>(a.kv.v_pool, base + d + half, x2);
+    }
+  }
+}
+
+template <int DT, int EPI, int NT>
+__device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&v)[NT], const int (&tile)[NT],
+                                                int row, int col) {
+  linear_epilogue_impl<DT, EPI, NT>(a, v, tile, row, col);
+}

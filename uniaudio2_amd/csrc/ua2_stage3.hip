@@ -22,7 +22,7 @@ struct ua2_stage3 {
   std::vector<void*> pools[4][2];
   std::vector<const void*> audio_head;
   // scratch carve
-  float *xa, *text, *xb, *hbuf, *xg, *hfin, *q, *act, *attn_o, *attn_ml, *xd, *curr_h;
+  float *xa, *text, *xb, *hbuf, *xg, *hfin, *q, *act, *yattn, *xd, *curr_h;
   float *text_logits, *audio_logits, *pmax_t, *pmax_a;
   int32_t *pidx_t, *pidx_a;
   int32_t npart_t, npart_a;
@@ -36,7 +36,7 @@ namespace {
 size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
-  size_t xa, text, xb, hbuf, xg, hfin, q, act, attn_o, attn_ml, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
+  size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
       pmax_a, pidx_a, total;
 };
 
@@ -44,18 +44,16 @@ Carve carve(const ua2_stage3_desc& d) {
   Carve c;
   const size_t R = d.max_rows;
   const ua2_gpt_desc* gs[4] = {&d.und, &d.backbone, &d.gen, &d.decoder};
-  size_t C = d.backbone.n_embd, Cd = d.decoder.n_embd, qmax = 0, actmax = 0, ao = 0, aml = 0;
+  size_t C = d.backbone.n_embd, Cd = d.decoder.n_embd, qmax = 0, actmax = 0;
   for (auto g : gs) {
     qmax = std::max(qmax, (size_t)g->n_head * g->head_size);
     actmax = std::max(actmax, (size_t)g->inter);
-    ao = std::max(ao, (size_t)g->n_head * g->max_pages * g->head_size);
-    aml = std::max(aml, (size_t)g->n_head * g->max_pages * 2);
   }
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
   c.xa = take(R * C); c.text = take(R * C); c.xb = take(R * C); c.hbuf = take(R * C); c.xg = take(R * C);
-  c.hfin = take(R * C); c.q = take(R * qmax); c.act = take(R * actmax); c.attn_o = take(R * ao);
-  c.attn_ml = take(R * aml); c.xd = take(d.max_batch * Cd); c.curr_h = take(d.max_batch * C);
+  c.hfin = take(R * C); c.q = take(R * qmax); c.act = take(R * actmax); c.yattn = take(R * qmax);
+  c.xd = take(d.max_batch * Cd); c.curr_h = take(d.max_batch * C);
   const size_t npt = (d.vt + 15) / 16, npa = (d.va + 15) / 16, Bm = d.max_batch;
   c.text_logits = take(Bm * d.vt); c.audio_logits = take(Bm * d.n_cb * d.va);
   c.pmax_t = take(Bm * npt); c.pidx_t = take(Bm * npt); c.pmax_a = take(Bm * npa); c.pidx_a = take(Bm * npa);
@@ -82,13 +80,12 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
 
     ua2_attn_args at;
     memset(&at, 0, sizeof(at));
-    at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.attn_o = h->attn_o;
-    at.attn_ml = h->attn_ml; at.grid_pages = std::min(grid_pages, g.max_pages); at.kv = kv;
+    at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.y = h->yattn; at.kv = kv;
     if (int rc = ua2_attn_launch(at, s)) return rc;
 
     memset(&a, 0, sizeof(a));
-    a.dtype = dt; a.prologue = UA2_PRO_ATTN; a.epilogue = UA2_EPI_RESIDUAL;
-    a.M = R; a.N = C; a.K = qn; a.attn_o = h->attn_o; a.attn_ml = h->attn_ml; a.row_pos = row_pos; a.kv = kv;
+    a.dtype = dt; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
+    a.M = R; a.N = C; a.K = qn; a.x = h->yattn; a.ldx = qn;
     a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
@@ -161,7 +158,7 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->audio_head.assign(d->audio_head, d->audio_head + d->n_cb);
   float* b = d->scratch;
   h->xa = b + c.xa; h->text = b + c.text; h->xb = b + c.xb; h->hbuf = b + c.hbuf; h->xg = b + c.xg;
-  h->hfin = b + c.hfin; h->q = b + c.q; h->act = b + c.act; h->attn_o = b + c.attn_o; h->attn_ml = b + c.attn_ml;
+  h->hfin = b + c.hfin; h->q = b + c.q; h->act = b + c.act; h->yattn = b + c.yattn;
   h->xd = b + c.xd; h->curr_h = b + c.curr_h; h->text_logits = b + c.text_logits;
   h->audio_logits = b + c.audio_logits; h->pmax_t = b + c.pmax_t; h->pidx_t = (int32_t*)(b + c.pidx_t);
   h->pmax_a = b + c.pmax_a; h->pidx_a = (int32_t*)(b + c.pidx_a);

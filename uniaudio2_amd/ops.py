@@ -86,8 +86,9 @@ def linear_chain_timed(args_list, iters):
     return ms.value / (len(args_list) * iters)
 
 
-def attn(*, dtype, R, q, row_pos, row_seq, attn_o, attn_ml, kv, grid_pages=0):
+def attn(*, dtype, R, q, row_pos, row_seq, kv, attn_o=None, attn_ml=None, grid_pages=0, y=None):
     a = AttnArgs()
+    a.y = ptr(y)
     a.dtype, a.R = dtype_code(dtype), R
     a.q, a.row_pos, a.row_seq = ptr(q), ptr(row_pos), ptr(row_seq)
     a.attn_o, a.attn_ml, a.grid_pages, a.kv = ptr(attn_o), ptr(attn_ml), grid_pages, kv
