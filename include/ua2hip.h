@@ -57,9 +57,12 @@ size_t ua2_packed_elems(int dtype, int64_t N, int64_t K);
  * contiguous 1 KiB line burst: out[N/16][K/KC][64 lanes][16 B].  `src` is [N,K] row-major
  * (nn.Linear.weight, lit_model.py:356-360) or, with transposed=1, [K,N] (audio_head[i],
  * model_new.py:349,632).  src_dtype is the dtype of `src`; dst dtype is `dtype`
- * (fp32 -> bf16 rounds to nearest even, as torch .to(bfloat16)). */
+ * (fp32 -> bf16 rounds to nearest even, as torch .to(bfloat16)).
+ * rope_head_size > 0 (fused qkv weights consumed by UA2_EPI_QKV_ROPE): the rows of every head are
+ * additionally permuted so that output tile r of a head carries dims [8r,8r+8) and their half-split
+ * rotation partners [hs/2+8r, hs/2+8r+8): RoPE then closes inside one 16-column tile. */
 int ua2_pack_linear(const void* src, int src_dtype, int transposed, int64_t N, int64_t K,
-                    void* out, int dtype, void* stream);
+                    void* out, int dtype, int rope_head_size, void* stream);
 
 /* Geometry of the paged KV cache shared by the QKV epilogue and the attention kernel.
  * Pool layout (per layer): [n_pages][n_kv][UA2_PAGE][head_size] of `dtype`, K and V separate.

@@ -58,7 +58,7 @@ _EXPORTS = {
     "ua2_last_error": (C.c_char_p, []),
     "ua2_version": (C.c_int, []),
     "ua2_packed_elems": (C.c_size_t, [C.c_int, i64, i64]),
-    "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, vp]),
+    "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),

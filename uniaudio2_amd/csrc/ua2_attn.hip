@@ -166,37 +166,60 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const ua2_attn_args 
 }
 
 
-// ---- single-pass variant: one workgroup per (row, kv-head), waves own pages ---------------------
-// After the first profile (profiles/r1_a): the split kernel above + the merge in the O-projection
-// prologue cost two dependent launches and re-read every partial in each of the O-projection's
-// workgroups.  Here the 8 waves of a workgroup take pages w, w+8, ... of the row's cache, keep
-// all K (then V) loads of a 64-position page in flight at once (16 x 16 B per lane), run an online
-// softmax per wave, and merge the <= 8 wave states through LDS in wave order (deterministic,
-// depends only on the position).  Output is the normalised attention row in fp32.
+// ---- single-pass variant: one workgroup per (row, kv-head) --------------------------------------
+// After the first profiles (profiles/r1_a, r1_b): at B = 1 attention is pure latency, so
+//   * the row's positions 0..pos are split evenly over the 8 waves (not by page), each wave walks
+//     its range 4*UNR rows at a time with all K and V loads of a step issued together;
+//   * the 16-lane dot-product reductions use DPP row operations (no LDS permutes);
+//   * exp is v_exp_f32 (exp2 of a pre-scaled argument);
+//   * online softmax per wave, the <= 8 wave states merge through LDS in wave order, so the
+//     summation order depends only on the position (batch invariant, deterministic).
+// Output is the normalised attention row in fp32 (input of the O-projection).
 constexpr int kFusedWaves = 8;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// all-reduce (sum) over aligned groups of LPR lanes, LPR in {4, 8, 16, 32}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v = dpp_add<0xB1>(v);                          // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                          // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v = dpp_add<0x141>(v);  // row_half_mirror
+  if constexpr (LPR >= 16) v = dpp_add<0x140>(v); // row_mirror
+  if constexpr (LPR >= 32) v += __shfl_xor(v, 16);
+  return v;
+}
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 template <int DT, int HS>
 __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_attn_args a) {
   constexpr int EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
-  constexpr int LPR = HS / EPL, RPW = 64 / LPR, ITS = UA2_PAGE / RPW, GRP = ITS < 16 ? ITS : 16;
+  constexpr int LPR = HS / EPL, RPW = 64 / LPR;
+  constexpr int UNR = (DT == UA2_BF16) ? 4 : 2;   // wave instructions per step (K and V each)
   __shared__ float w_m[kFusedWaves][kMaxG], w_l[kFusedWaves][kMaxG];
   __shared__ float w_o[kFusedWaves][kMaxG][HS];
 
   const int r = blockIdx.x, kvh = blockIdx.y;
   const int pos = a.row_pos[r];
-  const int npages = pos / UA2_PAGE + 1;
+  const int seq = a.row_seq[r];
+  const int n = pos + 1;
   const int G = a.kv.n_head / a.kv.n_kv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, rin = lane / LPR;
   const float scale = 1.0f / sqrtf((float)HS);
-  const int32_t* ptab = a.kv.page_table + (size_t)a.row_seq[r] * a.kv.max_pages;
+  const int32_t* ptab = a.kv.page_table + (size_t)seq * a.kv.max_pages;
+  // contiguous range of this wave, a multiple of RPW rows
+  const int chunk = ((n + kFusedWaves * RPW - 1) / (kFusedWaves * RPW)) * RPW;
+  const int j0 = wave * chunk, j1 = min(n, j0 + chunk);
 
   float q[kMaxG][EPL];
 #pragma unroll
   for (int h = 0; h < kMaxG; ++h) {
     const float* qp = a.q + ((size_t)r * a.kv.n_head + (size_t)kvh * G + (h < G ? h : 0)) * HS + sub * EPL;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) q[h][e] = (h < G) ? qp[e] : 0.f;
+    for (int e = 0; e < EPL; ++e) q[h][e] = (h < G) ? qp[e] * scale : 0.f;
   }
   float m_run[kMaxG], l_run[kMaxG], o_run[kMaxG][EPL];
 #pragma unroll
@@ -207,87 +230,76 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
     for (int e = 0; e < EPL; ++e) o_run[h][e] = 0.f;
   }
 
-  for (int pg = wave; pg < npages; pg += kFusedWaves) {
-    const int nvalid = min(UA2_PAGE, pos + 1 - pg * UA2_PAGE);
-    const size_t pbase = ((size_t)ptab[pg] * a.kv.n_kv + kvh) * UA2_PAGE * HS;
-    const char* kp = (const char*)a.kv.k_pool + (pbase + (size_t)sub * EPL) * BYTES;
-    const char* vp_ = (const char*)a.kv.v_pool + (pbase + (size_t)sub * EPL) * BYTES;
+  for (int jb = j0; jb < j1; jb += UNR * RPW) {
+    u32x4 kraw[UNR], vraw[UNR];
+    bool ok[UNR];
 #pragma unroll
-    for (int g0 = 0; g0 < ITS; g0 += GRP) {
-      if (g0 * RPW >= nvalid) break;
-      u32x4 kraw[GRP], vraw[GRP];
+    for (int u = 0; u < UNR; ++u) {
+      const int j = jb + u * RPW + rin;
+      ok[u] = j < j1;
+      const int jc = ok[u] ? j : j0;            // clamp: unconditional loads, masked below
+      const size_t off = ((((size_t)ptab[jc / UA2_PAGE] * a.kv.n_kv + kvh) * UA2_PAGE + (jc % UA2_PAGE)) * HS +
+                          (size_t)sub * EPL) * BYTES;
+      kraw[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.k_pool + off);
+      vraw[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.v_pool + off);
+    }
+    float s[UNR][kMaxG];
+    float gmax[kMaxG];
 #pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int j = (g0 + u) * RPW + rin;
-        kraw[u] = u32x4{0u, 0u, 0u, 0u};
-        if (j < nvalid) kraw[u] = *reinterpret_cast<const u32x4*>(kp + (size_t)j * HS * BYTES);
-      }
+    for (int h = 0; h < kMaxG; ++h) gmax[h] = -INFINITY;
 #pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int j = (g0 + u) * RPW + rin;
-        vraw[u] = u32x4{0u, 0u, 0u, 0u};
-        if (j < nvalid) vraw[u] = *reinterpret_cast<const u32x4*>(vp_ + (size_t)j * HS * BYTES);
-      }
-      float s[GRP][kMaxG];
-      float gmax[kMaxG];
+    for (int u = 0; u < UNR; ++u) {
+      float kf[EPL];
+      if constexpr (DT == UA2_BF16) {
 #pragma unroll
-      for (int h = 0; h < kMaxG; ++h) gmax[h] = -INFINITY;
-#pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int j = (g0 + u) * RPW + rin;
-        float kf[EPL];
-        if constexpr (DT == UA2_BF16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            kf[2 * e] = __uint_as_float(kraw[u][e] << 16);
-            kf[2 * e + 1] = __uint_as_float(kraw[u][e] & 0xffff0000u);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) kf[e] = __uint_as_float(kraw[u][e]);
+        for (int e = 0; e < 4; ++e) {
+          kf[2 * e] = __uint_as_float(kraw[u][e] << 16);
+          kf[2 * e + 1] = __uint_as_float(kraw[u][e] & 0xffff0000u);
         }
+      } else {
 #pragma unroll
-        for (int h = 0; h < kMaxG; ++h) {
-          float d = 0.f;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) d += q[h][e] * kf[e];
-#pragma unroll
-          for (int o = LPR / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-          s[u][h] = (j < nvalid) ? d * scale : -INFINITY;
-          gmax[h] = fmaxf(gmax[h], s[u][h]);
-        }
+        for (int e = 0; e < 4; ++e) kf[e] = __uint_as_float(kraw[u][e]);
       }
 #pragma unroll
       for (int h = 0; h < kMaxG; ++h) {
+        float d = 0.f;
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) gmax[h] = fmaxf(gmax[h], __shfl_xor(gmax[h], o));
-        const float m_new = fmaxf(m_run[h], gmax[h]);   // finite: row 0 of the group is valid
-        const float resc = expf(m_run[h] - m_new);      // exp(-inf) = 0 on the first group
-        m_run[h] = m_new;
-        l_run[h] *= resc;
+        for (int e = 0; e < EPL; ++e) d += q[h][e] * kf[e];
+        d = group_sum<LPR>(d);
+        s[u][h] = ok[u] ? d : -INFINITY;
+        gmax[h] = fmaxf(gmax[h], s[u][h]);
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) o_run[h][e] *= resc;
+    for (int h = 0; h < kMaxG; ++h) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) gmax[h] = fmaxf(gmax[h], __shfl_xor(gmax[h], o));
+      const float m_new = fmaxf(m_run[h], gmax[h]);   // finite: the first row of a step is valid
+      const float resc = fast_exp(m_run[h] - m_new);  // 0 on the first step
+      m_run[h] = m_new;
+      l_run[h] *= resc;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o_run[h][e] *= resc;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float vf[EPL];
+      if constexpr (DT == UA2_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vf[2 * e] = __uint_as_float(vraw[u][e] << 16);
+          vf[2 * e + 1] = __uint_as_float(vraw[u][e] & 0xffff0000u);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vf[e] = __uint_as_float(vraw[u][e]);
       }
 #pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        float vf[EPL];
-        if constexpr (DT == UA2_BF16) {
+      for (int h = 0; h < kMaxG; ++h) {
+        const float p = fast_exp(s[u][h] - m_run[h]);   // 0 for masked rows
+        if (sub == 0) l_run[h] += p;                    // one lane per row counts it
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            vf[2 * e] = __uint_as_float(vraw[u][e] << 16);
-            vf[2 * e + 1] = __uint_as_float(vraw[u][e] & 0xffff0000u);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vf[e] = __uint_as_float(vraw[u][e]);
-        }
-#pragma unroll
-        for (int h = 0; h < kMaxG; ++h) {
-          const float p = expf(s[u][h] - m_run[h]);     // 0 for masked rows
-          if (sub == 0) l_run[h] += p;                  // one lane per row counts it
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) o_run[h][e] += p * vf[e];
-        }
+        for (int e = 0; e < EPL; ++e) o_run[h][e] += p * vf[e];
       }
     }
   }
@@ -319,13 +331,13 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
   __syncthreads();
   for (int idx = tid; idx < G * HS; idx += kFusedWaves * 64) {
     const int h = idx / HS, d = idx - h * HS;
-    float mx = w_m[0][h];
+    float mx = w_m[0][h];                          // wave 0 always owns position 0
 #pragma unroll
     for (int w = 1; w < kFusedWaves; ++w) mx = fmaxf(mx, w_m[w][h]);
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int w = 0; w < kFusedWaves; ++w) {
-      const float f = expf(w_m[w][h] - mx);
+      const float f = fast_exp(w_m[w][h] - mx);    // 0 for waves without rows (m = -inf)
       num += f * w_o[w][h][d];
       den += f * w_l[w][h];
     }

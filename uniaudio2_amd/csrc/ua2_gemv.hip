@@ -23,7 +23,7 @@ template <int DT, int PRO, int EPI, int CPW>
 __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
                                                               const int red_off) {
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
-  constexpr int NT = (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_QKV_ROPE) ? 2 : 1;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* a_lds = smem;                                        // [rows][a_stride] of T
   float* red = reinterpret_cast<float*>(smem + red_off);     // [nw][NT][256]
@@ -39,14 +39,7 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
   const int nchunks = (a.K + KC - 1) / KC;
   int tile[NT];
   const u32x4* wp[NT];
-  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
-    const int hst = a.kv.head_size / 16, half = hst / 2;
-    const int h = blockIdx.x / half, r = blockIdx.x - h * half;
-    tile[0] = h * hst + r;
-    tile[1] = tile[0] + half;
-    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
-    wp[1] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[1] * nchunks * 64 + lane;
-  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+  if constexpr (EPI == UA2_EPI_SWIGLU) {
     tile[0] = tile[1] = blockIdx.x;
     wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
     wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)tile[0] * nchunks * 64 + lane;
@@ -202,10 +195,10 @@ void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, in
 template <int DT, int PRO, int EPI>
 int launch_cpw(const ua2_linear_args& a, hipStream_t s) {
   constexpr int KC = Elem<DT>::KC, BYTES = Elem<DT>::BYTES;
-  constexpr int NT = (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_QKV_ROPE) ? 2 : 1;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   const int nchunks = ua2_ceil_div(a.K, KC);
   const int ntiles = ua2_ceil_div(a.N, 16);
-  const int gx = (EPI == UA2_EPI_QKV_ROPE) ? ntiles / 2 : ntiles;
+  const int gx = ntiles;
   const int mtiles = ua2_ceil_div(a.M, 16);
   const Geometry geo = pick_geometry(nchunks, gx * mtiles, NT);
   const int rows = a.M < 16 ? a.M : 16;

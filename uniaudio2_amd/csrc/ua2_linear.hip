@@ -31,7 +31,7 @@ constexpr int UB = 4;  // chunks per software-pipelined batch
 
 template <int SRC, int DST>
 __global__ void pack_kernel(const void* __restrict__ src, void* __restrict__ out, int transposed, int64_t N, int64_t K,
-                            int64_t total) {
+                            int64_t total, int rope_hs) {
   constexpr int KC = Elem<DST>::KC, EPL = Elem<DST>::EPL;
   const int64_t nchunks = (K + KC - 1) / KC;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -40,7 +40,12 @@ __global__ void pack_kernel(const void* __restrict__ src, void* __restrict__ out
     const int lane = (int)((idx / EPL) % 64);
     const int64_t chunk = (idx / (EPL * 64)) % nchunks;
     const int64_t tile = idx / (EPL * 64 * nchunks);
-    const int64_t n = tile * 16 + (lane & 15);
+    int64_t n = tile * 16 + (lane & 15);
+    if (rope_hs > 0) {  // packed column -> source row: [8r, 8r+8) then [hs/2+8r, hs/2+8r+8) per tile r of a head
+      const int64_t h = n / rope_hs, within = n - h * rope_hs;
+      const int64_t r = within / 16, c = within % 16;
+      n = h * rope_hs + (c < 8 ? r * 8 + c : rope_hs / 2 + r * 8 + (c - 8));
+    }
     const int64_t k = chunk * KC + (lane >> 4) * EPL + e;
     float v = 0.f;
     if (n < N && k < K) v = load_elem<SRC>(src, transposed ? (size_t)(k * N + n) : (size_t)(n * K + k));
@@ -94,7 +99,7 @@ __device__ __forceinline__ void make_a(const ua2_linear_args& a, int m, bool val
 template <int DT, int PRO, int EPI>
 __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args a) {
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL;
-  constexpr int NT = (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_QKV_ROPE) ? 2 : 1;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   __shared__ float red[kWaves][NT][256];
   __shared__ float ssq[kWaves][16];
   __shared__ float rstd_s[16];
@@ -107,14 +112,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
   const int nchunks = (a.K + KC - 1) / KC;
   int tile[NT];
   const u32x4* wp[NT];
-  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
-    const int hst = a.kv.head_size / 16, half = hst / 2;
-    const int h = blockIdx.x / half, r = blockIdx.x - h * half;
-    tile[0] = h * hst + r;
-    tile[1] = tile[0] + half;
-    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
-    wp[1] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[1] * nchunks * 64 + lane;
-  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+  if constexpr (EPI == UA2_EPI_SWIGLU) {
     tile[0] = tile[1] = blockIdx.x;
     wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
     wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)tile[0] * nchunks * 64 + lane;
@@ -237,7 +235,7 @@ int launch_epi(const ua2_linear_args& a, hipStream_t s) {
       hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_SWIGLU>), dim3(ntiles, mtiles), block, 0, s, a);
       break;
     case UA2_EPI_QKV_ROPE:
-      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_QKV_ROPE>), dim3(ntiles / 2, mtiles), block, 0, s, a);
+      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_QKV_ROPE>), dim3(ntiles, mtiles), block, 0, s, a);
       break;
     default:
       ua2_set_error("ua2_linear: bad epilogue %d", a.epilogue);
@@ -333,20 +331,22 @@ extern "C" size_t ua2_packed_elems(int dtype, int64_t N, int64_t K) {
 }
 
 extern "C" int ua2_pack_linear(const void* src, int src_dtype, int transposed, int64_t N, int64_t K, void* out,
-                               int dtype, void* stream) {
+                               int dtype, int rope_head_size, void* stream) {
   UA2_CHECK(src && out && N > 0 && K > 0, "ua2_pack_linear: bad arguments");
+  UA2_CHECK(rope_head_size == 0 || (rope_head_size % 32 == 0 && N % rope_head_size == 0),
+            "ua2_pack_linear: rope_head_size=%d must divide N and be a multiple of 32", rope_head_size);
   const int64_t total = (int64_t)ua2_packed_elems(dtype, N, K);
   const int threads = 256;
   const int blocks = (int)((total + threads - 1) / threads < 65535 * 16 ? (total + threads - 1) / threads : 65535 * 16);
   hipStream_t s = (hipStream_t)stream;
   if (src_dtype == UA2_F32 && dtype == UA2_F32)
-    hipLaunchKernelGGL((pack_kernel<UA2_F32, UA2_F32>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+    hipLaunchKernelGGL((pack_kernel<UA2_F32, UA2_F32>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total, rope_head_size);
   else if (src_dtype == UA2_F32 && dtype == UA2_BF16)
-    hipLaunchKernelGGL((pack_kernel<UA2_F32, UA2_BF16>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+    hipLaunchKernelGGL((pack_kernel<UA2_F32, UA2_BF16>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total, rope_head_size);
   else if (src_dtype == UA2_BF16 && dtype == UA2_BF16)
-    hipLaunchKernelGGL((pack_kernel<UA2_BF16, UA2_BF16>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+    hipLaunchKernelGGL((pack_kernel<UA2_BF16, UA2_BF16>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total, rope_head_size);
   else if (src_dtype == UA2_BF16 && dtype == UA2_F32)
-    hipLaunchKernelGGL((pack_kernel<UA2_BF16, UA2_F32>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total);
+    hipLaunchKernelGGL((pack_kernel<UA2_BF16, UA2_F32>), dim3(blocks), dim3(threads), 0, s, src, out, transposed, N, K, total, rope_head_size);
   else {
     ua2_set_error("ua2_pack_linear: bad dtypes %d -> %d", src_dtype, dtype);
     return -1;

@@ -80,35 +80,36 @@ __device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, c
       const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
       a.y[(size_t)mr * a.ldy + n] = sg * v[1];
     }
-  } else {  // UA2_EPI_QKV_ROPE
+  } else {  // UA2_EPI_QKV_ROPE — weight rows were permuted at pack time (ua2_pack_linear rope_head_size):
+    // tile r of a head holds dims [8r, 8r+8) in columns 0-7 and their rotation partners
+    // [hs/2+8r, hs/2+8r+8) in columns 8-15, so the half-split rotation closes inside one tile.
+    const float other = __shfl_xor(v[0], 8);   // partner column, same row (all 256 threads participate)
     if (!rvalid) return;
     const int hs = a.kv.head_size, half = hs / 2;
-    const int n0 = tile[0] * 16 + col;  // column in the fused qkv output
-    const int h = n0 / hs, d = n0 - h * hs;  // d < half
+    const int n0 = tile[0] * 16;
+    const int h = n0 / hs, r = (n0 - h * hs) / 16;
+    const bool lo_half = col < 8;
+    const int d = r * 8 + (col & 7);           // dim in [0, half)
     const int pos = a.row_pos[mr];
-    const float x1 = v[0], x2 = v[1];
+    const float x1 = lo_half ? v[0] : other;   // x[d]
+    const float x2 = lo_half ? other : v[0];   // x[d + half]
+    float out;
     if (h < a.kv.n_head + a.kv.n_kv) {
       const float cs = a.rope_cos[(size_t)pos * half + d], sn = a.rope_sin[(size_t)pos * half + d];
       // roped = x*cos + rotate_half(x)*sin  (lit_model.py:795-806), products rounded separately
-      const float lo = __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn));
-      const float hi = __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
-      if (h < a.kv.n_head) {
-        float* q = a.q_out + (size_t)mr * a.kv.n_head * hs + (size_t)h * hs;
-        q[d] = lo;
-        q[d + half] = hi;
-      } else {
-        const int kvh = h - a.kv.n_head;
-        const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
-        const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
-        store_elem<DT>(a.kv.k_pool, base + d, lo);
-        store_elem<DT>(a.kv.k_pool, base + d + half, hi);
-      }
+      out = lo_half ? __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn)) : __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
     } else {
-      const int kvh = h - a.kv.n_head - a.kv.n_kv;
+      out = v[0];
+    }
+    const int dd = lo_half ? d : d + half;
+    if (h < a.kv.n_head) {
+      a.q_out[(size_t)mr * a.kv.n_head * hs + (size_t)h * hs + dd] = out;
+    } else {
+      const bool is_k = h < a.kv.n_head + a.kv.n_kv;
+      const int kvh = is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv;
       const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
       const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
-      store_elem<DT>(a.kv.v_pool, base + d, x1);
-      store_elem<DT>(a.kv.v_pool, base + d + half, x2);
+      store_elem<DT>(is_k ? a.kv.k_pool : a.kv.v_pool, base + dd, out);
     }
   }
 }

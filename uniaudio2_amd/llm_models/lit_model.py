@@ -137,7 +137,8 @@ class GPT(nn.Module):
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         pk = lambda lin: ops.pack_linear(lin.weight.detach().to(device), dtype)
         plan = dict(dtype=dtype, device=device, batch=batch_size, max_seq=max_seq_length)
-        plan["qkv"] = [pk(b.attn.qkv) for b in self.transformer.h]
+        plan["qkv"] = [ops.pack_linear(b.attn.qkv.weight.detach().to(device), dtype, rope_head_size=cfg.head_size)
+                       for b in self.transformer.h]
         plan["proj"] = [pk(b.attn.proj) for b in self.transformer.h]
         plan["fc1"] = [pk(b.mlp.fc_1) for b in self.transformer.h]
         plan["fc2"] = [pk(b.mlp.fc_2) for b in self.transformer.h]

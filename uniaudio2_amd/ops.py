@@ -35,7 +35,7 @@ def packed_elems(dtype, N, K):
     return lib.ua2_packed_elems(dtype_code(dtype), N, K)
 
 
-def pack_linear(weight, dtype, transposed=False):
+def pack_linear(weight, dtype, transposed=False, rope_head_size=0):
     """nn.Linear.weight [N,K] (or [K,N] with transposed=True) -> MFMA-fragment-ordered buffer of `dtype`."""
     assert weight.dim() == 2 and weight.is_cuda
     w = weight.contiguous()
@@ -44,7 +44,7 @@ def pack_linear(weight, dtype, transposed=False):
     N, K = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
     out = torch.empty(packed_elems(dtype, N, K), dtype=dtype, device=w.device)
     check(lib.ua2_pack_linear(ptr(w), dtype_code(w.dtype), int(transposed), N, K, ptr(out), dtype_code(dtype),
-                              stream()), "ua2_pack_linear")
+                              rope_head_size, stream()), "ua2_pack_linear")
     return out
 
 
