@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const ua2_attn_args 
   const int G = a.kv.n_head / a.kv.n_kv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, rin = lane / LPR;
-  const int page = a.kv.page_table[(size_t)a.row_seq[r] * a.kv.max_pages + pg];
+  const int page = a.kv.page_table[(size_t)(a.row_seq ? a.row_seq[r] : r) * a.kv.max_pages + pg];
   const size_t pbase = ((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE * HS;
   const float scale = 1.0f / sqrtf((float)HS);
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
 
   const int r = blockIdx.x, kvh = blockIdx.y;
   const int pos = a.row_pos[r];
-  const int seq = a.row_seq[r];
+  const int seq = a.row_seq ? a.row_seq[r] : r;   // NULL: row r is sequence r (decode batches)
   const int n = pos + 1;
   const int G = a.kv.n_head / a.kv.n_kv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -380,7 +380,7 @@ int launch_hs(const ua2_attn_args& a, hipStream_t s) {
 
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
   UA2_CHECK(a.R > 0, "ua2_attn: R=%d", a.R);
-  UA2_CHECK(a.q && a.row_pos && a.row_seq && (a.y || (a.attn_o && a.attn_ml)) && a.kv.k_pool && a.kv.v_pool &&
+  UA2_CHECK(a.q && a.row_pos && (a.y || (a.attn_o && a.attn_ml)) && a.kv.k_pool && a.kv.v_pool &&
                 a.kv.page_table,
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,

@@ -51,6 +51,28 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
   const int c0 = (wave * nchunks) / nw, c1 = ((wave + 1) * nchunks) / nw;
   const int last = max(c1 - 1, 0);
 
+  // Issue order matters: a wave's loads return in order, so everything small that the prologue or
+  // the epilogue needs goes out BEFORE the weight burst (it then completes in one L2 round trip
+  // while the weights are still streaming), never behind it.
+  constexpr int XPT = 2;  // float4 per thread kept in registers on the single-row fast path
+  const bool one = (rows == 1) && (a.K <= XPT * 4 * nthreads);
+  float4 xv[XPT], nv[XPT];
+  if (one) {
+    const float* xr = a.x + (size_t)m0 * a.ldx;
+#pragma unroll
+    for (int it = 0; it < XPT; ++it) {
+      const int k = (tid + it * nthreads) * 4;
+      xv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      nv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (k < a.K) {
+        xv[it] = *reinterpret_cast<const float4*>(xr + k);
+        if constexpr (PRO == UA2_PRO_NORM) nv[it] = *reinterpret_cast<const float4*>(a.norm_w + k);
+      }
+    }
+  }
+  EpiPre pre;
+  if (tid < 256) epilogue_prefetch<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre);
+
   u32x4 wf[NT][CPW];
 #pragma unroll
   for (int u = 0; u < CPW; ++u)
@@ -58,55 +80,85 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
     for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(c0 + u, last) * 64);
 
   // ---- stage the activation rows into LDS (operand dtype) ----
-  if constexpr (PRO == UA2_PRO_NORM) {
-    // pass 1: sum of squares per row
-    for (int r0 = 0; r0 < rows; ++r0) {
-      const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
+  auto put = [&](int r0, int k, float4 t) {
+    char* dst = a_lds + ((size_t)r0 * a_stride + k) * BYTES;
+    if constexpr (DT == UA2_BF16) {
+      uint2 p;
+      p.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
+      p.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
+      *reinterpret_cast<uint2*>(dst) = p;
+    } else {
+      *reinterpret_cast<float4*>(dst) = t;
+    }
+  };
+  if (one) {
+    float rs = 1.f;
+    if constexpr (PRO == UA2_PRO_NORM) {
       float ss = 0.f;
-      for (int k = tid * 4; k < a.K; k += nthreads * 4) {
-        const float4 t = *reinterpret_cast<const float4*>(xr + k);
-        ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
-      }
+#pragma unroll
+      for (int it = 0; it < XPT; ++it)
+        ss += xv[it].x * xv[it].x + xv[it].y * xv[it].y + xv[it].z * xv[it].z + xv[it].w * xv[it].w;
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-      if (lane == 0) ssq[wave * 16 + r0] = ss;
-    }
-    __syncthreads();
-    if (tid < rows) {
+      if (lane == 0) ssq[wave * 16] = ss;
+      __syncthreads();
       float t = 0.f;
-      for (int w = 0; w < nw; ++w) t += ssq[w * 16 + tid];
-      rstd_s[tid] = 1.0f / sqrtf(t / (float)a.K + a.eps);  // torch.rsqrt(mean(x*x) + eps), lit_model.py:886-887
+      for (int w = 0; w < nw; ++w) t += ssq[w * 16];      // every thread, same order: no second barrier
+      rs = 1.0f / sqrtf(t / (float)a.K + a.eps);          // torch.rsqrt(mean(x*x) + eps), lit_model.py:886-887
     }
-    __syncthreads();
-  }
-  for (int r0 = 0; r0 < rows; ++r0) {
-    const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
-    float rs = 1.f;
-    if constexpr (PRO == UA2_PRO_NORM) rs = rstd_s[r0];
-    for (int k = tid * 4; k < a.K; k += nthreads * 4) {
-      float4 t = *reinterpret_cast<const float4*>(xr + k);
-      if constexpr (PRO == UA2_PRO_NORM) {
-        const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
-        t.x = __fmul_rn(__fmul_rn(t.x, rs), w.x);  // (x*rstd)*w, lit_model.py:887-889
-        t.y = __fmul_rn(__fmul_rn(t.y, rs), w.y);
-        t.z = __fmul_rn(__fmul_rn(t.z, rs), w.z);
-        t.w = __fmul_rn(__fmul_rn(t.w, rs), w.w);
-      }
-      char* dst = a_lds + ((size_t)r0 * a_stride + k) * BYTES;
-      if constexpr (DT == UA2_BF16) {
-        uint2 p;
-        p.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
-        p.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
-        *reinterpret_cast<uint2*>(dst) = p;
-      } else {
-        *reinterpret_cast<float4*>(dst) = t;
+#pragma unroll
+    for (int it = 0; it < XPT; ++it) {
+      const int k = (tid + it * nthreads) * 4;
+      if (k < nchunks * KC) {                             // also zero-fills the K padding of the last chunk
+        float4 t = xv[it];
+        if constexpr (PRO == UA2_PRO_NORM) {
+          t.x = __fmul_rn(__fmul_rn(t.x, rs), nv[it].x);  // (x*rstd)*w, lit_model.py:887-889
+          t.y = __fmul_rn(__fmul_rn(t.y, rs), nv[it].y);
+          t.z = __fmul_rn(__fmul_rn(t.z, rs), nv[it].z);
+          t.w = __fmul_rn(__fmul_rn(t.w, rs), nv[it].w);
+        }
+        put(0, k, t);
       }
     }
-    // zero the K padding of the last chunk (K is a multiple of EPL, the padded tail is whole lanes)
-    for (int k = a.K + tid * 4; k < nchunks * KC; k += nthreads * 4) {
-      char* dst = a_lds + ((size_t)r0 * a_stride + k) * BYTES;
-      if constexpr (DT == UA2_BF16) *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);
-      else *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    if constexpr (PRO == UA2_PRO_NORM) {
+      for (int r0 = 0; r0 < rows; ++r0) {  // pass 1: sum of squares per row
+        const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
+        float ss = 0.f;
+        for (int k = tid * 4; k < a.K; k += nthreads * 4) {
+          const float4 t = *reinterpret_cast<const float4*>(xr + k);
+          ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) ssq[wave * 16 + r0] = ss;
+      }
+      __syncthreads();
+      if (tid < rows) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += ssq[w * 16 + tid];
+        rstd_s[tid] = 1.0f / sqrtf(t / (float)a.K + a.eps);
+      }
+      __syncthreads();
+    }
+    for (int r0 = 0; r0 < rows; ++r0) {
+      const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
+      float rs = 1.f;
+      if constexpr (PRO == UA2_PRO_NORM) rs = rstd_s[r0];
+      for (int k = tid * 4; k < nchunks * KC; k += nthreads * 4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < a.K) {
+          t = *reinterpret_cast<const float4*>(xr + k);
+          if constexpr (PRO == UA2_PRO_NORM) {
+            const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
+            t.x = __fmul_rn(__fmul_rn(t.x, rs), w.x);
+            t.y = __fmul_rn(__fmul_rn(t.y, rs), w.y);
+            t.z = __fmul_rn(__fmul_rn(t.z, rs), w.z);
+            t.w = __fmul_rn(__fmul_rn(t.w, rs), w.w);
+          }
+        }
+        put(r0, k, t);
+      }
     }
   }
   __syncthreads();
@@ -150,7 +202,7 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
     for (int w = 0; w < nw; ++w) s += red[(w * NT + t) * 256 + src];
     v[t] = s;
   }
-  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col);
+  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre);
 }
 
 struct Geometry {

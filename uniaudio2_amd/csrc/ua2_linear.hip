@@ -216,7 +216,9 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
     for (int w = 0; w < kWaves; ++w) s += red[w][t][src];
     v[t] = s;
   }
-  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col);
+  EpiPre pre;
+  epilogue_prefetch<DT, EPI>(a, tile[0], row, col, pre);
+  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre);
 }
 
 template <int DT, int PRO>
@@ -279,7 +281,7 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
   if (a.epilogue == UA2_EPI_QKV_ROPE) {
     UA2_CHECK(a.kv.head_size % 32 == 0 && a.N == (a.kv.n_head + 2 * a.kv.n_kv) * a.kv.head_size,
               "ua2_linear: QKV_ROPE needs head_size %% 32 == 0 and N == (n_head+2*n_kv)*head_size");
-    UA2_CHECK(a.row_pos && a.row_seq && a.rope_cos && a.rope_sin && a.q_out && a.kv.k_pool && a.kv.v_pool &&
+    UA2_CHECK(a.row_pos && a.rope_cos && a.rope_sin && a.q_out && a.kv.k_pool && a.kv.v_pool &&
                   a.kv.page_table,
               "ua2_linear: QKV_ROPE pointer arguments missing");
   }

@@ -44,10 +44,44 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&f)
 
 
 // ---- epilogues (thread = one (row, col) of the 16 x 16 output tile; v[t] = reduced sums) ----
-// NOTE: uses 16-lane shuffles for the arg-max partials: call with all 256 epilogue threads.
+// Split in two so the decode kernel can issue the epilogue's global loads (residual, position,
+// RoPE table entries, page id, forbid_prefix) at kernel entry, in the shadow of the weight stream,
+// instead of as dependent loads after the reduction.
+struct EpiPre {
+  float resid = 0.f, cs = 0.f, sn = 0.f;
+  int pos = 0, page = 0, forbid = 0;
+};
+
+// table row of the paged KV cache for matrix row mr: row_seq == NULL means "row r is sequence r"
+__device__ __forceinline__ int kv_table_row(const ua2_linear_args& a, int mr) { return a.row_seq ? a.row_seq[mr] : mr; }
+
+template <int DT, int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
+  const int mr = blockIdx.y * 16 + row;
+  if (mr >= a.M) return;
+  const int n = tile0 * 16 + col;
+  if constexpr (EPI == UA2_EPI_STORE) {
+    if (a.part_max && a.forbid) p.forbid = a.forbid[mr];
+  } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    if (n < a.N) p.resid = a.resid[(size_t)mr * a.ldr + n];
+  } else if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    const int hs = a.kv.head_size, half = hs / 2;
+    const int n0 = tile0 * 16;
+    const int h = n0 / hs, r = (n0 - h * hs) / 16;
+    const int d = r * 8 + (col & 7);
+    p.pos = a.row_pos[mr];
+    if (h < a.kv.n_head + a.kv.n_kv) {
+      p.cs = a.rope_cos[(size_t)p.pos * half + d];
+      p.sn = a.rope_sin[(size_t)p.pos * half + d];
+    }
+    if (h >= a.kv.n_head) p.page = a.kv.page_table[(size_t)kv_table_row(a, mr) * a.kv.max_pages + p.pos / UA2_PAGE];
+  }
+}
+
+// NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.
 template <int DT, int EPI, int NT>
-__device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, const float (&v)[NT],
-                                                     const int (&tile)[NT], int row, int col) {
+__device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&v)[NT], const int (&tile)[NT],
+                                                int row, int col, const EpiPre& p) {
   const int mr = blockIdx.y * 16 + row;
   const bool rvalid = mr < a.M;
 
@@ -55,8 +89,7 @@ __device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, c
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N && a.y) a.y[(size_t)mr * a.ldy + n] = v[0];
     if (a.part_max) {
-      const int fb = (a.forbid && rvalid) ? a.forbid[mr] : 0;
-      float bv = (n < a.N && n >= fb) ? v[0] : -INFINITY;
+      float bv = (n < a.N && n >= p.forbid) ? v[0] : -INFINITY;
       int bi = n;
 #pragma unroll
       for (int o = 8; o >= 1; o >>= 1) {  // 16-lane groups; ties -> lowest index
@@ -72,7 +105,7 @@ __device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, c
     }
   } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
     const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = v[0] + a.resid[(size_t)mr * a.ldr + n];
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = v[0] + p.resid;
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {
@@ -90,16 +123,12 @@ __device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, c
     const int h = n0 / hs, r = (n0 - h * hs) / 16;
     const bool lo_half = col < 8;
     const int d = r * 8 + (col & 7);           // dim in [0, half)
-    const int pos = a.row_pos[mr];
     const float x1 = lo_half ? v[0] : other;   // x[d]
     const float x2 = lo_half ? other : v[0];   // x[d + half]
-    float out;
+    float out = v[0];
     if (h < a.kv.n_head + a.kv.n_kv) {
-      const float cs = a.rope_cos[(size_t)pos * half + d], sn = a.rope_sin[(size_t)pos * half + d];
       // roped = x*cos + rotate_half(x)*sin  (lit_model.py:795-806), products rounded separately
-      out = lo_half ? __fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn)) : __fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn));
-    } else {
-      out = v[0];
+      out = lo_half ? __fadd_rn(__fmul_rn(x1, p.cs), __fmul_rn(-x2, p.sn)) : __fadd_rn(__fmul_rn(x2, p.cs), __fmul_rn(x1, p.sn));
     }
     const int dd = lo_half ? d : d + half;
     if (h < a.kv.n_head) {
@@ -107,15 +136,8 @@ __device__ __forceinline__ void linear_epilogue_impl(const ua2_linear_args& a, c
     } else {
       const bool is_k = h < a.kv.n_head + a.kv.n_kv;
       const int kvh = is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv;
-      const int page = a.kv.page_table[(size_t)a.row_seq[mr] * a.kv.max_pages + pos / UA2_PAGE];
-      const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs;
+      const size_t base = (((size_t)p.page * a.kv.n_kv + kvh) * UA2_PAGE + (p.pos % UA2_PAGE)) * hs;
       store_elem<DT>(is_k ? a.kv.k_pool : a.kv.v_pool, base + dd, out);
     }
   }
-}
-
-template <int DT, int EPI, int NT>
-__device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&v)[NT], const int (&tile)[NT],
-                                                int row, int col) {
-  linear_epilogue_impl<DT, EPI, NT>(a, v, tile, row, col);
 }

@@ -181,10 +181,11 @@ extern "C" int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages) {
   return 0;
 }
 
-extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
+// identity: rows are sequences 0..R-1 (decode frames) -> no row_seq indirection in the kernels
+static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_rows, "ua2_stage3_trunk: R=%d out of range", R);
-  hipStream_t s = (hipStream_t)stream;
-  const ua2_stage3_desc& d = h->d;
+  ua2_stage3_desc d = h->d;
+  if (identity) d.row_seq = nullptr;
   const int C = d.backbone.n_embd, w = d.n_cb + 1;
   if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, s)) return rc;
   if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
@@ -197,6 +198,11 @@ extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
   // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, s)) return rc;
   return 0;
+}
+
+extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
+  UA2_CHECK(h != nullptr, "ua2_stage3_trunk: NULL handle");
+  return trunk_impl(h, R, false, (hipStream_t)stream);
 }
 
 extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
@@ -218,7 +224,7 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
     if (int rc = ua2_linear_launch(a, s)) return rc;
-    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, d.dec_seq, 1, s)) return rc;
+    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, 1, s)) return rc;
     memset(&a, 0, sizeof(a));
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
@@ -248,7 +254,7 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
   UA2_CHECK(h != nullptr, "ua2_stage3_frame: NULL handle");
   hipStream_t s = (hipStream_t)stream;
   auto body = [&](hipStream_t st) -> int {
-    if (int rc = ua2_stage3_trunk(h, R, st)) return rc;
+    if (int rc = trunk_impl(h, R, true, st)) return rc;
     if (int rc = ua2_stage3_heads(h, R, st)) return rc;
     if (mode < 0) return 0;
     return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, st);
