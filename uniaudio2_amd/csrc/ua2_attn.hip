@@ -196,16 +196,22 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 template <int DT, int HS>
 __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_attn_args a) {
   constexpr int EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
-  constexpr int LPR = HS / EPL, RPW = 64 / LPR;
+  constexpr int LPR = HS / EPL, RPW = 64 / LPR;   // lanes per cache row, row groups per wave
   constexpr int UNR = (DT == UA2_BF16) ? 4 : 2;   // wave instructions per step (K and V each)
-  __shared__ float w_m[kFusedWaves][kMaxG], w_l[kFusedWaves][kMaxG];
-  __shared__ float w_o[kFusedWaves][kMaxG][HS];
-
+  constexpr int NS = kFusedWaves * RPW;           // independent online-softmax states per workgroup
+  // Every 16-/8-lane row group keeps its own (m, l, o) state: no cross-group traffic inside the
+  // loop (the first version spent ~6 us in serialized ds_bpermute chains).  States merge once,
+  // through LDS, in (wave, group) order.
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int r = blockIdx.x, kvh = blockIdx.y;
+  const int G = a.kv.n_head / a.kv.n_kv;
+  float* st_m = sm;                    // [NS][G]
+  float* st_l = st_m + NS * kMaxG;     // [NS][G]
+  float* st_o = st_l + NS * kMaxG;     // [NS][G][HS]
+
   const int pos = a.row_pos[r];
   const int seq = a.row_seq ? a.row_seq[r] : r;   // NULL: row r is sequence r (decode batches)
   const int n = pos + 1;
-  const int G = a.kv.n_head / a.kv.n_kv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, rin = lane / LPR;
   const float scale = 1.0f / sqrtf((float)HS);
@@ -218,8 +224,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
 #pragma unroll
   for (int h = 0; h < kMaxG; ++h) {
     const float* qp = a.q + ((size_t)r * a.kv.n_head + (size_t)kvh * G + (h < G ? h : 0)) * HS + sub * EPL;
+    const float sc = (h < G) ? scale : 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) q[h][e] = (h < G) ? qp[e] * scale : 0.f;
+    for (int e4 = 0; e4 < EPL / 4; ++e4) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 4 * e4);
+      q[h][4 * e4 + 0] = t.x * sc; q[h][4 * e4 + 1] = t.y * sc; q[h][4 * e4 + 2] = t.z * sc; q[h][4 * e4 + 3] = t.w * sc;
+    }
   }
   float m_run[kMaxG], l_run[kMaxG], o_run[kMaxG][EPL];
 #pragma unroll
@@ -230,19 +240,26 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
     for (int e = 0; e < EPL; ++e) o_run[h][e] = 0.f;
   }
 
-  for (int jb = j0; jb < j1; jb += UNR * RPW) {
-    u32x4 kraw[UNR], vraw[UNR];
-    bool ok[UNR];
+  // K/V loads of step t+1 are issued before the arithmetic of step t (one step of prefetch)
+  auto issue = [&](int jb, u32x4 (&kr)[UNR], u32x4 (&vr)[UNR]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = jb + u * RPW + rin;
-      ok[u] = j < j1;
-      const int jc = ok[u] ? j : j0;            // clamp: unconditional loads, masked below
+      const int jc = (j < j1) ? j : j0;           // clamp: unconditional loads, masked in the math
       const size_t off = ((((size_t)ptab[jc / UA2_PAGE] * a.kv.n_kv + kvh) * UA2_PAGE + (jc % UA2_PAGE)) * HS +
                           (size_t)sub * EPL) * BYTES;
-      kraw[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.k_pool + off);
-      vraw[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.v_pool + off);
+      kr[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.k_pool + off);
+      vr[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.v_pool + off);
     }
+  };
+  u32x4 kraw[UNR], vraw[UNR], knext[UNR], vnext[UNR];
+  if (j0 < j1) issue(j0, kraw, vraw);
+  for (int jb = j0; jb < j1; jb += UNR * RPW) {
+    const bool more = jb + UNR * RPW < j1;
+    if (more) issue(jb + UNR * RPW, knext, vnext);
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) ok[u] = (jb + u * RPW + rin) < j1;
     float s[UNR][kMaxG];
     float gmax[kMaxG];
 #pragma unroll
@@ -270,12 +287,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
         gmax[h] = fmaxf(gmax[h], s[u][h]);
       }
     }
+    // online softmax of THIS row group (its rows jb + u*RPW + rin, u < UNR); u = 0 may be masked
+    // for trailing groups, so guard the all-masked case
 #pragma unroll
     for (int h = 0; h < kMaxG; ++h) {
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) gmax[h] = fmaxf(gmax[h], __shfl_xor(gmax[h], o));
-      const float m_new = fmaxf(m_run[h], gmax[h]);   // finite: the first row of a step is valid
-      const float resc = fast_exp(m_run[h] - m_new);  // 0 on the first step
+      const float m_new = fmaxf(m_run[h], gmax[h]);
+      const float resc = (m_new == -INFINITY) ? 1.f : fast_exp(m_run[h] - m_new);
       m_run[h] = m_new;
       l_run[h] *= resc;
 #pragma unroll
@@ -296,62 +313,94 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
       }
 #pragma unroll
       for (int h = 0; h < kMaxG; ++h) {
-        const float p = fast_exp(s[u][h] - m_run[h]);   // 0 for masked rows
-        if (sub == 0) l_run[h] += p;                    // one lane per row counts it
+        const float p = ok[u] ? fast_exp(s[u][h] - m_run[h]) : 0.f;
+        l_run[h] += p;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o_run[h][e] += p * vf[e];
       }
     }
-  }
-  // fold the RPW row groups of the wave, publish the wave state
+    if (more) {
 #pragma unroll
-  for (int h = 0; h < kMaxG; ++h) {
-    float l = l_run[h];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
-    l_run[h] = l;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      float t = o_run[h][e];
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o);
-      o_run[h][e] = t;
+      for (int u = 0; u < UNR; ++u) { kraw[u] = knext[u]; vraw[u] = vnext[u]; }
     }
   }
+  // publish the state of this row group
+  const int sidx = wave * RPW + rin;
 #pragma unroll
   for (int h = 0; h < kMaxG; ++h) {
     if (h < G) {
-      if (lane == 0) { w_m[wave][h] = m_run[h]; w_l[wave][h] = l_run[h]; }
-      if (rin == 0) {
+      if (sub == 0) { st_m[sidx * kMaxG + h] = m_run[h]; st_l[sidx * kMaxG + h] = l_run[h]; }
+      float* o = st_o + ((size_t)sidx * G + h) * HS + sub * EPL;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) w_o[wave][h][sub * EPL + e] = o_run[h][e];
-      }
+      for (int e4 = 0; e4 < EPL / 4; ++e4)
+        *reinterpret_cast<float4*>(o + 4 * e4) =
+            make_float4(o_run[h][4 * e4], o_run[h][4 * e4 + 1], o_run[h][4 * e4 + 2], o_run[h][4 * e4 + 3]);
     }
   }
   __syncthreads();
+  // merge, phase 1: wave h turns the NS (m, l) pairs of head h into normalised weights
+  //   wgt[w] = exp(m_w - M) / sum_w exp(m_w - M) l_w        (0 for groups that saw no row)
+  float* wgt = st_l;   // overwrite l in place
+  if (wave < G) {
+    const int h = wave;
+    constexpr int SPL = (NS + 63) / 64;   // states per lane
+    float mw[SPL], lw[SPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int w = lane + 64 * k;
+      mw[k] = (w < NS) ? st_m[w * kMaxG + h] : -INFINITY;
+      lw[k] = (w < NS) ? st_l[w * kMaxG + h] : 0.f;
+      mx = fmaxf(mx, mw[k]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float f[SPL], den = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      f[k] = (mw[k] == -INFINITY) ? 0.f : fast_exp(mw[k] - mx);
+      den += f[k] * lw[k];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) den += __shfl_xor(den, o);
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const int w = lane + 64 * k;
+      if (w < NS) wgt[w * kMaxG + h] = f[k] * inv;
+    }
+  }
+  __syncthreads();
+  // phase 2: y[h][d] = sum_w wgt[w][h] * o[w][h][d], fixed (wave, group) order
   for (int idx = tid; idx < G * HS; idx += kFusedWaves * 64) {
     const int h = idx / HS, d = idx - h * HS;
-    float mx = w_m[0][h];                          // wave 0 always owns position 0
-#pragma unroll
-    for (int w = 1; w < kFusedWaves; ++w) mx = fmaxf(mx, w_m[w][h]);
-    float num = 0.f, den = 0.f;
-#pragma unroll
-    for (int w = 0; w < kFusedWaves; ++w) {
-      const float f = fast_exp(w_m[w][h] - mx);    // 0 for waves without rows (m = -inf)
-      num += f * w_o[w][h][d];
-      den += f * w_l[w][h];
-    }
-    a.y[((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + d] = num / den;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int w = 0; w < NS; ++w) acc += wgt[w * kMaxG + h] * st_o[((size_t)w * G + h) * HS + d];
+    a.y[((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + d] = acc;
   }
+}
+
+template <int DT, int HS>
+void launch_fused_hs(const ua2_attn_args& a, hipStream_t s) {
+  constexpr int EPL = Elem<DT>::EPL, RPW = 64 / (HS / EPL), NS = kFusedWaves * RPW;
+  const int G = a.kv.n_head / a.kv.n_kv;
+  const size_t smem = (size_t)(2 * NS * kMaxG + (size_t)NS * G * HS) * sizeof(float);
+  auto kern = attn_fused_kernel<DT, HS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.R, a.kv.n_kv), dim3(kFusedWaves * 64), smem, s, a);
 }
 
 template <int DT>
 int launch_fused(const ua2_attn_args& a, hipStream_t s) {
-  const dim3 grid(a.R, a.kv.n_kv), block(kFusedWaves * 64);
   switch (a.kv.head_size) {
-    case 32: hipLaunchKernelGGL((attn_fused_kernel<DT, 32>), grid, block, 0, s, a); break;
-    case 64: hipLaunchKernelGGL((attn_fused_kernel<DT, 64>), grid, block, 0, s, a); break;
-    case 128: hipLaunchKernelGGL((attn_fused_kernel<DT, 128>), grid, block, 0, s, a); break;
+    case 32: launch_fused_hs<DT, 32>(a, s); break;
+    case 64: launch_fused_hs<DT, 64>(a, s); break;
+    case 128: launch_fused_hs<DT, 128>(a, s); break;
     default:
       ua2_set_error("ua2_attn: head_size %d not supported (32, 64, 128)", a.kv.head_size);
       return -1;
@@ -385,7 +434,7 @@ int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
-  UA2_CHECK(a.grid_pages <= a.kv.max_pages, "ua2_attn: grid_pages > max_pages");
+  UA2_CHECK(a.y || a.grid_pages <= a.kv.max_pages, "ua2_attn: grid_pages > max_pages");
   if (a.y) {
     if (a.dtype == UA2_BF16) return launch_fused<UA2_BF16>(a, s);
     if (a.dtype == UA2_F32) return launch_fused<UA2_F32>(a, s);
