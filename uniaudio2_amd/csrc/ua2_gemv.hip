@@ -12,6 +12,8 @@
 //     global loads that serialised behind the weight stream;
 //   * the wave count (8-16) and chunks-per-wave (CPW) are chosen by the launcher so that
 //     waves x CPW tiles K exactly for the model's shapes: no tail, no predicated loads.
+#include <stdlib.h>
+
 #include "ua2_common.h"
 #include "ua2_linear_common.h"
 
@@ -19,8 +21,10 @@ namespace {
 
 constexpr int kMaxWaves = 16;
 
-template <int DT, int PRO, int EPI, int CPW>
-__global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
+// MR = multi-round: <= 8 waves per workgroup, several rounds of CPW chunks per wave, next round's
+// weights prefetched (double buffer); !MR = single burst: up to 16 waves, everything up front.
+template <int DT, int PRO, int EPI, int CPW, bool MR>
+__global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
                                                               const int red_off) {
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
@@ -71,13 +75,14 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
     }
   }
   EpiPre pre;
-  if (tid < 256) epilogue_prefetch<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre);
+  if (tid < 256) epilogue_prefetch_a<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre);
 
   u32x4 wf[NT][CPW];
 #pragma unroll
   for (int u = 0; u < CPW; ++u)
 #pragma unroll
     for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(c0 + u, last) * 64);
+  if (tid < 256) epilogue_prefetch_b<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre);
 
   // ---- stage the activation rows into LDS (operand dtype) ----
   auto put = [&](int r0, int k, float4 t) {
@@ -170,11 +175,14 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
   const bool arow = i < rows;
   const char* abase = a_lds + ((size_t)i * a_stride + g * EPL) * BYTES;
   for (int cb = c0; cb < c1; cb += CPW) {
-    if (cb != c0) {  // further rounds (fp32 / unusual K): reload
+    // multi-round geometries: the next round's weights go out before this round's MFMAs
+    u32x4 wn[NT][MR ? CPW : 1];
+    const bool more = MR && (cb + CPW < c1);
+    if constexpr (MR) if (more) {
 #pragma unroll
       for (int u = 0; u < CPW; ++u)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(cb + u, last) * 64);
+        for (int t = 0; t < NT; ++t) wn[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(cb + CPW + u, last) * 64);
     }
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
@@ -185,6 +193,19 @@ __global__ __launch_bounds__(kMaxWaves * 64) void gemv_kernel(const ua2_linear_a
       af.v = __builtin_bit_cast(decltype(af.v), raw);
 #pragma unroll
       for (int t = 0; t < NT; ++t) af.mma(wf[t][u], acc[t]);
+    }
+    if constexpr (MR) {
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < CPW; ++u)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wf[t][u] = wn[t][u];
+      }
+    } else if (cb + CPW < c1) {  // rare: single-burst geometry that does not tile K exactly
+#pragma unroll
+      for (int u = 0; u < CPW; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(cb + CPW + u, last) * 64);
     }
   }
 
@@ -212,6 +233,16 @@ struct Geometry {
 // waves x cpw == nchunks when possible (no tail); prefer many waves for small grids (latency),
 // fewer + deeper for large grids (two workgroups per CU overlap each other's prologue/epilogue).
 Geometry pick_geometry(int nchunks, int blocks, int nt) {
+  if (const char* e = getenv("UA2_GEMV_GEOM")) {  // experiment hook: "waves,cpw"
+    int w = 0, c = 0;
+    if (sscanf(e, "%d,%d", &w, &c) == 2 && w >= 1 && w <= kMaxWaves && (c == 4 || c == 8 || (c == 16 && nt == 1)) && w <= nchunks &&
+        nchunks % w == 0 && (nchunks / w) % c == 0)
+      return Geometry{w, c};
+  }
+  // measured (tools/ubench/gemv_shapes.py, profiles/r1_gemv_geometry.txt): grids larger than the CU
+  // count stream best as 8-wave workgroups walking K in double-buffered rounds of 4 chunks (two
+  // workgroups per CU overlap each other's reduce/epilogue); smaller grids as one wide burst.
+  if (blocks > 256 && nchunks >= 96 && nchunks % 32 == 0) return Geometry{8, 4};
   const int cap = (nt == 2) ? 8 : 16;
   const int cpws[3] = {4, 8, 16};
   Geometry best{0, 0};
@@ -233,9 +264,9 @@ Geometry pick_geometry(int nchunks, int blocks, int nt) {
   return Geometry{w, c};
 }
 
-template <int DT, int PRO, int EPI, int CPW>
+template <int DT, int PRO, int EPI, int CPW, bool MR>
 void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, int red_off, size_t smem, hipStream_t s) {
-  auto kern = gemv_kernel<DT, PRO, EPI, CPW>;
+  auto kern = gemv_kernel<DT, PRO, EPI, CPW, MR>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -259,12 +290,18 @@ int launch_cpw(const ua2_linear_args& a, hipStream_t s) {
   const int red_off = (int)(((size_t)rows * a_stride * BYTES + 255) & ~(size_t)255);
   const size_t smem = (size_t)red_off + (size_t)(kMaxWaves * NT * 256 + kMaxWaves * 16 + 16) * sizeof(float);
   const dim3 grid(gx, mtiles);
-  switch (geo.cpw) {
-    case 4: launch_one<DT, PRO, EPI, 4>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
-    case 8: launch_one<DT, PRO, EPI, 8>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
-    default:
-      if constexpr (NT == 1) launch_one<DT, PRO, EPI, 16>(a, grid, geo.waves, a_stride, red_off, smem, s);
-      else launch_one<DT, PRO, EPI, 8>(a, grid, geo.waves, a_stride, red_off, smem, s);
+  const bool mr = geo.waves <= 8 && geo.waves * geo.cpw < nchunks;
+  if (mr) {
+    if (geo.cpw == 4) launch_one<DT, PRO, EPI, 4, true>(a, grid, geo.waves, a_stride, red_off, smem, s);
+    else launch_one<DT, PRO, EPI, 8, true>(a, grid, geo.waves, a_stride, red_off, smem, s);
+  } else {
+    switch (geo.cpw) {
+      case 4: launch_one<DT, PRO, EPI, 4, false>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
+      case 8: launch_one<DT, PRO, EPI, 8, false>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
+      default:
+        if constexpr (NT == 1) launch_one<DT, PRO, EPI, 16, false>(a, grid, geo.waves, a_stride, red_off, smem, s);
+        else launch_one<DT, PRO, EPI, 8, false>(a, grid, geo.waves, a_stride, red_off, smem, s);
+    }
   }
   UA2_LAUNCH_CHECK();
   return 0;

@@ -55,8 +55,9 @@ struct EpiPre {
 // table row of the paged KV cache for matrix row mr: row_seq == NULL means "row r is sequence r"
 __device__ __forceinline__ int kv_table_row(const ua2_linear_args& a, int mr) { return a.row_seq ? a.row_seq[mr] : mr; }
 
+// stage A: loads that depend on nothing (issue BEFORE the weight burst)
 template <int DT, int EPI>
-__device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
+__device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
   const int mr = blockIdx.y * 16 + row;
   if (mr >= a.M) return;
   const int n = tile0 * 16 + col;
@@ -65,17 +66,32 @@ __device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int 
   } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
     if (n < a.N) p.resid = a.resid[(size_t)mr * a.ldr + n];
   } else if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    p.pos = a.row_pos[mr];
+    p.page = kv_table_row(a, mr);   // table row for now; resolved to a page id in stage B
+  }
+}
+// stage B: loads that depend on stage A (issue AFTER the weight burst: they queue behind it and are
+// only needed by the epilogue)
+template <int DT, int EPI>
+__device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
+  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    const int mr = blockIdx.y * 16 + row;
+    if (mr >= a.M) return;
     const int hs = a.kv.head_size, half = hs / 2;
     const int n0 = tile0 * 16;
     const int h = n0 / hs, r = (n0 - h * hs) / 16;
     const int d = r * 8 + (col & 7);
-    p.pos = a.row_pos[mr];
     if (h < a.kv.n_head + a.kv.n_kv) {
       p.cs = a.rope_cos[(size_t)p.pos * half + d];
       p.sn = a.rope_sin[(size_t)p.pos * half + d];
     }
-    if (h >= a.kv.n_head) p.page = a.kv.page_table[(size_t)kv_table_row(a, mr) * a.kv.max_pages + p.pos / UA2_PAGE];
+    if (h >= a.kv.n_head) p.page = a.kv.page_table[(size_t)p.page * a.kv.max_pages + p.pos / UA2_PAGE];
   }
+}
+template <int DT, int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
+  epilogue_prefetch_a<DT, EPI>(a, tile0, row, col, p);
+  epilogue_prefetch_b<DT, EPI>(a, tile0, row, col, p);
 }
 
 // NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.

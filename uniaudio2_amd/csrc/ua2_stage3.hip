@@ -8,6 +8,7 @@
 // into a hipGraph and replayed: no host round trip between the 350-odd kernels of a frame and
 // none between frames (the reference synchronises twice per frame, tts_task.py:261,263).
 #include <map>
+#include <stdlib.h>
 #include <string.h>
 #include <tuple>
 #include <vector>
@@ -27,7 +28,11 @@ struct ua2_stage3 {
   int32_t *pidx_t, *pidx_a;
   int32_t npart_t, npart_a;
   int32_t grid_pages;
-  hipStream_t cap_stream = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
+  hipStream_t cap_stream = nullptr;
+  // optional (UA2_FORK_LM_HEAD=1): lm_head + text arg-max on a side stream, concurrent with the 8-step
+  // local decoder (they only share read-only inputs)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
   std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
 };
 
@@ -172,6 +177,9 @@ extern "C" void ua2_stage3_destroy(ua2_stage3* h) {
   if (!h) return;
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
 }
 
@@ -216,8 +224,23 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
   a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
   a.M = R; a.N = d.vt; a.K = C; a.x = h->hfin; a.ldx = C; a.w0 = d.lm_head; a.y = h->text_logits; a.ldy = d.vt;
   a.part_max = h->pmax_t; a.part_idx = h->pidx_t;
-  if (int rc = ua2_linear_launch(a, s)) return rc;
-  if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr, s)) return rc;
+  if (!h->side_stream) {
+    UA2_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    UA2_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    UA2_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  // measured (profiles/r1_notes.md): the forked graph replays 0.4 ms/frame SLOWER than the linear
+  // chain on ROCm 7.2 (3.60 vs 3.21 ms), so the fork is opt-in for experiments only
+  static const bool no_fork = getenv("UA2_FORK_LM_HEAD") == nullptr;
+  hipStream_t side = no_fork ? s : h->side_stream;
+  if (!no_fork) {
+    UA2_HIP(hipEventRecord(h->ev_fork, s));
+    UA2_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
+  }
+  if (int rc = ua2_linear_launch(a, side)) return rc;
+  if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
+                                side)) return rc;
+  if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
   const float* curr = h->hfin;
   for (int i = 0; i < d.n_cb; ++i) {                               // model_new.py:630-641
     memset(&a, 0, sizeof(a));
@@ -235,6 +258,7 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
                                   i * d.va, C, h->curr_h, s)) return rc;
     curr = h->curr_h;
   }
+  if (!no_fork) UA2_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
   return 0;
 }
 
