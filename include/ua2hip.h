@@ -158,6 +158,19 @@ int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const float* part_max
                      int32_t* out_tokens, int32_t out_ld, int32_t out_col,
                      const void* emb, int32_t emb_row_offset, int32_t C, float* next_h, void* stream);
 
+/* ---- codec: residual vector quantisation ------------------------------------------------ */
+
+/* Nearest-codeword search, level by level on the residual (core_vq.py:179-185, 365-376; the live codec's
+ * ResidualVQ calls AudioDiffusion1D.py:388,529,535,544).  x [N,D] fp32 in codebook space (after any
+ * project_in), emb [L,C,D] fp32, embT [L,D,C] = the same codebooks k-major (coalesced scan).
+ * codes [N,L] int32; quantized [N,D] = sum of the chosen codewords (may be NULL).
+ * d2 = sum_k fma(x_k-e_k, x_k-e_k, .), k ascending; lowest index wins ties (= oracle/rvq_oracle.c bit for bit). */
+int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C, int32_t D,
+                   int32_t* codes, float* quantized, void* stream);
+/* Lookup + sum over levels (core_vq.py:378-384; AudioDiffusion1D.py:577-583 get_output_from_indices). */
+int ua2_rvq_decode(const int32_t* codes, const float* emb, int64_t N, int32_t L, int32_t C, int32_t D, float* out,
+                   void* stream);
+
 /* ---- whole-frame executor -------------------------------------------------------------- */
 
 typedef struct ua2_gpt_desc {

@@ -66,6 +66,8 @@ _EXPORTS = {
     "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]),
     "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
+    "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
+    "ua2_rvq_decode": (C.c_int, [vp, vp, i64, i32, i32, i32, vp, vp]),
     "ua2_stage3_scratch_floats": (C.c_size_t, [C.POINTER(Stage3Desc)]),
     "ua2_stage3_create": (C.c_int, [C.POINTER(Stage3Desc), C.POINTER(vp)]),
     "ua2_stage3_destroy": (None, [vp]),

@@ -120,3 +120,24 @@ def argmax_embed(dtype, part_max, part_idx, out_tokens, out_col, emb=None, emb_r
     check(lib.ua2_argmax_embed(dtype_code(dtype), M, n_part, ptr(part_max), ptr(part_idx), ptr(out_tokens),
                                out_tokens.shape[1], out_col, ptr(emb), emb_row_offset,
                                emb.shape[1] if emb is not None else 0, ptr(next_h), stream()), "ua2_argmax_embed")
+
+
+def rvq_encode(x, emb, embT=None):
+    """x [N,D] fp32, emb [L,C,D] fp32 -> codes [N,L] int32, quantized [N,D] fp32 (core_vq.py:365-376)."""
+    N, D = x.shape
+    L, Cc, _ = emb.shape
+    if embT is None:
+        embT = emb.transpose(1, 2).contiguous()
+    codes = torch.empty(N, L, dtype=torch.int32, device=x.device)
+    q = torch.empty(N, D, dtype=torch.float32, device=x.device)
+    check(lib.ua2_rvq_encode(ptr(x), ptr(emb), ptr(embT), N, L, Cc, D, ptr(codes), ptr(q), stream()), "ua2_rvq_encode")
+    return codes, q
+
+
+def rvq_decode(codes, emb):
+    """codes [N,L] int32, emb [L,C,D] -> [N,D] fp32 (core_vq.py:378-384)."""
+    N, L = codes.shape
+    _, Cc, D = emb.shape
+    out = torch.empty(N, D, dtype=torch.float32, device=emb.device)
+    check(lib.ua2_rvq_decode(ptr(codes), ptr(emb), N, L, Cc, D, ptr(out), stream()), "ua2_rvq_decode")
+    return out
