@@ -238,7 +238,8 @@ int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream);
 /* model_new.py:617-641: lm_head + greedy text sample, then the 8-step local decoder. */
 int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream);
 /* Feedback for the next frame, on device (evaluation/tts_task.py:259-280 mode 0 "audio";
- * evaluation/asr_task.py:668-682 mode 1 "text"): logs out_tokens, builds the next input frame,
+ * evaluation/asr_task.py:668-682 mode 1 "text"; mode 2 = "audio" with every row continuing from row 0's
+ * sample, the classifier-free-guidance pair of tts_task.py:256-258,278-280): logs out_tokens, builds the next input frame,
  * row_pos += 1, applies the reason_eos -> forbid_prefix switch (tts_task.py:263-266). */
 int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card, void* stream);
 /* trunk + heads + feedback (mode < 0: no feedback), captured once into a hipGraph and replayed

@@ -1,0 +1,132 @@
+"""Host logic of the generators (no GPU): prompt layout and the phase / EOS bookkeeping, against a
+direct restatement of the reference's loops (evaluation/tts_task.py:192-205,253-284; asr_task.py:299-326)."""
+import types
+
+import pytest
+import torch
+
+from uniaudio2_amd.evaluation._generator import GeneratorBase, PhaseSplitter
+
+TA = types.SimpleNamespace(text_pad_token=128004, semantic_pad_token=9, semantic_eos=8193, semantic_bos=8192,
+                           reason_eos=4097, reason_bos=4096, reason_pad_token=7, parallel_number=9,
+                           audio_reason_card=4100)
+
+
+def reference_loop(frames, reason_eos, semantic_eos, reason_card):
+    """tts_task.py:253-284 restated on a given stream of (1, 8) samples."""
+    is_reason, save_flag = True, True
+    pre_r, pre_s = [], []
+    for audio in frames:
+        if torch.all(audio == (semantic_eos + reason_card)):
+            break
+        if torch.all(audio == reason_eos):
+            is_reason = False
+            save_flag = False
+        if save_flag:
+            if is_reason:
+                pre_r.append(audio)
+            else:
+                pre_s.append(audio - reason_card)
+        else:
+            save_flag = True
+    return (torch.stack(pre_r[1:]).permute(1, 2, 0).squeeze(0), torch.stack(pre_s[1:]).permute(1, 2, 0).squeeze(0))
+
+
+@pytest.mark.parametrize("n_reason,n_sem,tail", [(5, 9, 3), (2, 2, 0), (20, 50, 7)])
+def test_phase_splitter_equals_reference_loop(n_reason, n_sem, tail):
+    g = torch.Generator().manual_seed(n_reason * 100 + n_sem)
+    frames = [torch.randint(0, 4096, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_reason)]
+    frames.append(torch.full((1, 8), TA.reason_eos, dtype=torch.int32))
+    frames += [torch.randint(4100, 4100 + 8192, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_sem)]
+    frames.append(torch.full((1, 8), TA.semantic_eos + TA.audio_reason_card, dtype=torch.int32))
+    frames += [torch.randint(0, 100, (1, 8), generator=g, dtype=torch.int32) for _ in range(tail)]   # computed past EOS, discarded
+    ph = PhaseSplitter(TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+    for f in frames:
+        ph.push(f)
+    r, s = ph.result()
+    rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+    assert torch.equal(r, rr) and torch.equal(s, rs)
+    assert r.shape == (8, n_reason - 1) and s.shape == (8, n_sem - 1) and r.dtype == torch.int32
+
+
+def test_phase_splitter_raises_like_reference_when_empty():
+    ph = PhaseSplitter(TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+    ph.push(torch.zeros(1, 8, dtype=torch.int32))
+    with pytest.raises(RuntimeError):
+        ph.result()
+
+
+def _gen():
+    g = GeneratorBase.__new__(GeneratorBase)
+    for k, v in vars(TA).items():
+        setattr(g, k, v)
+    g.empty_token = 0
+    g.special_token_dict = g.get_special_token()
+    return g
+
+
+def test_tts_prompt_layout():
+    g = _gen()
+    prompt = torch.tensor([128000, 11, 12, 128001]); text = torch.tensor([128000, 21, 22, 23, 128001])
+    data, mask = g._prepare_text_conditioned(prompt, text, 'transcription_seq')
+    assert data.shape == (4 + 5 + 2, 9) and data.dtype == torch.int64
+    assert data[:, :-1].eq(0).all() and mask[:, :-1].eq(0).all() and mask[:, -1].eq(1).all()
+    assert data[4, -1] == 128011 and data[-1, -1] == 128012 and data[5:10, -1].tolist() == text.tolist()
+    cd, cm = g._prepare_text_conditioned(prompt, text, 'transcription_seq', cfg=True)
+    assert cd.shape == data.shape and cd[:, -1].eq(TA.text_pad_token).all()
+
+
+def test_asr_prompt_layout():
+    g = _gen()
+    prompt = torch.tensor([128000, 5, 128001])
+    reason = torch.arange(3 * 8).view(3, 8); sem = torch.arange(4 * 8).view(4, 8)
+    data, mask = g.prepare_asr_task(prompt, reason, sem)
+    assert data.shape == (3 + 5 + 6, 9)
+    assert data[3, :8].eq(TA.reason_bos).all() and data[7, :8].eq(TA.reason_eos).all()
+    assert data[8, :8].eq(TA.semantic_bos + TA.audio_reason_card).all()
+    assert data[13, :8].eq(TA.semantic_eos + TA.audio_reason_card).all()
+    assert torch.equal(data[9:13, :8], sem + TA.audio_reason_card)
+    assert mask[:3, -1].eq(1).all() and mask[3:, :8].eq(1).all() and mask[3:, -1].eq(0).all()
+
+
+class _ScriptedModel:
+    """Stands in for Model_stage3 on CPU: replays a scripted id log through the generate_frames interface."""
+
+    def __init__(self, log):
+        self.log, self.cursor, self.calls = log, 0, []
+        self._p = torch.nn.Parameter(torch.zeros(1))
+
+    def parameters(self):
+        return iter([self._p])
+
+    def setup_caches(self, b): self.batch = b
+    def reset_caches(self): self.cursor = 0
+    def forward_prefix(self, *a, **k): pass
+    def begin_decode(self, *a, **k): pass
+
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
+        self.calls.append((n, batch, mode))
+        out = self.log[self.cursor:self.cursor + n]
+        self.cursor += n
+        return out
+
+
+@pytest.mark.parametrize("n_reason,n_sem", [(5, 9), (16, 16), (15, 17), (30, 41)])
+def test_generate_tts_chunked_loop_equals_reference_loop(n_reason, n_sem):
+    """EOS inside / at the edge of a 16-frame device chunk; frames computed past EOS are discarded."""
+    from uniaudio2_amd.evaluation.tts_task import Generator
+    g = torch.Generator().manual_seed(n_reason)
+    frames = [torch.randint(0, 4096, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_reason)]
+    frames.append(torch.full((1, 8), TA.reason_eos, dtype=torch.int32))
+    frames += [torch.randint(4100, 12292, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_sem)]
+    frames.append(torch.full((1, 8), TA.semantic_eos + TA.audio_reason_card, dtype=torch.int32))
+    frames += [torch.randint(0, 100, (1, 8), generator=g, dtype=torch.int32) for _ in range(40)]
+    log = torch.zeros(len(frames), 1, 9, dtype=torch.int32)
+    log[:, 0, 1:] = torch.cat(frames)
+    gen = Generator(_ScriptedModel(log), TA, text_tokenizer_path="ids")
+    r, s = gen.generate_tts(torch.tensor([128000, 1, 128001]), "tts", text_token=torch.tensor([128000, 2, 3, 128001]), topk=1)
+    rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+    assert torch.equal(r, rr) and torch.equal(s, rs) and r.dtype == torch.int32
+    assert all(c[2] == 0 for c in gen._model.calls)
+    with pytest.raises(NotImplementedError):
+        gen.generate_tts(torch.tensor([1]), "tts", text_token=torch.tensor([2]), topk=50)

@@ -165,3 +165,31 @@ def test_batch_rows_equal_single_runs_ragged(golden, sd, dtype):
     log = model.generate_frames(6, 2, 0).cpu()
     assert torch.equal(log[:, 0], singles[0].int())
     assert torch.equal(log[:, 1], singles[1].int())
+
+
+def test_generators_end_to_end_fp32(golden, sd):
+    """Generator.generate_asr-style text loop and the device-side reason_eos -> forbid_prefix switch."""
+    import types
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import check, lib
+    from uniaudio2_amd.evaluation.asr_task import Generator
+    d, _ = golden
+    ta = types.SimpleNamespace(text_pad_token=3, semantic_pad_token=0, semantic_eos=69, semantic_bos=68, reason_eos=39,
+                               reason_bos=38, reason_pad_token=0, parallel_number=9, audio_reason_card=RC)
+    from helpers import shrink_product_registry
+    from uniaudio2_amd.llm_models.model_new import Model_stage3, ModelArgs
+    shrink_product_registry()
+    m = Model_stage3(ModelArgs(**TOY_MODEL_ARGS))
+    m.load_state_dict(sd)
+    m = m.to("cuda").float()
+    gen = Generator(m, ta, text_tokenizer_path="ids")                # setup_caches(1) inside, fp32 parameters -> fp32 kernels
+    tokens, mask = _case(d, "asr1")
+    text = gen._generate_text(tokens[0], mask[0], topk=1, max_frames=10)
+    assert [int(t) for t in text.split()] == d["asr1_samples"][:, 0, 0].tolist()
+    # device-side switch (tts_task.py:263-266): a frame whose 8 audio ids equal reason_eos sets forbid_prefix
+    st = m._st
+    st["out_tokens"][:1] = torch.tensor([[5] + [ta.reason_eos] * 8], dtype=torch.int32, device="cuda")
+    st["forbid"].zero_()
+    check(lib.ua2_stage3_feedback(m._h, 1, 0, ta.reason_eos, RC, ops.stream()), "feedback")
+    assert int(st["forbid"][0]) == RC
+    assert st["tokens"][0].tolist() == [ta.reason_eos] * 8 + [5] and st["mask"][0].tolist() == [1] * 8 + [0]

@@ -115,20 +115,24 @@ __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int re
                                 const int32_t* __restrict__ out, int32_t* __restrict__ log, int32_t* counters) {
   const int frame = counters[0];
   const int w = ncb + 1;
+  const bool audio_fb = (mode == 0 || mode == 2);
   for (int m = threadIdx.x; m < R; m += blockDim.x) {
-    const int32_t* o = out + (size_t)m * w;
+    const int32_t* own = out + (size_t)m * w;
     if (frame < log_frames)
-      for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = o[j];
+      for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = own[j];
+    // mode 2 (classifier-free-guidance pair, tts_task.py:256-258,278-280): every row continues from
+    // the conditional row's sample
+    const int32_t* o = (mode == 2) ? out : own;
     bool all_reason_eos = true;
     for (int i = 0; i < ncb; ++i) {
       all_reason_eos = all_reason_eos && (o[1 + i] == reason_eos);
-      tokens[(size_t)m * w + i] = (mode == 0) ? o[1 + i] : 0;
-      mask[(size_t)m * w + i] = (mode == 0) ? 1 : 0;
+      tokens[(size_t)m * w + i] = audio_fb ? o[1 + i] : 0;
+      mask[(size_t)m * w + i] = audio_fb ? 1 : 0;
     }
     tokens[(size_t)m * w + ncb] = o[0];
-    mask[(size_t)m * w + ncb] = (mode == 0) ? 0 : 1;
+    mask[(size_t)m * w + ncb] = audio_fb ? 0 : 1;
     row_pos[m] += 1;
-    if (mode == 0 && all_reason_eos) forbid[m] = reason_card;  // tts_task.py:263-266
+    if (audio_fb && all_reason_eos) forbid[m] = reason_card;  // tts_task.py:263-266
   }
   __syncthreads();
   if (threadIdx.x == 0) counters[0] = frame + 1;
@@ -264,7 +268,7 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
 
 extern "C" int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
                                    void* stream) {
-  UA2_CHECK(h && R > 0 && R <= h->d.max_rows && (mode == 0 || mode == 1), "ua2_stage3_feedback: bad arguments");
+  UA2_CHECK(h && R > 0 && R <= h->d.max_rows && mode >= 0 && mode <= 2, "ua2_stage3_feedback: bad arguments");
   const ua2_stage3_desc& d = h->d;
   hipLaunchKernelGGL(feedback_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, R, d.n_cb, mode, reason_eos,
                      reason_card, d.log_frames, d.max_rows, d.tokens, d.mask, d.row_pos, d.forbid, d.out_tokens,
