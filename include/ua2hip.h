@@ -171,6 +171,39 @@ int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t 
 int ua2_rvq_decode(const int32_t* codes, const float* emb, int64_t N, int32_t L, int32_t C, int32_t D, float* out,
                    void* stream);
 
+/* ---- codec: 1-D convolutions -------------------------------------------------------------- */
+
+enum ua2_act { UA2_ACT_NONE = 0, UA2_ACT_PRELU = 1, UA2_ACT_ELU = 2, UA2_ACT_TANH = 3, UA2_ACT_ROUND9 = 4 };
+
+/* out[b][co][t] = post( bias[co] + sum_{ci,j} W[co][ci][j] * pre(x[b][ci][(t*stride + j*dilation - pad_left)/in_repeat]) )
+ *                 (+ residual[b][co][t]),   zero outside [0, Tin*in_repeat).
+ * Covers scalar24k.py Conv1d :36-74 (causal: pad_left = d(k-1); else symmetric) and conv.py StreamingConv1d
+ * :232-254 (pad_left = k_eff - stride, right pad implied by Tout); PReLU/ELU/tanh/round9 fused before or
+ * after; in_repeat = repeat-upsampling (scalar24k.py:136-138).
+ * Transposed conv (scalar24k.py:76-112, conv.py:306-329): out_phases = stride P, `w` holds the P phase
+ * filters stacked (rows phase*Cout + co, taps of a phase in descending order: ua2 host helper
+ * pack_convtr_weight), K = taps per phase, pad_left = K - 1, stride = dilation = 1; result written to
+ * y[co][t*P + phase - out_trim_left], Tout = final (trimmed) length.
+ * w: ua2_pack_linear(fp32) of the [rows, Cin_pad*K] matrix, Cin padded with zeros to a multiple of 16. */
+typedef struct ua2_conv1d_args {
+  int32_t B, Cin, Cout, Tin, Tout;
+  int32_t K, stride, dilation, pad_left;
+  int32_t in_repeat, out_phases, out_trim_left;
+  int32_t pre_act, post_act;       /* enum ua2_act */
+  const float* x;                  /* [B, Cin, Tin] fp32 */
+  const void* w;                   /* packed fp32 */
+  const float* bias;               /* [Cout] or NULL */
+  const float* pre_alpha;          /* PReLU slope for pre_act (1 value) or NULL */
+  const float* post_alpha;         /* PReLU slope(s) for post_act */
+  int32_t post_alpha_n;            /* 1 or Cout */
+  const float* residual;           /* [B, Cout, Tout] or NULL, added after post_act (scalar24k.py:151) */
+  float* y;                        /* [B, Cout, Tout] */
+} ua2_conv1d_args;
+
+int ua2_conv1d(const ua2_conv1d_args* a, void* stream);
+/* torch.nn.AvgPool1d(kernel_size=k) over the last axis of [rows, Tin] (scalar24k.py:118). */
+int ua2_avgpool1d(const float* x, float* y, int64_t rows, int32_t Tin, int32_t k, void* stream);
+
 /* ---- whole-frame executor -------------------------------------------------------------- */
 
 typedef struct ua2_gpt_desc {

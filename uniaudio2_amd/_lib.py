@@ -36,6 +36,16 @@ class AttnArgs(C.Structure):
                 ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp)]
 
 
+class Conv1dArgs(C.Structure):
+    _fields_ = [("B", i32), ("Cin", i32), ("Cout", i32), ("Tin", i32), ("Tout", i32), ("K", i32), ("stride", i32),
+                ("dilation", i32), ("pad_left", i32), ("in_repeat", i32), ("out_phases", i32), ("out_trim_left", i32),
+                ("pre_act", i32), ("post_act", i32), ("x", vp), ("w", vp), ("bias", vp), ("pre_alpha", vp),
+                ("post_alpha", vp), ("post_alpha_n", i32), ("residual", vp), ("y", vp)]
+
+
+ACT_NONE, ACT_PRELU, ACT_ELU, ACT_TANH, ACT_ROUND9 = 0, 1, 2, 3, 4
+
+
 class GptDesc(C.Structure):
     _fields_ = [("n_layer", i32), ("n_embd", i32), ("n_head", i32), ("n_kv", i32), ("head_size", i32),
                 ("inter", i32), ("eps", f32),
@@ -66,6 +76,8 @@ _EXPORTS = {
     "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]),
     "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
+    "ua2_conv1d": (C.c_int, [C.POINTER(Conv1dArgs), vp]),
+    "ua2_avgpool1d": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
     "ua2_rvq_decode": (C.c_int, [vp, vp, i64, i32, i32, i32, vp, vp]),
     "ua2_stage3_scratch_floats": (C.c_size_t, [C.POINTER(Stage3Desc)]),

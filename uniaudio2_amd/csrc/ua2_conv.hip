@@ -1,0 +1,166 @@
+// 1-D convolution / transposed convolution of the codec's waveform auto-encoders, exact fp32.
+//
+// Replaces (§2.3 K14-K16, K19, K21):
+//   ReasoningCodec_film/models/scalar24k.py  Conv1d :36-74 (causal = left zero-pad d(k-1), else
+//     symmetric), ConvTranspose1d :76-112 (causal: k = 2s, trim the last s), PReLU / tanh /
+//     round(9x)/9 / repeat-upsample epilogues (:120,133,136-138,148-149,206,243,266,278,289,385),
+//     AudioDiffusion1D.py:188,244-251 strided k = s down-samplers;
+//   MimiCodec/model/modules/conv.py StreamingConv1d :232-254 (left pad k_eff - s, extra right pad),
+//     StreamingConvTranspose1d :306-329 (trim k - s), seanet.py:92-94 ELU -> conv resblocks.
+//
+// One kernel does all of them as an implicit GEMM on the f32-input matrix pipe
+// (v_mfma_f32_16x16x4_f32: exact fp32 multiply-add, 1/16 of the bf16 rate but 2.4x a VALU conv and
+// bit-comparable with an fma chain).  With the codec's channel counts (32..1024) the arithmetic
+// intensity is ~100 flop/byte, so the bound is the f32 MFMA pipe, not HBM; activations make exactly
+// one trip through HBM per layer because bias, activation, residual add, input pre-activation,
+// repeat-upsampling and the transposed conv's phase interleave are fused into the load / store.
+//
+//   out[n][t] = act( bias[n] + sum_{ci,j} W[n][ci*K + j] * pre(x[ci][(t*stride + j*dil - pad_left) / in_repeat]) ) (+ residual)
+//   transposed conv with stride P: P phase-convolutions, packed rows n = phase*Cout + co, written to
+//   y[co][t*P + phase - out_trim_left]  (the taps of a phase are W[ci][co][phase + m*P], m descending).
+//
+// Tiling: workgroup = 4 waves = 64 output rows x 64 time steps; wave w owns rows 16w..16w+15 and four
+// 16-wide time tiles (4 accumulators).  Input channels are consumed 16 at a time: their window
+// (zero-padded, pre-activated) is staged once in LDS and feeds K chunks of 16 reduction indices; the
+// weight fragments come pre-tiled (ua2_pack_linear fp32 layout over [rows][Cin_pad*K]) as one 16-byte
+// load per lane per chunk, reused by the 16 MFMAs of the four time tiles.
+#include "ua2_common.h"
+
+namespace {
+
+constexpr int kBT = 64;       // time steps per workgroup
+constexpr int kBR = 64;       // output rows per workgroup
+constexpr int kCIG = 16;      // input channels per staging group
+constexpr int kMaxK = 32;
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+  switch (act) {
+    case UA2_ACT_PRELU: return v >= 0.f ? v : alpha * v;
+    case UA2_ACT_ELU: return v > 0.f ? v : expm1f(v);               // nn.ELU(alpha=1)
+    case UA2_ACT_TANH: return tanhf(v);
+    case UA2_ACT_ROUND9: return rintf(9.f * v) / 9.f;               // torch.round(9*x)/9, scalar24k.py:289
+    default: return v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.K, s = a.stride, d = a.dilation;
+  const int W = (kBT - 1) * s + (K - 1) * d + 1;       // staged window per input channel
+  const int Wp = W + 1;                                // +1: de-phase the rows across LDS banks
+  float* xs = sm;                                      // [kCIG][Wp]
+  int* koff = reinterpret_cast<int*>(xs + kCIG * Wp);  // [kCIG*K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 15, g = lane >> 4;
+  const int t0 = blockIdx.x * kBT;
+  const int r0 = blockIdx.y * kBR + wave * 16;
+  const int b = blockIdx.z;
+  const int rows = a.Cout * a.out_phases;
+  const int cin_pad = (a.Cin + kCIG - 1) / kCIG * kCIG;
+  const int nchunks = cin_pad * K / 16;                // packed chunks per row tile
+  const int tin_eff = a.Tin * a.in_repeat;
+
+  for (int kk = tid; kk < kCIG * K; kk += 256) koff[kk] = (kk / K) * Wp + (kk % K) * d;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_active = r0 < rows;
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.w) + (size_t)(r0 / 16) * nchunks * 64 + lane;
+  const float pre_alpha = (a.pre_act == UA2_ACT_PRELU && a.pre_alpha) ? a.pre_alpha[0] : 0.f;
+  const int in_start = t0 * s - a.pad_left;
+
+  for (int cg = 0; cg < cin_pad / kCIG; ++cg) {
+    __syncthreads();
+    for (int idx = tid; idx < kCIG * W; idx += 256) {
+      const int cl = idx / W, wi = idx - cl * W;
+      const int ci = cg * kCIG + cl, ti = in_start + wi;
+      float v = 0.f;
+      if (ci < a.Cin && ti >= 0 && ti < tin_eff) {
+        v = a.x[((size_t)b * a.Cin + ci) * a.Tin + ti / a.in_repeat];
+        v = apply_act(v, a.pre_act, pre_alpha);
+      }
+      xs[cl * Wp + wi] = v;
+    }
+    __syncthreads();
+    if (wave_active) {
+      for (int c = 0; c < K; ++c) {
+        const f32x4 wa = __builtin_bit_cast(f32x4, wp[(size_t)(cg * K + c) * 64]);
+        const int4 ko = *reinterpret_cast<const int4*>(&koff[c * 16 + g * 4]);
+        const int kov[4] = {ko.x, ko.y, ko.z, ko.w};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int tb = (nt * 16 + tl) * s;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xs[kov[e] + tb], acc[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_active) return;
+  // epilogue: D[row = (lane>>4)*4 + r][col = lane & 15]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = r0 + g * 4 + r;
+    if (n >= rows) continue;
+    const int phase = n / a.Cout, co = n - phase * a.Cout;
+    const float bias = a.bias ? a.bias[co] : 0.f;
+    const float alpha = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? co : 0] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int t = t0 + nt * 16 + tl;
+      const int to = t * a.out_phases + phase - a.out_trim_left;
+      if (to < 0 || to >= a.Tout) continue;
+      float v = acc[nt][r] + bias;
+      v = apply_act(v, a.post_act, alpha);
+      const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
+      if (a.residual) v += a.residual[o];
+      a.y[o] = v;
+    }
+  }
+}
+
+__global__ void avgpool1d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int Tin, int Tout, int k) {
+  const int64_t total = rows * Tout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / Tout;
+    const int t = (int)(idx - r * Tout);
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += x[r * Tin + (int64_t)t * k + j];
+    y[idx] = s / (float)k;   // torch.nn.AvgPool1d(kernel_size=k), scalar24k.py:118
+  }
+}
+
+}  // namespace
+
+extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
+  UA2_CHECK(a && a->x && a->w && a->y, "ua2_conv1d: NULL argument");
+  UA2_CHECK(a->B > 0 && a->Cin > 0 && a->Cout > 0 && a->Tin > 0 && a->Tout > 0, "ua2_conv1d: empty problem");
+  UA2_CHECK(a->K >= 1 && a->K <= kMaxK && a->stride >= 1 && a->dilation >= 1 && a->in_repeat >= 1 && a->out_phases >= 1,
+            "ua2_conv1d: bad geometry K=%d stride=%d dil=%d", a->K, a->stride, a->dilation);
+  UA2_CHECK(a->out_phases == 1 || (a->stride == 1 && a->dilation == 1), "ua2_conv1d: phase mode needs stride=dilation=1");
+  UA2_CHECK(a->post_act != UA2_ACT_PRELU || a->post_alpha, "ua2_conv1d: PReLU needs post_alpha");
+  const int W = (kBT - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+  const size_t smem = (size_t)kCIG * (W + 1) * sizeof(float) + (size_t)kCIG * a->K * sizeof(int);
+  UA2_CHECK(smem <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int tq = a->out_phases == 1 ? a->Tout : ua2_ceil_div(a->Tout + a->out_trim_left, a->out_phases);
+  const dim3 grid(ua2_ceil_div(tq, kBT), ua2_ceil_div((int64_t)a->Cout * a->out_phases, kBR), a->B);
+  hipLaunchKernelGGL(conv1d_kernel, grid, dim3(256), smem, (hipStream_t)stream, *a);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ua2_avgpool1d(const float* x, float* y, int64_t rows, int32_t Tin, int32_t k, void* stream) {
+  UA2_CHECK(x && y && rows > 0 && Tin > 0 && k > 0 && Tin >= k, "ua2_avgpool1d: bad arguments");
+  const int Tout = Tin / k;
+  const int64_t total = rows * Tout;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(avgpool1d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows, Tin, Tout, k);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}

@@ -141,3 +141,54 @@ def rvq_decode(codes, emb):
     out = torch.empty(N, D, dtype=torch.float32, device=emb.device)
     check(lib.ua2_rvq_decode(ptr(codes), ptr(emb), N, L, Cc, D, ptr(out), stream()), "ua2_rvq_decode")
     return out
+
+
+# ---- codec convolutions ------------------------------------------------------------------------
+
+def pack_conv_weight(w):
+    """nn.Conv1d weight [Cout, Cin, K] fp32 -> packed buffer for ua2_conv1d (Cin zero-padded to 16)."""
+    Cout, Cin, K = w.shape
+    cin_pad = (Cin + 15) // 16 * 16
+    wp = torch.zeros(Cout, cin_pad, K, dtype=torch.float32, device=w.device)
+    wp[:, :Cin] = w.float()
+    return pack_linear(wp.view(Cout, cin_pad * K), torch.float32), K
+
+
+def pack_convtr_weight(w, stride):
+    """nn.ConvTranspose1d weight [Cin, Cout, K] -> the `stride` phase filters of ua2_conv1d's phase mode:
+    row phase*Cout + co, taps in descending order (x index q - m  <->  original tap phase + m*stride)."""
+    Cin, Cout, K = w.shape
+    M = (K + stride - 1) // stride
+    cin_pad = (Cin + 15) // 16 * 16
+    wp = torch.zeros(stride, Cout, cin_pad, M, dtype=torch.float32, device=w.device)
+    for ph in range(stride):
+        for m in range(M):
+            j = ph + m * stride
+            if j < K:
+                wp[ph, :, :Cin, M - 1 - m] = w[:, :, j].float().t()
+    return pack_linear(wp.view(stride * Cout, cin_pad * M), torch.float32), M
+
+
+def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None, bias=None, pre_act=0, pre_alpha=None,
+           post_act=0, post_alpha=None, residual=None, in_repeat=1, out_phases=1, out_trim_left=0):
+    from ._lib import Conv1dArgs
+    B, Cin, Tin = x.shape
+    a = Conv1dArgs()
+    a.B, a.Cin, a.Cout, a.Tin, a.Tout = B, Cin, Cout, Tin, Tout
+    a.K, a.stride, a.dilation, a.pad_left = K, stride, dilation, pad_left
+    a.in_repeat, a.out_phases, a.out_trim_left = in_repeat, out_phases, out_trim_left
+    a.pre_act, a.post_act = pre_act, post_act
+    y = torch.empty(B, Cout, Tout, dtype=torch.float32, device=x.device)
+    a.x, a.w, a.bias = ptr(x), ptr(w_packed), ptr(bias)
+    a.pre_alpha, a.post_alpha = ptr(pre_alpha), ptr(post_alpha)
+    a.post_alpha_n = post_alpha.numel() if post_alpha is not None else 0
+    a.residual, a.y = ptr(residual), ptr(y)
+    check(lib.ua2_conv1d(C.byref(a), stream()), "ua2_conv1d")
+    return y
+
+
+def avgpool1d(x, k):
+    B, Cc, T = x.shape
+    y = torch.empty(B, Cc, T // k, dtype=torch.float32, device=x.device)
+    check(lib.ua2_avgpool1d(ptr(x), ptr(y), B * Cc, T, k, stream()), "ua2_avgpool1d")
+    return y
