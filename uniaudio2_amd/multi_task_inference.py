@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Command line of the hot path — mirror of the reference's multi_task_inference.py (flags :554-598,
+validation :601-649, run_understanding :258-382, run_generation_stage1 :408-525, stage 2 :529-549) on the
+MI355X kernels.  Same flags, same `{name}_reason.pt` / `{name}_semantic.pt` (8, T) tensor contract
+(generation writes int32, :523-524), same error messages for missing inputs.
+
+    python -m uniaudio2_amd.multi_task_inference --task TTS --stage 1 --text "..." --topk 1 \\
+        --llm_train_config cfg.yaml --resume llm.checkpoint --text_tokenizer_path tok_dir --prompt_json prompts.json
+
+Differences, all explicit:
+  * `--dtype {bf16,fp32}` (default bf16) picks the kernel precision; the reference runs fp32.
+  * Under `torchrun` (WORLD_SIZE > 1) the texts of --text_file are sharded over the ranks, one utterance
+    per GPU at a time, and gathered with one RCCL all-gather (uniaudio2_amd/parallel.py); rank 0 writes.
+  * Only greedy decoding (--topk 1) is on the device path this round; --decode_type ngram/beamsearch and
+    --topk > 1 raise NotImplementedError (the reference's beam search is dead code).
+  * Encoding raw audio (--audio / --audio_dir) and stage 2 (tokens -> wav) need the codec's frozen SSL
+    encoders / flow-matching DiT, which are out of scope: they raise with that message.
+    Pre-tokenised `--reason_pt/--semantic_pt/--token_dir` inputs work.
+"""
+import argparse
+import glob
+import json
+import os
+import random
+import sys
+
+import torch
+import yaml
+
+from .llm_models.model_new import Model_stage3, ModelArgs
+
+UNDERSTANDING_TASKS = ["ASR", "Yue_ASR", "lyric_recognition", "audio_caption", "music_caption", "audio_understanding", "speech_s2t"]
+GENERATION_TASKS = ["TTS", "Yue_TTS", "TTA", "TTM", "LTS", "InstructTTS", "speech_s2s"]
+TASK_PROMPT_SUFFIX = "\n\n"
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def _prompt_key_from_task(task):
+    t = task.strip().lower()
+    fixed = {"yue_tts": "Yue_TTS", "yue_asr": "Yue_ASR", "instruct_tts": "InstructTTS", "speech_s2s": "speech_s2s",
+             "speech_s2t": "speech_s2t"}
+    if t in fixed:
+        return fixed[t]
+    return t.upper() if t in ("asr", "tts", "tta", "ttm", "lts") else t
+
+
+def _get_prompt_tensor(args, text_tokenizer, task_name):
+    prompt_text = (getattr(args, "prompt_text", None) or "").strip()
+    path = getattr(args, "prompt_json", None)
+    if prompt_text:
+        chosen = prompt_text
+    elif path and os.path.isfile(path):
+        with open(path, "r", encoding="utf-8") as f:
+            prompts = json.load(f)
+        key = _prompt_key_from_task(task_name)
+        if key not in prompts:
+            key = task_name if task_name in prompts else task_name.upper()
+        if key not in prompts:
+            key = list(prompts.keys())[0]
+        if not prompts[key]:
+            raise ValueError(f"Task '{key}' has no prompts in {path}.")
+        chosen = random.choice(prompts[key])
+    else:
+        raise ValueError("Provide --prompt_text or --prompt_json.")
+    return torch.tensor(text_tokenizer.tokenize(chosen.strip() + TASK_PROMPT_SUFFIX), dtype=torch.long)
+
+
+def resume_for_inference(resume, exp_dir, model, device):
+    """llm_utils/train_utils.py:159-177: {'model': state_dict}, 'module.' prefixes stripped; latest epN.checkpoint of exp_dir otherwise."""
+    if resume is None and exp_dir:
+        cands = sorted(glob.glob(os.path.join(exp_dir, "ep*.checkpoint")), key=os.path.getmtime)
+        resume = cands[-1] if cands else None
+    if resume is None:
+        raise ValueError("Set --resume or --exp_dir with a checkpoint.")
+    ckpt = torch.load(resume, map_location="cpu")
+    sd = ckpt["model"] if "model" in ckpt else ckpt
+    sd = {(k.split("module.")[-1] if k.startswith("module.") else k): v for k, v in sd.items()}
+    model.load_state_dict(sd)
+    return model
+
+
+def _load_config_and_llm(args):
+    with open(args.llm_train_config, "r", encoding="utf-8") as f:
+        train_args = argparse.Namespace(**yaml.safe_load(f))
+    torch.manual_seed(args.seed)
+    if not torch.cuda.is_available():
+        raise RuntimeError("uniaudio2_amd needs a ROCm GPU (no CPU fallback)")
+    rank = int(os.environ.get("LOCAL_RANK", getattr(args, "rank", 0)))
+    device = torch.device(f"cuda:{rank % torch.cuda.device_count()}")
+    torch.cuda.set_device(device)
+    config = ModelArgs(decoder_name=train_args.local_model, llm_pretrained_model=train_args.llm_pretrained_model,
+                       llm_name=train_args.llm_name, audio_semantic_vocab_size=train_args.audio_semantic_card,
+                       audio_reason_vocab_size=train_args.audio_reason_card, audio_num_codebooks=train_args.parallel_number - 1,
+                       audio_embeddings_path=train_args.audio_embeddings_path,
+                       audio_understanding_expert_path=train_args.audio_understanding_expert_path)
+    model = Model_stage3(config)
+    resume_for_inference(args.resume, args.exp_dir, model, device)
+    model.to(device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    return train_args, model, device
+
+
+def _get_generator_class(task):
+    task = task.strip().lower()
+    from .evaluation import asr_task, audiogen_task, musicgen_task, songen_task, tts_task
+    table = {"asr": asr_task, "yue_asr": asr_task, "lyric_recognition": asr_task, "audio_caption": asr_task,
+             "music_caption": asr_task, "audio_understanding": asr_task, "speech_s2t": asr_task,
+             "tts": tts_task, "yue_tts": tts_task, "tta": audiogen_task, "ttm": musicgen_task, "lts": songen_task}
+    if task not in table:
+        raise ValueError(f"Unknown task: {task}. Understanding: {UNDERSTANDING_TASKS}. Generation: {GENERATION_TASKS}.")
+    return table[task].Generator
+
+
+def _generation_method_name(task):
+    t = task.strip().lower()
+    if t in ("tts", "yue_tts"):
+        return "generate_tts"
+    if t in ("tta", "ttm"):
+        return "generate_audio"
+    if t == "lts":
+        return "generate_LTS"
+    raise ValueError(f"Unknown generation task: {task}")
+
+
+def _check_decode(args):
+    if args.decode_type != "greedy":
+        raise NotImplementedError("--decode_type ngram/beamsearch are not on the device path (greedy only this round)")
+
+
+def run_understanding(args):
+    task = args.task.strip().lower()
+    _check_decode(args)
+    if (args.audio and os.path.isfile(args.audio)) or (args.audio_dir and os.path.isdir(args.audio_dir)):
+        raise NotImplementedError("encoding raw audio needs the codec's frozen SSL encoders (out of scope, SURVEY.md §8f); "
+                                  "pass --reason_pt + --semantic_pt or --token_dir")
+    if args.reason_pt and args.semantic_pt and os.path.isfile(args.reason_pt) and os.path.isfile(args.semantic_pt):
+        token_dir = os.path.dirname(args.reason_pt) or "."
+        names = [os.path.basename(args.reason_pt).replace("_reason.pt", "")]
+    elif args.token_dir and os.path.isdir(args.token_dir):
+        names = [os.path.basename(p).replace("_reason.pt", "") for p in sorted(glob.glob(os.path.join(args.token_dir, "*_reason.pt")))]
+        token_dir = args.token_dir
+    else:
+        raise ValueError("For understanding task provide --audio/--audio_dir, --reason_pt+--semantic_pt, or --token_dir with *_reason.pt.")
+    train_args, model, device = _load_config_and_llm(args)
+    generator = _get_generator_class(task)(model, train_args, audio_tokenizer_config=args.audio_tokenizer_config,
+                                           audio_model_path=args.audio_model_path, text_tokenizer_path=args.text_tokenizer_path,
+                                           is_cfg=args.use_cfg)
+    task_prompt = _get_prompt_tensor(args, generator._text_tokenizer, args.task)
+    results_path = args.results or os.path.join(args.output_dir, f"{task}_results.txt")
+    os.makedirs(os.path.dirname(results_path) or ".", exist_ok=True)
+    with open(results_path, "w") as f_out:
+        for name in names:
+            rp, sp = os.path.join(token_dir, f"{name}_reason.pt"), os.path.join(token_dir, f"{name}_semantic.pt")
+            if not os.path.isfile(rp) or not os.path.isfile(sp):
+                print(f"[Skip] {name}: missing reason/semantic .pt")
+                continue
+            reason = torch.load(rp, map_location="cpu").transpose(0, 1).long()          # (T, 8), :304-308
+            semantic = torch.load(sp, map_location="cpu").transpose(0, 1).long()
+            if task == "audio_understanding":
+                question = (args.question or "").strip() or "What is described in this audio?"
+                d = {"text_seq_question": torch.tensor(generator._text_tokenizer.tokenize(question), dtype=torch.long),
+                     "reason_seq": reason.transpose(0, 1), "semantic_seq": semantic.transpose(0, 1)}
+                text_out = generator.generate_answer(task_prompt, task_name=task, d=d, keys=list(d), types=["text", "audio", "audio"],
+                                                     temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
+            else:
+                text_out = generator.generate_asr(task_prompt, task_name=task, reason_token=reason, semantic_token=semantic,
+                                                  temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
+            f_out.write(f"{name}\t{text_out}\n")
+            print(f"[{task}] {name} -> {text_out[:80]}...")
+    print(f"Results written to {results_path}")
+
+
+def run_generation_stage1(args):
+    import torch.distributed as dist
+    from . import parallel
+    task = args.task.strip().lower()
+    _check_decode(args)
+    os.makedirs(args.output_dir, exist_ok=True)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    train_args, model, device = _load_config_and_llm(args)
+    generator = _get_generator_class(task)(model, train_args, audio_tokenizer_config=args.audio_tokenizer_config,
+                                           audio_model_path=args.audio_model_path, text_tokenizer_path=args.text_tokenizer_path,
+                                           is_cfg=args.use_cfg)
+    tok = generator._text_tokenizer
+    task_prompt = _get_prompt_tensor(args, tok, args.task)
+    if args.text and args.text.strip():
+        items = [("utt_0", args.text.strip())]
+    elif args.text_file and os.path.isfile(args.text_file):
+        with open(args.text_file, "r", encoding="utf-8") as f:
+            items = [(f"utt_{i}", line.strip()) for i, line in enumerate(f) if line.strip()]
+    else:
+        raise ValueError("Generation requires --text or --text_file.")
+    if not items:
+        raise ValueError("No text input.")
+    gen_fn = getattr(generator, _generation_method_name(task))
+    ids = [torch.tensor(tok.tokenize(t), dtype=torch.long) for _, t in items]
+
+    def one(i):
+        return gen_fn(task_prompt=task_prompt, task_name=task, text_token=ids[i], temperature=args.temperature,
+                      topk=args.topk, cfg_scale=args.cfg_scale)
+
+    results = parallel.run_sharded(list(range(len(items))), [len(x) for x in ids], one)
+    if int(os.environ.get("RANK", "0")) == 0:
+        for i, (name, _) in enumerate(items):
+            reason, semantic = results[i]
+            torch.save(reason.cpu(), os.path.join(args.output_dir, f"{name}_reason.pt"))
+            torch.save(semantic.cpu(), os.path.join(args.output_dir, f"{name}_semantic.pt"))
+            print(f"[Stage1] {name} -> {name}_reason.pt, {name}_semantic.pt")
+    return args.output_dir
+
+
+def run_generation_stage2(args):
+    raise NotImplementedError("stage 2 (tokens -> wav) needs the codec's flow-matching DiT, out of scope this round "
+                              "(SURVEY.md §8f #1); the in-scope part (RVQ lookup, ScalarModel.decode, windowing, cross-fade) "
+                              "is uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer.ReasoningTokenizer")
+
+
+def get_parser():
+    p = argparse.ArgumentParser(description="Multi-task inference: understanding (audio->text) or generation (text->wav)")
+    p.add_argument("--task", type=str, required=True)
+    p.add_argument("--stage", type=str, default="all", choices=["1", "2", "all"])
+    for name in ("audio", "audio_dir", "reason_pt", "semantic_pt", "question", "question_file", "text_file", "results", "token_dir",
+                 "wav_dir", "prompt_text", "prompt_json", "llm_train_config", "resume", "exp_dir", "text_tokenizer_path",
+                 "audio_tokenizer_config", "audio_model_path", "codec_config", "codec_ckpt", "music_ssl_folder"):
+        p.add_argument(f"--{name}", type=str, default=None)
+    p.add_argument("--text", type=str, default="")
+    p.add_argument("--output_dir", type=str, default="./multi_task_out")
+    p.add_argument("--use_cfg", type=str2bool, default=False)
+    p.add_argument("--temperature", type=float, default=0.9)
+    p.add_argument("--topk", type=int, default=50)
+    p.add_argument("--cfg_scale", type=float, default=1.0)
+    p.add_argument("--decode_type", type=str, default="greedy", choices=["greedy", "ngram", "beamsearch"])
+    p.add_argument("--codec_steps", type=int, default=50)
+    p.add_argument("--codec_duration", type=float, default=30.0)
+    p.add_argument("--seed", type=int, default=888)
+    p.add_argument("--rank", type=int, default=0)
+    p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="kernel precision (extension; the reference runs fp32)")
+    return p
+
+
+def main(argv=None):
+    args = get_parser().parse_args(argv)
+    task = args.task.strip().lower()
+    if task in [t.lower() for t in UNDERSTANDING_TASKS]:
+        has_input = ((args.audio and os.path.isfile(args.audio)) or (args.audio_dir and os.path.isdir(args.audio_dir)) or
+                     (args.reason_pt and args.semantic_pt and os.path.isfile(args.reason_pt) and os.path.isfile(args.semantic_pt)) or
+                     (args.token_dir and os.path.isdir(args.token_dir)))
+        if not has_input:
+            raise ValueError("For understanding task provide --audio, --audio_dir, or --reason_pt + --semantic_pt.")
+        if not args.llm_train_config or not args.text_tokenizer_path:
+            raise ValueError("Set --llm_train_config and --text_tokenizer_path.")
+        if not (args.prompt_text or (args.prompt_json and os.path.isfile(args.prompt_json))):
+            raise ValueError("Set --prompt_text or --prompt_json.")
+        run_understanding(args)
+        return
+    if task in [t.lower() for t in GENERATION_TASKS]:
+        if task in ("instructtts", "instruct_tts", "speech_s2s"):
+            raise NotImplementedError(f"task {args.task}: generator variant not mirrored yet")
+        if not ((args.text and args.text.strip()) or (args.text_file and os.path.isfile(args.text_file))):
+            raise ValueError("For generation task provide --text or --text_file.")
+        if not args.llm_train_config or not args.text_tokenizer_path:
+            raise ValueError("Set --llm_train_config and --text_tokenizer_path.")
+        if not (args.prompt_text or (args.prompt_json and os.path.isfile(args.prompt_json))):
+            raise ValueError("Set --prompt_text or --prompt_json.")
+        if args.stage in ("1", "all"):
+            run_generation_stage1(args)
+            if args.stage == "1":
+                print("[Done] Stage 1 only. Run with --stage 2 --token_dir ... to decode to wav.")
+                return
+        run_generation_stage2(args)
+        return
+    raise ValueError(f"Unsupported task: {task}. Understanding: {UNDERSTANDING_TASKS}. Generation: {GENERATION_TASKS}.")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Data-parallel sharding of utterances over the GPUs of one node.
+
+The reference decodes utterances one by one in a Python `for` (multi_task_inference.py:298,510,540);
+they are independent, so each rank keeps a full weight replica and its own KV pool, takes the
+utterances `i % world == rank` of a longest-first ordering, and the only exchange of the path is one
+all-gather of the output token tensors at the end of the shard (RCCL over xGMI: `torch.distributed`
+backend "nccl" on ROCm; "gloo" in the CPU tests).  Payload <= 2 x 8 x 500 x 4 B = 32 KB per
+utterance: latency-bound, one fixed-shape padded int32 tensor + a lengths tensor, no all-reduce.
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+MAX_FRAMES = 500          # evaluation/tts_task.py:222
+
+
+def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:
+    """Longest-first round-robin: utterance order[i] goes to rank i % world (balances decode time)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    return [order[i] for i in range(rank, len(order), world)]
+
+
+def pack_local(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_local_max: int, device, n_cb: int = 8):
+    """results: global index -> (reason (8,T_r), semantic (8,T_s)) int32.  Fixed-shape buffers for the all-gather."""
+    tok = torch.zeros(n_local_max, 2, n_cb, MAX_FRAMES, dtype=torch.int32, device=device)
+    meta = torch.full((n_local_max, 3), -1, dtype=torch.int32, device=device)      # (global index, T_r, T_s)
+    for slot, (gi, (r, s)) in enumerate(sorted(results.items())):
+        tok[slot, 0, :, :r.shape[1]] = r.to(device=device, dtype=torch.int32)
+        tok[slot, 1, :, :s.shape[1]] = s.to(device=device, dtype=torch.int32)
+        meta[slot] = torch.tensor([gi, r.shape[1], s.shape[1]], dtype=torch.int32)
+    return tok, meta
+
+
+def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_total: int, device=None):
+    """All ranks end up with every utterance's (reason, semantic) tensors, keyed by global index."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dict(results)
+    world = dist.get_world_size()
+    n_local_max = (n_total + world - 1) // world
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    tok, meta = pack_local(results, n_local_max, device)
+    toks = [torch.empty_like(tok) for _ in range(world)]
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(toks, tok)          # the path's only collective
+    dist.all_gather(metas, meta)
+    out = {}
+    for t, m in zip(toks, metas):
+        for slot in range(n_local_max):
+            gi, tr, ts = (int(v) for v in m[slot])
+            if gi >= 0:
+                out[gi] = (t[slot, 0, :, :tr].clone(), t[slot, 1, :, :ts].clone())
+    return out
+
+
+def run_sharded(items: Sequence, lengths: Sequence[int], generate_fn) -> Dict[int, Tuple[torch.Tensor, torch.Tensor]]:
+    """generate_fn(item) -> (reason, semantic); runs this rank's shard, then gathers everything everywhere."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    local = {i: generate_fn(items[i]) for i in shard_indices(lengths, world, rank)}
+    return gather_results(local, len(items))
