@@ -74,8 +74,11 @@ def utterance(model, tokens, mask, frames=FRAMES):
 
 
 def roofline_leg(model):
-    """HIP-event timing of the dominant kernel, linear_kernel<bf16, NORM, SWIGLU>, over exactly the
-    launches one frame makes: 33 at 3072 -> 2x8192 and 32 at 2048 -> 2x8192 (4 decoder layers x 8)."""
+    """HIP-event timing of the dominant kernel — gemv_kernel<bf16, NORM, SWIGLU, CPW=4, multi-round>
+    (rocprof symbol `gemv_kernel<1, 1, 2, 4, true>`): fused RMSNorm + fc_1/fc_2 + SwiGLU at 3072 -> 2x8192 —
+    over exactly its launches in one frame: the 33 layers of the three 3072-d GPTs, each with its own
+    100.7 MB of weights (so every launch streams cold data).  The 2048-d local decoder's SwiGLU is a
+    different instantiation and is reported by tools/ubench/gemv_shapes.py, not here."""
     from uniaudio2_amd import ops
     from uniaudio2_amd._lib import EPI_SWIGLU, PRO_NORM
     dev = model.projection.weight.device
@@ -99,15 +102,50 @@ def roofline_leg(model):
     add(model.audio_understanding_expert, 1)
     add(model.backbone, 1)
     add(model.audio_generation_expert, 1)
-    add(model.decoder, 8)
     ops.linear_chain_timed(args, 2)                       # warm
     ms = ops.linear_chain_timed(args, 10)
     per_launch_bytes = bytes_total / len(args)
     achieved = per_launch_bytes / (ms * 1e-3) / 1e9
-    return {"kernel": "linear_kernel<bf16,NORM,SWIGLU> (RMSNorm + fc_1/fc_2 + SwiGLU GEMV)", "bound": "hbm",
+    return {"kernel": "gemv_kernel<1, 1, 2, 4, true> (RMSNorm + fc_1/fc_2 + SwiGLU GEMV, 3072 -> 2x8192, bf16)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches_per_frame": len(args), "avg_launch_us": round(ms * 1e3, 2),
+            # HBM read bytes per launch from a separate PMC pass (profiles/r1_pmc_swiglu.txt: FETCH_SIZE x 1024 x 2,
+            # the gfx950 half-count correction of MI355X_MICROARCH.md §HBM); 1.002x the algorithmic bytes
+            "traffic": 100958000, "launches_per_frame": len(args), "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_bytes_per_launch": int(per_launch_bytes)}
+
+
+def codec_leg(dev):
+    """Codec side of the metric ("codec RTF"): the in-scope deterministic stage-2 sub-graph on one 20-s
+    window — ScalarModel.decode of a (1, 136, 500) latent -> 480 000 samples — and the RVQ search of a
+    10-s clip (125 frames x (1+1+6) levels of 8192 x 32).  Channel widths / strides live in the
+    reference's sqcodec_config.yaml, which is not in the repo: placeholder config with hop 960,
+    latent 136, init_channel 32."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
+    torch.manual_seed(1)
+    sq = ScalarModel(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
+                     downsample_kernel_sizes=[4, 8, 8, 10, 6], upsample_factors=[3, 5, 4, 4, 2],
+                     upsample_kernel_sizes=[6, 10, 8, 8, 4], latent_hidden_dim=136, default_kernel_size=7,
+                     delay_kernel_size=5, init_channel=32, res_kernel_size=7).to(dev).prepare()
+    lat = torch.tanh(torch.randn(1, 136, 500, device=dev))
+    wav = sq.decode(lat)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        wav = sq.decode(lat)
+    e1.record(); torch.cuda.synchronize()
+    dec_ms = e0.elapsed_time(e1) / 3
+    x = torch.randn(125, 32, device=dev)
+    emb = torch.randn(6, 8192, 32, device=dev)
+    embT = emb.transpose(1, 2).contiguous()
+    ops.rvq_encode(x, emb, embT); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        ops.rvq_encode(x, emb, embT)
+    e1.record(); torch.cuda.synchronize()
+    return {"scalar_decode_ms_per_20s_window": round(dec_ms, 3), "scalar_decode_rtf": round(dec_ms / 1e3 / (wav.shape[-1] / 24000.0), 6),
+            "rvq_encode_us_125x6x8192x32": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "config": "placeholder init_channel=32, hop 960"}
 
 
 def cpu_baseline_leg(model, tokens, mask, frames=6):
@@ -202,6 +240,8 @@ def main():
         res["roofline"] = roofline_leg(model)
         # whole-frame view of the same roofline: unique weight bytes a frame must stream (bf16)
         res["frame_hbm_frac_unique_weights"] = round(8.33e9 / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if rank == 0 and world == 1 and not a.no_roofline:
+        res["codec"] = codec_leg(dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb, cpu_ids = cpu_baseline_leg(model, tokens, mask)
         res["cpu_baseline"] = cb
