@@ -193,3 +193,34 @@ def test_generators_end_to_end_fp32(golden, sd):
     check(lib.ua2_stage3_feedback(m._h, 1, 0, ta.reason_eos, RC, ops.stream()), "feedback")
     assert int(st["forbid"][0]) == RC
     assert st["tokens"][0].tolist() == [ta.reason_eos] * 8 + [5] and st["mask"][0].tolist() == [1] * 8 + [0]
+
+
+def test_general_m_kernel_path_and_standalone_gpt(golden, sd):
+    """The general-M GEMM (prefill path) forced for every launch reproduces the reference ids too, and a
+    stand-alone GPT.forward (op-by-op: split-per-page attention + merge prologue) matches the oracle GPT."""
+    from oracle.lm_oracle import GPTOracle, shapes_from_configs
+    from toy_configs import TOY_LM
+    from uniaudio2_amd._lib import lib
+    d, _ = golden
+    tokens, mask = _case(d, "tts1")
+    old = lib.ua2_debug_force_general_linear(1)
+    try:
+        m = build_product_model(sd, torch.float32, batch=1)
+        r = product_decode_loop(m, tokens, mask, 8, "audio")
+        assert np.array_equal(r["samples"].numpy(), d["tts1_samples"][:8])
+    finally:
+        lib.ua2_debug_force_general_linear(old)
+    shp = shapes_from_configs(TOY_LM)["backbone"]
+    o = GPTOracle(sd, "backbone.", shp, "fp32", 2048)
+    o.set_kv_cache(2)
+    g = m.backbone
+    g.set_kv_cache(2, max_seq_length=2048, dtype=torch.float32)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 70, 256, generator=gen)                      # 70 positions: two KV pages
+    pos = torch.arange(70).unsqueeze(0).repeat(2, 1)
+    ref = o.forward(x, pos)
+    got = g.forward(x.cuda(), pos.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=0)
+    x1 = torch.randn(2, 1, 256, generator=gen)
+    p1 = torch.full((2, 1), 70)
+    np.testing.assert_allclose(g.forward(x1.cuda(), p1.cuda()).cpu().numpy(), o.forward(x1, p1).numpy(), atol=2e-4, rtol=0)

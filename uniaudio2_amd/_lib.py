@@ -7,6 +7,12 @@ this module raises (the product must fail loudly, never silently run something e
 import ctypes as C
 import os
 
+# torch owns the device memory and the streams this library is handed, so both must sit on ONE HIP
+# runtime: importing torch first makes the dynamic loader resolve libua2hip.so's libamdhip64 to the copy
+# torch already loaded (loading ours first gives the process two runtimes and launches fail with
+# "no ROCm-capable device").
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libua2hip.so")
 
