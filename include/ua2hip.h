@@ -158,6 +158,15 @@ int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const float* part_max
                      int32_t* out_tokens, int32_t out_ld, int32_t out_col,
                      const void* emb, int32_t emb_row_offset, int32_t C, float* next_h, void* stream);
 
+/* Top-k sampling tail (model_new.py:146-187 with topk > 1: temperature, forbid_prefix, keep logits >= the
+ * k-th largest, exponential-race multinomial draw) + next-step embedding gather.  Philox4x32-10 keyed by
+ * (seed, counter[0] = draw index on device, row, stream_id): reproducible under graph replay; it does not
+ * reproduce torch's generator stream (parity with the reference is distributional). */
+int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
+                    const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
+                    int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,
+                    int32_t C, float* next_h, void* stream);
+
 /* ---- codec: residual vector quantisation ------------------------------------------------ */
 
 /* Nearest-codeword search, level by level on the residual (core_vq.py:179-185, 365-376; the live codec's
@@ -249,7 +258,7 @@ typedef struct ua2_stage3_desc {
   int32_t* forbid;      /* [max_rows] forbid_prefix per row */
   int32_t* out_tokens;  /* [max_rows, n_cb+1] sampled [text, a0..a7] */
   int32_t* frame_log;   /* [log_frames, max_rows, n_cb+1] */
-  int32_t* counters;    /* [4]: frame index, ... */
+  int32_t* counters;    /* [4]: [0] frame index (log slot), [1] sampling draw index */
   int32_t log_frames;
   /* scratch (device, fp32 unless noted) — sizes in ua2_stage3_scratch_floats() */
   float* scratch;
@@ -263,6 +272,8 @@ int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out);
 void ua2_stage3_destroy(ua2_stage3* h);
 /* Number of KV pages the attention grid covers (>= max position / UA2_PAGE + 1). Default: max_pages. */
 int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages);
+/* Sampling mode of the heads: topk == 1 -> greedy (default); topk > 1 -> ua2_sample_topk with this temperature / seed. */
+int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed);
 
 /* model_new.py:594-613 (embed-merge -> U-expert -> backbone -> G-expert -> blend) for R rows
  * described by tokens/mask/row_pos/row_seq.  Used for prefill (forward_prefix, :456-497; the

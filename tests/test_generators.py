@@ -104,6 +104,8 @@ class _ScriptedModel:
     def forward_prefix(self, *a, **k): pass
     def begin_decode(self, *a, **k): pass
 
+    def set_sampling(self, topk, temperature, seed=None): self.sampling = (topk, temperature)
+
     def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
         self.calls.append((n, batch, mode))
         out = self.log[self.cursor:self.cursor + n]
@@ -128,5 +130,6 @@ def test_generate_tts_chunked_loop_equals_reference_loop(n_reason, n_sem):
     rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
     assert torch.equal(r, rr) and torch.equal(s, rs) and r.dtype == torch.int32
     assert all(c[2] == 0 for c in gen._model.calls)
-    with pytest.raises(NotImplementedError):
-        gen.generate_tts(torch.tensor([1]), "tts", text_token=torch.tensor([2]), topk=50)
+    gen._model.cursor = 0
+    gen.generate_tts(torch.tensor([1]), "tts", text_token=torch.tensor([2]), topk=50, temperature=0.9)
+    assert gen._model.sampling == (50, 0.9)                    # forwarded to the device sampler

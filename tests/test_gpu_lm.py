@@ -224,3 +224,54 @@ def test_general_m_kernel_path_and_standalone_gpt(golden, sd):
     x1 = torch.randn(2, 1, 256, generator=gen)
     p1 = torch.full((2, 1), 70)
     np.testing.assert_allclose(g.forward(x1.cuda(), p1.cuda()).cpu().numpy(), o.forward(x1, p1).numpy(), atol=2e-4, rtol=0)
+
+
+def test_topk_sampling_kernel_distribution_and_threshold():
+    """ua2_sample_topk: (i) topk=1 == arg-max; (ii) never returns a column outside the top-k set or below
+    forbid_prefix, ties at the threshold kept; (iii) frequencies over 4000 draws match softmax(top-k logits / T)
+    within 2e-2 (the reference's own multinomial self-test uses 1.5e-2 over 1000 draws on 10 classes,
+    llm_utils/sampling.py:156-174); (iv) same (seed, counter) -> same draw, different counter -> different stream."""
+    import ctypes as C
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import check, lib
+    g = torch.Generator().manual_seed(0)
+    V, M, K, T, FB = 1000, 4000, 8, 0.7, 3
+    base = torch.randn(V, generator=g) * 2
+    base[10] = base[11]                                            # an exact tie
+    logits = base.unsqueeze(0).repeat(M, 1).contiguous().cuda()
+    forbid = torch.full((M,), FB, dtype=torch.int32, device="cuda")
+    out = torch.zeros(M, 1, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def draw(topk, cnt):
+        counter.fill_(cnt)
+        check(lib.ua2_sample_topk(1, M, logits.data_ptr(), V, V, topk, C.c_float(T), forbid.data_ptr(), 888, counter.data_ptr(), 2,
+                                  out.data_ptr(), 1, 0, None, 0, 0, None, ops.stream()), "ua2_sample_topk")
+        return out[:, 0].cpu().long()
+
+    valid = base.clone(); valid[:FB] = float("-inf")
+    assert (draw(1, 0) == int(valid.argmax())).all()
+    s = draw(K, 0)
+    kth = valid.topk(K).values[-1]
+    keep = (valid >= kth).nonzero().view(-1)
+    assert set(s.tolist()) <= set(keep.tolist()) and s.min() >= FB
+    p = torch.softmax(valid[keep] / T, 0)
+    freq = torch.stack([(s == c).float().mean() for c in keep])
+    assert float((freq - p).abs().max()) < 2e-2, (freq, p)
+    assert torch.equal(draw(K, 0), s) and not torch.equal(draw(K, 1), s)
+
+
+def test_model_topk_sampling_runs_and_is_reproducible(golden, sd):
+    d, _ = golden
+    tokens, mask = _case(d, "tts1")
+    m = build_product_model(sd, torch.bfloat16, batch=1)
+    m.set_sampling(20, 0.9, seed=888)
+    a = product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"]
+    b = product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"]
+    m.set_sampling(1, 1.0)
+    c = product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"]
+    assert a.shape == (12, 1, 9) and not torch.equal(a, c)
+    assert (a[:, :, 0] < 512).all() and (a[:, :, 1:] < 110).all() and (a >= 0).all()
+    # same seed but the draw index keeps counting across utterances (like torch's global generator): streams differ
+    assert not torch.equal(a, b)
+    m.reset_caches()

@@ -89,6 +89,8 @@ _EXPORTS = {
     "ua2_stage3_scratch_floats": (C.c_size_t, [C.POINTER(Stage3Desc)]),
     "ua2_stage3_create": (C.c_int, [C.POINTER(Stage3Desc), C.POINTER(vp)]),
     "ua2_stage3_destroy": (None, [vp]),
+    "ua2_sample_topk": (C.c_int, [C.c_int, i32, vp, i32, i32, i32, f32, vp, C.c_uint64, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp]),
+    "ua2_stage3_set_sampling": (C.c_int, [vp, i32, f32, C.c_uint64]),
     "ua2_stage3_set_grid_pages": (C.c_int, [vp, i32]),
     "ua2_stage3_trunk": (C.c_int, [vp, i32, vp]),
     "ua2_stage3_heads": (C.c_int, [vp, i32, vp]),

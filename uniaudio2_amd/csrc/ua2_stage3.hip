@@ -28,12 +28,15 @@ struct ua2_stage3 {
   int32_t *pidx_t, *pidx_a;
   int32_t npart_t, npart_a;
   int32_t grid_pages;
+  int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
+  float temperature = 1.f;
+  uint64_t seed = 0;
   hipStream_t cap_stream = nullptr;
   // optional (UA2_FORK_LM_HEAD=1): lm_head + text arg-max on a side stream, concurrent with the 8-step
   // local decoder (they only share read-only inputs)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
-  std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+  std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
 };
 
 namespace {
@@ -108,6 +111,8 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
   }
   return 0;
 }
+
+__global__ void bump_kernel(int32_t* c) { c[0] += 1; }
 
 __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int reason_card, int log_frames,
                                 int max_rows, int32_t* __restrict__ tokens, uint8_t* __restrict__ mask,
@@ -212,6 +217,14 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   return 0;
 }
 
+extern "C" int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed) {
+  UA2_CHECK(h != nullptr, "ua2_stage3_set_sampling: NULL handle");
+  UA2_CHECK(temperature > 0.f, "temperature must be > 0");
+  UA2_CHECK(topk >= 1 && topk <= h->d.va, "topk must be in 1..%d", h->d.va);
+  h->topk = topk; h->temperature = temperature; h->seed = seed;
+  return 0;
+}
+
 extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
   UA2_CHECK(h != nullptr, "ua2_stage3_trunk: NULL handle");
   return trunk_impl(h, R, false, (hipStream_t)stream);
@@ -242,8 +255,13 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
     UA2_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
   }
   if (int rc = ua2_linear_launch(a, side)) return rc;
-  if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
-                                side)) return rc;
+  if (h->topk == 1) {
+    if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
+                                  side)) return rc;
+  } else {   // model_new.py:623 sample_topk(text_logits, topk, temperature)
+    if (int rc = ua2_sample_topk(d.dtype, R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature, nullptr,
+                                 h->seed, d.counters + 1, 0, d.out_tokens, w, 0, nullptr, 0, C, nullptr, side)) return rc;
+  }
   if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
   const float* curr = h->hfin;
   for (int i = 0; i < d.n_cb; ++i) {                               // model_new.py:630-641
@@ -258,9 +276,19 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
     a.w0 = h->audio_head[i]; a.y = h->audio_logits + (size_t)i * d.va; a.ldy = d.n_cb * d.va;
     a.part_max = h->pmax_a; a.part_idx = h->pidx_a; a.forbid = d.forbid;
     if (int rc = ua2_linear_launch(a, s)) return rc;
-    if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
-                                  i * d.va, C, h->curr_h, s)) return rc;
+    if (h->topk == 1) {
+      if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
+                                    i * d.va, C, h->curr_h, s)) return rc;
+    } else {   // model_new.py:639 audio_sample_topk(ci_logits, topk, temperature, forbid_prefix)
+      if (int rc = ua2_sample_topk(d.dtype, R, h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->topk,
+                                   h->temperature, d.forbid, h->seed, d.counters + 1, 1 + i, d.out_tokens, w, 1 + i,
+                                   d.audio_emb, i * d.va, C, h->curr_h, s)) return rc;
+    }
     curr = h->curr_h;
+  }
+  if (h->topk != 1) {   // one draw index per frame, advanced after every sampler of the frame has read it
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, d.counters + 1);
+    UA2_LAUNCH_CHECK();
   }
   if (!no_fork) UA2_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
   return 0;
@@ -288,7 +316,9 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
     return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, st);
   };
   if (!use_graph) return body(s);
-  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages);
+  int tbits;
+  memcpy(&tbits, &h->temperature, sizeof(int));
+  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages, (int)h->topk, tbits);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;

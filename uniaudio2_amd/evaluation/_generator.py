@@ -175,11 +175,8 @@ class GeneratorBase:
         return torch.cat(sequence, dim=0).to(torch.int64), torch.cat(mask, dim=0)
 
     # ---- loops ----------------------------------------------------------------------------------
-    def _check_sampling(self, topk):
-        if topk != 1:
-            raise NotImplementedError(
-                "uniaudio2_amd builds greedy decoding (--topk 1, the BASELINE.json metric) in this round; "
-                "top-k sampling (model_new.py:146-187 with topk > 1) is not on the device path yet")
+    def _set_sampling(self, topk, temperature):
+        self._model.set_sampling(topk, temperature)
 
     def _prefill(self, rows_tokens, rows_mask):
         """rows_*: list of (L, 9) prompts of equal length (1, or 2 with CFG; tts_task.py:228-245)."""
@@ -195,14 +192,14 @@ class GeneratorBase:
         return B, L
 
     @torch.inference_mode()
-    def _generate_audio_tokens(self, tokens, tokens_mask, cfg_tokens=None, cfg_mask=None, topk=1,
+    def _generate_audio_tokens(self, tokens, tokens_mask, cfg_tokens=None, cfg_mask=None, topk=1, temperature=1.0,
                                max_audio_frames=500) -> Tuple[torch.Tensor, torch.Tensor]:
         """The loop of generate_tts / generate_audio / generate_LTS (tts_task.py:246-285)."""
-        self._check_sampling(topk)
         rows_t, rows_m = [tokens], [tokens_mask]
         if self.is_cfg:
             rows_t.append(cfg_tokens); rows_m.append(cfg_mask)
         B, L = self._prefill(rows_t, rows_m)
+        self._set_sampling(topk, temperature)
         ph = PhaseSplitter(self.reason_eos, self.semantic_eos, self.audio_reason_card)
         frame = 0
         while not ph.done and frame < max_audio_frames:
@@ -218,10 +215,10 @@ class GeneratorBase:
         return de_reason.to(self.device), de_sem.to(self.device)
 
     @torch.inference_mode()
-    def _generate_text(self, tokens, tokens_mask, topk=1, max_frames=500) -> str:
+    def _generate_text(self, tokens, tokens_mask, topk=1, temperature=1.0, max_frames=500) -> str:
         """The loop of generate_asr / generate_audio_caption / generate_answer (asr_task.py:658-688)."""
-        self._check_sampling(topk)
         B, L = self._prefill([tokens], [tokens_mask])
+        self._set_sampling(topk, temperature)
         text, frame, done = [], 0, False
         while not done and frame < max_frames:
             n = min(self.chunk_frames, max_frames - frame)

@@ -11,7 +11,7 @@ class Generator(GeneratorBase):
                      temperature: float = 0.9, topk: int = 200, cfg_scale=1.0) -> str:
         """reason_token (T_r, 8), semantic_token (T_s, 8) long -> transcription text (asr_task.py:630-688)."""
         tokens, mask = self.prepare_asr_task(task_prompt, reason_token, semantic_token)
-        return self._generate_text(tokens, mask, topk=topk)
+        return self._generate_text(tokens, mask, topk=topk, temperature=temperature)
 
     # audio_music_caption_task.py uses the same prompt layout and loop under another name
     generate_audio_caption = generate_asr
@@ -21,4 +21,4 @@ class Generator(GeneratorBase):
                         topk: int = 200, cfg_scale=1.0) -> str:
         """audio_understanding.py:284-339."""
         tokens, mask = self.get_condition_seq(d, keys, types, task_prompt)
-        return self._generate_text(tokens, mask, topk=topk)
+        return self._generate_text(tokens, mask, topk=topk, temperature=temperature)

@@ -22,4 +22,4 @@ class Generator(GeneratorBase):
         cfg_t = cfg_m = None
         if self.is_cfg:
             cfg_t, cfg_m = self.prepare_tts_task_for_cfg(task_prompt, text_token)
-        return self._generate_audio_tokens(tokens, mask, cfg_t, cfg_m, topk=topk)
+        return self._generate_audio_tokens(tokens, mask, cfg_t, cfg_m, topk=topk, temperature=temperature)

@@ -117,6 +117,7 @@ class Model_stage3(nn.Module):
         st["keep"] = (d, gd, ah)
         self._h, self._st = h, st
         self._grid_pages = None
+        self._sampling = None
 
     def _destroy(self):
         if self._h is not None:
@@ -133,7 +134,7 @@ class Model_stage3(nn.Module):
         """model_new.py:647-651."""
         self._need()
         st = self._st
-        st["counters"].zero_()
+        st["counters"][0:1].zero_()      # frame-log slot; the sampler's draw index [1] keeps counting (like a generator)
         st["forbid"].zero_()
 
     def _need(self):
@@ -191,8 +192,7 @@ class Model_stage3(nn.Module):
         """model_new.py:568-645.  tokens (B, 1, 9), tokens_mask (B, 1, 9), input_pos (1,) shared
         or (B,) per sequence.  Returns (B, 9) int32 [text, a0..a7] on device."""
         self._need()
-        if topk != 1:
-            raise NotImplementedError("only greedy decoding (topk=1, BASELINE.json metric) is built in this round")
+        self.set_sampling(topk, temperature)
         if cfg_scale > 1.0 and tokens.size(0) > 1:
             raise NotImplementedError("classifier-free guidance logit mixing (model_new.py:618-622) is not built yet")
         if temperature <= 0:
@@ -209,6 +209,23 @@ class Model_stage3(nn.Module):
         self._set_grid_pages(int(input_pos_maxp1) if input_pos_maxp1 is not None else int(pos.max().item()) + 1)
         check(lib.ua2_stage3_frame(self._h, B, -1, 0, 0, 1, ops.stream()), "ua2_stage3_frame")
         return st["out_tokens"][:B].clone()
+
+    def set_sampling(self, topk: int = 1, temperature: float = 1.0, seed: Optional[int] = None):
+        """topk == 1: greedy (masked arg-max, lowest index on ties).  topk > 1: model_new.py:146-187 on device
+        (top-k threshold, exponential-race draw) with a counter-based generator keyed by `seed` (default: the
+        torch seed, multi_task_inference.py:159) — reproducible, but not torch's random stream."""
+        self._need()
+        if temperature <= 0:
+            raise ValueError("temperature must be > 0")
+        va = self._st["va"]
+        if topk <= 0 or topk > va:
+            raise ValueError(f"topk must be in 1..{va}")
+        if seed is None:
+            seed = torch.initial_seed()
+        key = (int(topk), float(temperature), int(seed) & (2 ** 64 - 1))
+        if getattr(self, "_sampling", None) != key:
+            check(lib.ua2_stage3_set_sampling(self._h, key[0], key[1], key[2]), "ua2_stage3_set_sampling")
+            self._sampling = key
 
     # ---- MI355X-native fast path ---------------------------------------------------------------
     @torch.inference_mode()

@@ -11,8 +11,9 @@ Differences, all explicit:
   * `--dtype {bf16,fp32}` (default bf16) picks the kernel precision; the reference runs fp32.
   * Under `torchrun` (WORLD_SIZE > 1) the texts of --text_file are sharded over the ranks, one utterance
     per GPU at a time, and gathered with one RCCL all-gather (uniaudio2_amd/parallel.py); rank 0 writes.
-  * Only greedy decoding (--topk 1) is on the device path this round; --decode_type ngram/beamsearch and
-    --topk > 1 raise NotImplementedError (the reference's beam search is dead code).
+  * --topk > 1 samples on the device with a counter-based generator seeded by --seed: reproducible, same
+    distribution as the reference's sample_topk, but not torch's random stream.  --decode_type
+    ngram/beamsearch raise NotImplementedError (the reference's beam search is dead code).
   * Encoding raw audio (--audio / --audio_dir) and stage 2 (tokens -> wav) need the codec's frozen SSL
     encoders / flow-matching DiT, which are out of scope: they raise with that message.
     Pre-tokenised `--reason_pt/--semantic_pt/--token_dir` inputs work.
