@@ -43,8 +43,22 @@ enum ua2_epilogue {
   UA2_EPI_STORE = 0,    /* y = xW^T; optional per-tile (max,idx) partials for greedy sampling (model_new.py:146-187) */
   UA2_EPI_RESIDUAL = 1, /* y = resid + xW^T                          (lit_model.py:345,349)                    */
   UA2_EPI_SWIGLU = 2,   /* y = silu(xW1^T) * (xW2^T)                 (lit_model.py:592-594)                    */
-  UA2_EPI_QKV_ROPE = 3  /* split q|k|v, half-split RoPE on q,k, append k,v to the paged cache
-                           (lit_model.py:431, 458-461, 778-807, 831-856)                                       */
+  UA2_EPI_QKV_ROPE = 3, /* split q|k|v, RoPE on q,k (rope_mode), append k,v to the paged cache
+                           (lit_model.py:431, 458-461, 778-807, 831-856; Moshi: transformer.py:386-396, rope.py:12-68) */
+  UA2_EPI_GELU = 4      /* y = gelu(xW^T), exact erf form (Moshi FFN, transformer.py:559 F.gelu)                  */
+};
+
+/* flavours of UA2_PRO_NORM */
+enum ua2_norm_kind {
+  UA2_NORM_RMS_LIT = 0,   /* (x * rsqrt(mean(x^2) + eps)) * w           lit_model.py:883-890                     */
+  UA2_NORM_RMS_MOSHI = 1, /* x * (alpha * rsqrt(eps + mean(x^2)))       llm_modules/transformer.py:34-46          */
+  UA2_NORM_LAYERNORM = 2  /* (x - mean) * rsqrt(var + eps) * w + b      nn.LayerNorm (create_norm_fn :111-112)    */
+};
+/* RoPE flavours of UA2_EPI_QKV_ROPE */
+enum ua2_rope_mode {
+  UA2_ROPE_HALF_SPLIT = 0,  /* rotate-half (lit_model.py:795-806); weight packed with rope_head_size          */
+  UA2_ROPE_INTERLEAVED = 1, /* adjacent pairs (2i, 2i+1) (rope.py:46-66); weight packed without permutation  */
+  UA2_ROPE_NONE = 2         /* positional_embedding='none'                                                   */
 };
 
 const char* ua2_last_error(void);
@@ -103,6 +117,10 @@ typedef struct ua2_linear_args {
   const float* rope_sin;
   float* q_out;           /* QKV_ROPE: [M, n_head*head_size] fp32, rotated */
   ua2_kv_geom kv;         /* ATTN (n_head, head_size, max_pages), QKV_ROPE (all) */
+  const float* norm_b;    /* NORM, LAYERNORM only: [K] bias */
+  int32_t norm_kind;      /* enum ua2_norm_kind */
+  const float* out_scale; /* RESIDUAL, optional [N]: y = resid + out_scale[n] * xW^T  (LayerScale, transformer.py:97) */
+  int32_t rope_mode;      /* enum ua2_rope_mode */
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
@@ -132,6 +150,8 @@ typedef struct ua2_attn_args {
   float* y;               /* if non-NULL: single-pass mode — one workgroup per (row, kv-head) walks all pages
                              (waves own pages, online softmax, merge in LDS) and writes the normalised
                              output [R, n_head*head_size]; attn_o / attn_ml / grid_pages are unused */
+  int32_t window;         /* single-pass mode: > 0 = attend only to the last `window` positions (Moshi `context`,
+                             transformer.py:405-406: delta < context); 0 = all positions <= row_pos */
 } ua2_attn_args;
 
 int ua2_attn(const ua2_attn_args* a, void* stream);

@@ -18,7 +18,9 @@ LIB_PATH = os.path.join(_HERE, "libua2hip.so")
 
 UA2_F32, UA2_BF16 = 0, 1
 PRO_CAST, PRO_NORM, PRO_ATTN = 0, 1, 2
-EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE = 0, 1, 2, 3
+EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE, EPI_GELU = 0, 1, 2, 3, 4
+NORM_RMS_LIT, NORM_RMS_MOSHI, NORM_LAYERNORM = 0, 1, 2
+ROPE_HALF_SPLIT, ROPE_INTERLEAVED, ROPE_NONE = 0, 1, 2
 UA2_PAGE = 64
 
 vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
@@ -34,12 +36,13 @@ class LinearArgs(C.Structure):
                 ("x", vp), ("ldx", i32), ("norm_w", vp), ("eps", f32), ("attn_o", vp), ("attn_ml", vp),
                 ("w0", vp), ("w1", vp), ("y", vp), ("ldy", i32), ("resid", vp), ("ldr", i32),
                 ("part_max", vp), ("part_idx", vp), ("forbid", vp), ("row_pos", vp), ("row_seq", vp),
-                ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom)]
+                ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom),
+                ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("attn_o", vp),
-                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp)]
+                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp), ("window", i32)]
 
 
 class Conv1dArgs(C.Structure):

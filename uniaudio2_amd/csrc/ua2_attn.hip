@@ -217,8 +217,9 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
   const float scale = 1.0f / sqrtf((float)HS);
   const int32_t* ptab = a.kv.page_table + (size_t)seq * a.kv.max_pages;
   // contiguous range of this wave, a multiple of RPW rows
-  const int chunk = ((n + kFusedWaves * RPW - 1) / (kFusedWaves * RPW)) * RPW;
-  const int j0 = wave * chunk, j1 = min(n, j0 + chunk);
+  const int lo = (a.window > 0) ? max(0, n - a.window) : 0;   // Moshi `context`: delta < context (transformer.py:405-406)
+  const int chunk = ((n - lo + kFusedWaves * RPW - 1) / (kFusedWaves * RPW)) * RPW;
+  const int j0 = lo + wave * chunk, j1 = min(n, j0 + chunk);
 
   float q[kMaxG][EPL];
 #pragma unroll

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   char* a_lds = smem;                                        // [rows][a_stride] of T
   float* red = reinterpret_cast<float*>(smem + red_off);     // [nw][NT][256]
   float* ssq = red + kMaxWaves * NT * 256;                   // [nw][16]
-  float* rstd_s = ssq + kMaxWaves * 16;                      // [16]
+  float* ssum = ssq + kMaxWaves * 16;                        // [nw][16]
+  float* rstd_s = ssum + kMaxWaves * 16;                     // [16]
+  float* mean_s = rstd_s + 16;                               // [16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nw = nthreads >> 6;
@@ -60,7 +62,8 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   // while the weights are still streaming), never behind it.
   constexpr int XPT = 2;  // float4 per thread kept in registers on the single-row fast path
   const bool one = (rows == 1) && (a.K <= XPT * 4 * nthreads);
-  float4 xv[XPT], nv[XPT];
+  float4 xv[XPT], nv[XPT], nb[XPT];
+  const bool ln = (PRO == UA2_PRO_NORM) && a.norm_kind == UA2_NORM_LAYERNORM;
   if (one) {
     const float* xr = a.x + (size_t)m0 * a.ldx;
 #pragma unroll
@@ -68,9 +71,13 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
       const int k = (tid + it * nthreads) * 4;
       xv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       nv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+      nb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k < a.K) {
         xv[it] = *reinterpret_cast<const float4*>(xr + k);
-        if constexpr (PRO == UA2_PRO_NORM) nv[it] = *reinterpret_cast<const float4*>(a.norm_w + k);
+        if constexpr (PRO == UA2_PRO_NORM) {
+          nv[it] = *reinterpret_cast<const float4*>(a.norm_w + k);
+          if (ln) nb[it] = *reinterpret_cast<const float4*>(a.norm_b + k);
+        }
       }
     }
   }
@@ -97,19 +104,21 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
     }
   };
   if (one) {
-    float rs = 1.f;
+    NormStat st{0.f, 1.f};
     if constexpr (PRO == UA2_PRO_NORM) {
-      float ss = 0.f;
+      float ss = 0.f, sm = 0.f;
 #pragma unroll
-      for (int it = 0; it < XPT; ++it)
+      for (int it = 0; it < XPT; ++it) {
         ss += xv[it].x * xv[it].x + xv[it].y * xv[it].y + xv[it].z * xv[it].z + xv[it].w * xv[it].w;
+        sm += (xv[it].x + xv[it].y) + (xv[it].z + xv[it].w);
+      }
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-      if (lane == 0) ssq[wave * 16] = ss;
+      for (int o = 32; o >= 1; o >>= 1) { ss += __shfl_xor(ss, o); sm += __shfl_xor(sm, o); }
+      if (lane == 0) { ssq[wave * 16] = ss; ssum[wave * 16] = sm; }
       __syncthreads();
-      float t = 0.f;
-      for (int w = 0; w < nw; ++w) t += ssq[w * 16];      // every thread, same order: no second barrier
-      rs = 1.0f / sqrtf(t / (float)a.K + a.eps);          // torch.rsqrt(mean(x*x) + eps), lit_model.py:886-887
+      float t = 0.f, u = 0.f;
+      for (int w = 0; w < nw; ++w) { t += ssq[w * 16]; u += ssum[w * 16]; }   // every thread, same order: no second barrier
+      st = norm_stat(a, u, t);
     }
 #pragma unroll
     for (int it = 0; it < XPT; ++it) {
@@ -117,49 +126,55 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
       if (k < nchunks * KC) {                             // also zero-fills the K padding of the last chunk
         float4 t = xv[it];
         if constexpr (PRO == UA2_PRO_NORM) {
-          t.x = __fmul_rn(__fmul_rn(t.x, rs), nv[it].x);  // (x*rstd)*w, lit_model.py:887-889
-          t.y = __fmul_rn(__fmul_rn(t.y, rs), nv[it].y);
-          t.z = __fmul_rn(__fmul_rn(t.z, rs), nv[it].z);
-          t.w = __fmul_rn(__fmul_rn(t.w, rs), nv[it].w);
+          if (k < a.K) {
+            t.x = norm_apply(a, t.x, nv[it].x, nb[it].x, st);
+            t.y = norm_apply(a, t.y, nv[it].y, nb[it].y, st);
+            t.z = norm_apply(a, t.z, nv[it].z, nb[it].z, st);
+            t.w = norm_apply(a, t.w, nv[it].w, nb[it].w, st);
+          }
         }
         put(0, k, t);
       }
     }
   } else {
     if constexpr (PRO == UA2_PRO_NORM) {
-      for (int r0 = 0; r0 < rows; ++r0) {  // pass 1: sum of squares per row
+      for (int r0 = 0; r0 < rows; ++r0) {  // pass 1: sum and sum of squares per row
         const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
-        float ss = 0.f;
+        float ss = 0.f, sm = 0.f;
         for (int k = tid * 4; k < a.K; k += nthreads * 4) {
           const float4 t = *reinterpret_cast<const float4*>(xr + k);
           ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+          sm += (t.x + t.y) + (t.z + t.w);
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-        if (lane == 0) ssq[wave * 16 + r0] = ss;
+        for (int o = 32; o >= 1; o >>= 1) { ss += __shfl_xor(ss, o); sm += __shfl_xor(sm, o); }
+        if (lane == 0) { ssq[wave * 16 + r0] = ss; ssum[wave * 16 + r0] = sm; }
       }
       __syncthreads();
       if (tid < rows) {
-        float t = 0.f;
-        for (int w = 0; w < nw; ++w) t += ssq[w * 16 + tid];
-        rstd_s[tid] = 1.0f / sqrtf(t / (float)a.K + a.eps);
+        float t = 0.f, u = 0.f;
+        for (int w = 0; w < nw; ++w) { t += ssq[w * 16 + tid]; u += ssum[w * 16 + tid]; }
+        const NormStat st = norm_stat(a, u, t);
+        rstd_s[tid] = st.rstd; mean_s[tid] = st.mean;
       }
       __syncthreads();
     }
     for (int r0 = 0; r0 < rows; ++r0) {
       const float* xr = a.x + (size_t)(m0 + r0) * a.ldx;
-      float rs = 1.f;
-      if constexpr (PRO == UA2_PRO_NORM) rs = rstd_s[r0];
+      NormStat st{0.f, 1.f};
+      if constexpr (PRO == UA2_PRO_NORM) { st.rstd = rstd_s[r0]; st.mean = mean_s[r0]; }
       for (int k = tid * 4; k < nchunks * KC; k += nthreads * 4) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < a.K) {
           t = *reinterpret_cast<const float4*>(xr + k);
           if constexpr (PRO == UA2_PRO_NORM) {
             const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
-            t.x = __fmul_rn(__fmul_rn(t.x, rs), w.x);
-            t.y = __fmul_rn(__fmul_rn(t.y, rs), w.y);
-            t.z = __fmul_rn(__fmul_rn(t.z, rs), w.z);
-            t.w = __fmul_rn(__fmul_rn(t.w, rs), w.w);
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ln) b = *reinterpret_cast<const float4*>(a.norm_b + k);
+            t.x = norm_apply(a, t.x, w.x, b.x, st);
+            t.y = norm_apply(a, t.y, w.y, b.y, st);
+            t.z = norm_apply(a, t.z, w.z, b.z, st);
+            t.w = norm_apply(a, t.w, w.w, b.w, st);
           }
         }
         put(r0, k, t);
@@ -288,7 +303,7 @@ int launch_cpw(const ua2_linear_args& a, hipStream_t s) {
   // +16 B per row: breaks the power-of-two row stride (LDS bank conflicts across rows)
   const int a_stride = nchunks * KC + 16 / BYTES;
   const int red_off = (int)(((size_t)rows * a_stride * BYTES + 255) & ~(size_t)255);
-  const size_t smem = (size_t)red_off + (size_t)(kMaxWaves * NT * 256 + kMaxWaves * 16 + 16) * sizeof(float);
+  const size_t smem = (size_t)red_off + (size_t)(kMaxWaves * NT * 256 + 2 * kMaxWaves * 16 + 32) * sizeof(float);
   const dim3 grid(gx, mtiles);
   const bool mr = geo.waves <= 8 && geo.waves * geo.cpw < nchunks;
   if (mr) {
@@ -313,6 +328,7 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
     if (a.epilogue == UA2_EPI_QKV_ROPE) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_QKV_ROPE>(a, s);
     if (a.epilogue == UA2_EPI_SWIGLU) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_SWIGLU>(a, s);
     if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_STORE>(a, s);
+    if (a.epilogue == UA2_EPI_GELU) return launch_cpw<DT, UA2_PRO_NORM, UA2_EPI_GELU>(a, s);
   } else if (a.prologue == UA2_PRO_CAST) {
     if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_RESIDUAL>(a, s);
     if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_STORE>(a, s);

@@ -54,7 +54,7 @@ __global__ void pack_kernel(const void* __restrict__ src, void* __restrict__ out
 }
 
 template <int DT, int PRO>
-__device__ __forceinline__ void make_a(const ua2_linear_args& a, int m, bool valid, int k0, float rstd,
+__device__ __forceinline__ void make_a(const ua2_linear_args& a, int m, bool valid, int k0, const NormStat& st,
                                        AFrag<DT>& out) {
   constexpr int EPL = Elem<DT>::EPL;
   float f[EPL];
@@ -64,11 +64,14 @@ __device__ __forceinline__ void make_a(const ua2_linear_args& a, int m, bool val
     if constexpr (PRO == UA2_PRO_CAST) {
       load_row<EPL>(a.x + (size_t)m * a.ldx + k0, f);
     } else if constexpr (PRO == UA2_PRO_NORM) {
-      float w[EPL];
+      float w[EPL], b[EPL];
       load_row<EPL>(a.x + (size_t)m * a.ldx + k0, f);
       load_row<EPL>(a.norm_w + k0, w);
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) f[e] = __fmul_rn(__fmul_rn(f[e], rstd), w[e]);  // (x*rstd)*w, lit_model.py:887-889
+      for (int e = 0; e < EPL; ++e) b[e] = 0.f;
+      if (a.norm_kind == UA2_NORM_LAYERNORM) load_row<EPL>(a.norm_b + k0, b);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] = norm_apply(a, f[e], w[e], b[e], st);
     } else {  // UA2_PRO_ATTN: merge the per-page partials of head h
       const int hs = a.kv.head_size, mp = a.kv.max_pages;
       const int h = k0 / hs, d = k0 - h * hs;
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   __shared__ float red[kWaves][NT][256];
-  __shared__ float ssq[kWaves][16];
-  __shared__ float rstd_s[16];
+  __shared__ float ssq[kWaves][16], ssum[kWaves][16];
+  __shared__ float rstd_s[16], mean_s[16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -132,9 +135,9 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
       for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(c0 + u) * 64);
   }
 
-  float rstd = 1.f;
+  NormStat nst{0.f, 1.f};
   if constexpr (PRO == UA2_PRO_NORM) {
-    float ss = 0.f;
+    float ss = 0.f, sm = 0.f;
     if (mvalid) {
       for (int c = c0; c < c1; ++c) {
         const int k0 = c * KC + g * EPL;
@@ -142,22 +145,23 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
           float f[EPL];
           load_row<EPL>(a.x + (size_t)m * a.ldx + k0, f);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) ss += f[e] * f[e];
+          for (int e = 0; e < EPL; ++e) { ss += f[e] * f[e]; sm += f[e]; }
         }
       }
     }
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    if (g == 0) ssq[wave][i] = ss;
+    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+    sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+    if (g == 0) { ssq[wave][i] = ss; ssum[wave][i] = sm; }
     __syncthreads();
     if (tid < 16) {
-      float t = 0.f;
+      float t = 0.f, u = 0.f;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) t += ssq[w][tid];
-      rstd_s[tid] = 1.0f / sqrtf(t / (float)a.K + a.eps);  // torch.rsqrt(mean(x*x) + eps), lit_model.py:886-887
+      for (int w = 0; w < kWaves; ++w) { t += ssq[w][tid]; u += ssum[w][tid]; }
+      const NormStat st = norm_stat(a, u, t);
+      rstd_s[tid] = st.rstd; mean_s[tid] = st.mean;
     }
     __syncthreads();
-    rstd = rstd_s[i];
+    nst.rstd = rstd_s[i]; nst.mean = mean_s[i];
   }
 
   f32x4 acc[NT];
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
     for (; c + UB <= c1; c += UB) {
       AFrag<DT> af[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) make_a<DT, PRO>(a, m, mvalid, (c + u) * KC + g * EPL, rstd, af[u]);
+      for (int u = 0; u < UB; ++u) make_a<DT, PRO>(a, m, mvalid, (c + u) * KC + g * EPL, nst, af[u]);
       u32x4 wn[NT][UB];
       const bool more = c + 2 * UB <= c1;
       if (more) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
   }
   for (; c < c1; ++c) {  // remainder chunks (K not a multiple of 8*UB*KC)
     AFrag<DT> af;
-    make_a<DT, PRO>(a, m, mvalid, c * KC + g * EPL, rstd, af);
+    make_a<DT, PRO>(a, m, mvalid, c * KC + g * EPL, nst, af);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const u32x4 w = __builtin_nontemporal_load(wp[t] + (size_t)c * 64);
@@ -239,6 +243,9 @@ int launch_epi(const ua2_linear_args& a, hipStream_t s) {
     case UA2_EPI_QKV_ROPE:
       hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_QKV_ROPE>), dim3(ntiles, mtiles), block, 0, s, a);
       break;
+    case UA2_EPI_GELU:
+      hipLaunchKernelGGL((linear_kernel<DT, PRO, UA2_EPI_GELU>), dim3(ntiles, mtiles), block, 0, s, a);
+      break;
     default:
       ua2_set_error("ua2_linear: bad epilogue %d", a.epilogue);
       return -1;
@@ -274,14 +281,18 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
                   a.K == a.kv.n_head * a.kv.head_size,
               "ua2_linear: bad ATTN prologue arguments");
   }
-  if (a.prologue == UA2_PRO_NORM) UA2_CHECK(a.norm_w != nullptr, "ua2_linear: norm_w is NULL");
+  if (a.prologue == UA2_PRO_NORM)
+    UA2_CHECK(a.norm_w != nullptr && (a.norm_kind != UA2_NORM_LAYERNORM || a.norm_b != nullptr) && a.norm_kind >= 0 && a.norm_kind <= 2,
+              "ua2_linear: norm_w / norm_b / norm_kind invalid");
+  if (a.epilogue == UA2_EPI_GELU) UA2_CHECK(a.y != nullptr, "ua2_linear: GELU needs y");
   if (a.epilogue == UA2_EPI_SWIGLU) UA2_CHECK(a.w1 != nullptr && a.y != nullptr, "ua2_linear: SWIGLU needs w1, y");
   if (a.epilogue == UA2_EPI_RESIDUAL) UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
   if (a.epilogue == UA2_EPI_STORE) UA2_CHECK(a.y != nullptr || a.part_max != nullptr, "ua2_linear: STORE needs y or part_max");
   if (a.epilogue == UA2_EPI_QKV_ROPE) {
-    UA2_CHECK(a.kv.head_size % 32 == 0 && a.N == (a.kv.n_head + 2 * a.kv.n_kv) * a.kv.head_size,
-              "ua2_linear: QKV_ROPE needs head_size %% 32 == 0 and N == (n_head+2*n_kv)*head_size");
-    UA2_CHECK(a.row_pos && a.rope_cos && a.rope_sin && a.q_out && a.kv.k_pool && a.kv.v_pool &&
+    UA2_CHECK(a.kv.head_size % (a.rope_mode == UA2_ROPE_HALF_SPLIT ? 32 : 16) == 0 &&
+                  a.N == (a.kv.n_head + 2 * a.kv.n_kv) * a.kv.head_size && a.rope_mode >= 0 && a.rope_mode <= 2,
+              "ua2_linear: QKV_ROPE needs head_size %% 32 == 0 (16 when not half-split) and N == (n_head+2*n_kv)*head_size");
+    UA2_CHECK(a.row_pos && (a.rope_mode == UA2_ROPE_NONE || (a.rope_cos && a.rope_sin)) && a.q_out && a.kv.k_pool && a.kv.v_pool &&
                   a.kv.page_table,
               "ua2_linear: QKV_ROPE pointer arguments missing");
   }

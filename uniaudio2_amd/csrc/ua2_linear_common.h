@@ -43,6 +43,26 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&f)
 }
 
 
+// ---- normalisation flavours of UA2_PRO_NORM -----------------------------------------------------
+struct NormStat { float mean, rstd; };
+__device__ __forceinline__ NormStat norm_stat(const ua2_linear_args& a, float sum, float sumsq) {
+  NormStat s;
+  const float ms = sumsq / (float)a.K;
+  if (a.norm_kind == UA2_NORM_LAYERNORM) {
+    s.mean = sum / (float)a.K;
+    s.rstd = 1.0f / sqrtf(fmaxf(ms - s.mean * s.mean, 0.f) + a.eps);
+  } else {
+    s.mean = 0.f;
+    s.rstd = 1.0f / sqrtf(ms + a.eps);     // torch.rsqrt(mean(x*x) + eps)  (lit :886-887; Moshi: eps + mean, same sum)
+  }
+  return s;
+}
+__device__ __forceinline__ float norm_apply(const ua2_linear_args& a, float x, float w, float b, const NormStat& s) {
+  if (a.norm_kind == UA2_NORM_RMS_LIT) return __fmul_rn(__fmul_rn(x, s.rstd), w);      // (x*rstd)*w
+  if (a.norm_kind == UA2_NORM_RMS_MOSHI) return __fmul_rn(x, __fmul_rn(w, s.rstd));    // x*(alpha*rstd)
+  return __fadd_rn(__fmul_rn(__fmul_rn(x - s.mean, s.rstd), w), b);                    // layer norm
+}
+
 // ---- epilogues (thread = one (row, col) of the 16 x 16 output tile; v[t] = reduced sums) ----
 // Split in two so the decode kernel can issue the epilogue's global loads (residual, position,
 // RoPE table entries, page id, forbid_prefix) at kernel entry, in the shadow of the weight stream,
@@ -80,8 +100,8 @@ __device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, in
     const int hs = a.kv.head_size, half = hs / 2;
     const int n0 = tile0 * 16;
     const int h = n0 / hs, r = (n0 - h * hs) / 16;
-    const int d = r * 8 + (col & 7);
-    if (h < a.kv.n_head + a.kv.n_kv) {
+    const int d = (a.rope_mode == UA2_ROPE_INTERLEAVED) ? (r * 16 + col) / 2 : r * 8 + (col & 7);   // table column
+    if (h < a.kv.n_head + a.kv.n_kv && a.rope_mode != UA2_ROPE_NONE) {
       p.cs = a.rope_cos[(size_t)p.pos * half + d];
       p.sn = a.rope_sin[(size_t)p.pos * half + d];
     }
@@ -121,7 +141,7 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
     }
   } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
     const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = v[0] + p.resid;
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = (a.out_scale ? a.out_scale[n] * v[0] : v[0]) + p.resid;
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {
@@ -129,24 +149,36 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
       const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
       a.y[(size_t)mr * a.ldy + n] = sg * v[1];
     }
+  } else if constexpr (EPI == UA2_EPI_GELU) {
+    const int n = tile[0] * 16 + col;
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = 0.5f * v[0] * (1.0f + erff(v[0] * 0.70710678118654752440f));
   } else {  // UA2_EPI_QKV_ROPE — weight rows were permuted at pack time (ua2_pack_linear rope_head_size):
     // tile r of a head holds dims [8r, 8r+8) in columns 0-7 and their rotation partners
     // [hs/2+8r, hs/2+8r+8) in columns 8-15, so the half-split rotation closes inside one tile.
-    const float other = __shfl_xor(v[0], 8);   // partner column, same row (all 256 threads participate)
+    const float other8 = __shfl_xor(v[0], 8);  // half-split partner column, same row (all 256 threads participate)
+    const float other1 = __shfl_xor(v[0], 1);  // interleaved partner
     if (!rvalid) return;
     const int hs = a.kv.head_size, half = hs / 2;
     const int n0 = tile[0] * 16;
     const int h = n0 / hs, r = (n0 - h * hs) / 16;
-    const bool lo_half = col < 8;
-    const int d = r * 8 + (col & 7);           // dim in [0, half)
-    const float x1 = lo_half ? v[0] : other;   // x[d]
-    const float x2 = lo_half ? other : v[0];   // x[d + half]
+    const bool rot = h < a.kv.n_head + a.kv.n_kv && a.rope_mode != UA2_ROPE_NONE;
     float out = v[0];
-    if (h < a.kv.n_head + a.kv.n_kv) {
+    int dd;
+    if (a.rope_mode == UA2_ROPE_HALF_SPLIT) {
+      const bool lo_half = col < 8;
+      const int d = r * 8 + (col & 7);           // dim in [0, half)
+      const float x1 = lo_half ? v[0] : other8;  // x[d]
+      const float x2 = lo_half ? other8 : v[0];  // x[d + half]
       // roped = x*cos + rotate_half(x)*sin  (lit_model.py:795-806), products rounded separately
-      out = lo_half ? __fadd_rn(__fmul_rn(x1, p.cs), __fmul_rn(-x2, p.sn)) : __fadd_rn(__fmul_rn(x2, p.cs), __fmul_rn(x1, p.sn));
+      if (rot) out = lo_half ? __fadd_rn(__fmul_rn(x1, p.cs), __fmul_rn(-x2, p.sn)) : __fadd_rn(__fmul_rn(x2, p.cs), __fmul_rn(x1, p.sn));
+      dd = lo_half ? d : d + half;
+    } else {
+      dd = r * 16 + col;                         // natural order
+      const bool even = (col & 1) == 0;
+      const float xr = even ? v[0] : other1, xi = even ? other1 : v[0];
+      // qor = qr*rotr - qi*roti ; qoi = qr*roti + qi*rotr   (rope.py:58-62)
+      if (rot) out = even ? __fsub_rn(__fmul_rn(xr, p.cs), __fmul_rn(xi, p.sn)) : __fadd_rn(__fmul_rn(xr, p.sn), __fmul_rn(xi, p.cs));
     }
-    const int dd = lo_half ? d : d + half;
     if (h < a.kv.n_head) {
       a.q_out[(size_t)mr * a.kv.n_head * hs + (size_t)h * hs + dd] = out;
     } else {

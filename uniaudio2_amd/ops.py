@@ -58,7 +58,8 @@ def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
 
 def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None, ldx=None, norm_w=None, eps=1e-5,
            attn_o=None, attn_ml=None, w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
-           forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True):
+           forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True,
+           norm_b=None, norm_kind=0, out_scale=None, rope_mode=0):
     a = LinearArgs()
     a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
     a.M, a.N, a.K = M, N, K
@@ -71,6 +72,7 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
     a.part_max, a.part_idx, a.forbid = ptr(part_max), ptr(part_idx), ptr(forbid)
     a.row_pos, a.row_seq = ptr(row_pos), ptr(row_seq)
     a.rope_cos, a.rope_sin, a.q_out = ptr(rope_cos), ptr(rope_sin), ptr(q_out)
+    a.norm_b, a.norm_kind, a.out_scale, a.rope_mode = ptr(norm_b), norm_kind, ptr(out_scale), rope_mode
     if kv is not None:
         a.kv = kv
     if not launch:
@@ -86,9 +88,10 @@ def linear_chain_timed(args_list, iters):
     return ms.value / (len(args_list) * iters)
 
 
-def attn(*, dtype, R, q, row_pos, row_seq, kv, attn_o=None, attn_ml=None, grid_pages=0, y=None):
+def attn(*, dtype, R, q, row_pos, row_seq, kv, attn_o=None, attn_ml=None, grid_pages=0, y=None, window=0):
     a = AttnArgs()
     a.y = ptr(y)
+    a.window = window
     a.dtype, a.R = dtype_code(dtype), R
     a.q, a.row_pos, a.row_seq = ptr(q), ptr(row_pos), ptr(row_seq)
     a.attn_o, a.attn_ml, a.grid_pages, a.kv = ptr(attn_o), ptr(attn_ml), grid_pages, kv
