@@ -25,7 +25,7 @@ constexpr int kMaxWaves = 16;
 // weights prefetched (double buffer); !MR = single burst: up to 16 waves, everything up front.
 template <int DT, int PRO, int EPI, int CPW, bool MR>
 __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
-                                                              const int red_off) {
+                                                              const int red_off, const int rt) {
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nw = nthreads >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.y * 16;
-  const int rows = min(16, a.M - m0);
+  const int m0 = blockIdx.y * rt;            // rt rows per workgroup: a function of K and dtype only
+  const int rows = min(rt, a.M - m0);
 
   const int nchunks = (a.K + KC - 1) / KC;
   int tile[NT];
@@ -82,14 +82,14 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
     }
   }
   EpiPre pre;
-  if (tid < 256) epilogue_prefetch_a<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre);
+  if (tid < 256) epilogue_prefetch_a<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre, m0);
 
   u32x4 wf[NT][CPW];
 #pragma unroll
   for (int u = 0; u < CPW; ++u)
 #pragma unroll
     for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(c0 + u, last) * 64);
-  if (tid < 256) epilogue_prefetch_b<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre);
+  if (tid < 256) epilogue_prefetch_b<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre, m0);
 
   // ---- stage the activation rows into LDS (operand dtype) ----
   auto put = [&](int r0, int k, float4 t) {
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
       float ss = 0.f, sm = 0.f;
 #pragma unroll
       for (int it = 0; it < XPT; ++it) {
-        ss += xv[it].x * xv[it].x + xv[it].y * xv[it].y + xv[it].z * xv[it].z + xv[it].w * xv[it].w;
-        sm += (xv[it].x + xv[it].y) + (xv[it].z + xv[it].w);
+        ss = sumsq4(ss, xv[it]);
+        sm = sum4(sm, xv[it]);
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { ss += __shfl_xor(ss, o); sm += __shfl_xor(sm, o); }
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
         float ss = 0.f, sm = 0.f;
         for (int k = tid * 4; k < a.K; k += nthreads * 4) {
           const float4 t = *reinterpret_cast<const float4*>(xr + k);
-          ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
-          sm += (t.x + t.y) + (t.z + t.w);
+          ss = sumsq4(ss, t);
+          sm = sum4(sm, t);
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { ss += __shfl_xor(ss, o); sm += __shfl_xor(sm, o); }
@@ -238,7 +238,16 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
     for (int w = 0; w < nw; ++w) s += red[(w * NT + t) * 256 + src];
     v[t] = s;
   }
-  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre);
+  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0, rows);
+}
+
+constexpr size_t kLdsABudget = 112 * 1024;   // activation tile budget (of 160 KiB; the rest holds the reduction buffers)
+
+int rows_per_tile(int dtype, int K) {
+  const int kc = dtype == UA2_BF16 ? 32 : 16, bytes = dtype == UA2_BF16 ? 2 : 4;
+  const size_t row_bytes = ((size_t)ua2_ceil_div(K, kc) * kc + 16 / bytes) * bytes;
+  const int r = (int)(kLdsABudget / row_bytes);
+  return r > 16 ? 16 : r;
 }
 
 struct Geometry {
@@ -280,14 +289,14 @@ Geometry pick_geometry(int nchunks, int blocks, int nt) {
 }
 
 template <int DT, int PRO, int EPI, int CPW, bool MR>
-void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, int red_off, size_t smem, hipStream_t s) {
+void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, int red_off, size_t smem, hipStream_t s, int rt) {
   auto kern = gemv_kernel<DT, PRO, EPI, CPW, MR>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(waves * 64), smem, s, a, a_stride, red_off);
+  hipLaunchKernelGGL(kern, grid, dim3(waves * 64), smem, s, a, a_stride, red_off, rt);
 }
 
 template <int DT, int PRO, int EPI>
@@ -297,25 +306,29 @@ int launch_cpw(const ua2_linear_args& a, hipStream_t s) {
   const int nchunks = ua2_ceil_div(a.K, KC);
   const int ntiles = ua2_ceil_div(a.N, 16);
   const int gx = ntiles;
-  const int mtiles = ua2_ceil_div(a.M, 16);
-  const Geometry geo = pick_geometry(nchunks, gx * mtiles, NT);
-  const int rows = a.M < 16 ? a.M : 16;
+  // rows per workgroup and launch geometry depend on (N, K, dtype) only — never on M — so that a row
+  // sees the same instruction stream and summation order whatever the batch around it
+  const Geometry geo = pick_geometry(nchunks, gx, NT);
   // +16 B per row: breaks the power-of-two row stride (LDS bank conflicts across rows)
   const int a_stride = nchunks * KC + 16 / BYTES;
-  const int red_off = (int)(((size_t)rows * a_stride * BYTES + 255) & ~(size_t)255);
+  const int rt = rows_per_tile(a.dtype, a.K);
+  const int mtiles = ua2_ceil_div(a.M, rt);
+  // LDS is sized for the rows actually present (occupancy: two single-row workgroups share a CU);
+  // the size changes nothing a row computes
+  const int red_off = (int)(((size_t)(a.M < rt ? a.M : rt) * a_stride * BYTES + 255) & ~(size_t)255);
   const size_t smem = (size_t)red_off + (size_t)(kMaxWaves * NT * 256 + 2 * kMaxWaves * 16 + 32) * sizeof(float);
   const dim3 grid(gx, mtiles);
   const bool mr = geo.waves <= 8 && geo.waves * geo.cpw < nchunks;
   if (mr) {
-    if (geo.cpw == 4) launch_one<DT, PRO, EPI, 4, true>(a, grid, geo.waves, a_stride, red_off, smem, s);
-    else launch_one<DT, PRO, EPI, 8, true>(a, grid, geo.waves, a_stride, red_off, smem, s);
+    if (geo.cpw == 4) launch_one<DT, PRO, EPI, 4, true>(a, grid, geo.waves, a_stride, red_off, smem, s, rt);
+    else launch_one<DT, PRO, EPI, 8, true>(a, grid, geo.waves, a_stride, red_off, smem, s, rt);
   } else {
     switch (geo.cpw) {
-      case 4: launch_one<DT, PRO, EPI, 4, false>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
-      case 8: launch_one<DT, PRO, EPI, 8, false>(a, grid, geo.waves, a_stride, red_off, smem, s); break;
+      case 4: launch_one<DT, PRO, EPI, 4, false>(a, grid, geo.waves, a_stride, red_off, smem, s, rt); break;
+      case 8: launch_one<DT, PRO, EPI, 8, false>(a, grid, geo.waves, a_stride, red_off, smem, s, rt); break;
       default:
-        if constexpr (NT == 1) launch_one<DT, PRO, EPI, 16, false>(a, grid, geo.waves, a_stride, red_off, smem, s);
-        else launch_one<DT, PRO, EPI, 8, false>(a, grid, geo.waves, a_stride, red_off, smem, s);
+        if constexpr (NT == 1) launch_one<DT, PRO, EPI, 16, false>(a, grid, geo.waves, a_stride, red_off, smem, s, rt);
+        else launch_one<DT, PRO, EPI, 8, false>(a, grid, geo.waves, a_stride, red_off, smem, s, rt);
     }
   }
   UA2_LAUNCH_CHECK();
@@ -342,10 +355,7 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
 // kernel), negative on error.
 int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s) {
   if (a.prologue == UA2_PRO_ATTN) return 1;
-  const int kc = a.dtype == UA2_BF16 ? 32 : 16, bytes = a.dtype == UA2_BF16 ? 2 : 4;
-  const int rows = a.M < 16 ? a.M : 16;
-  const size_t a_bytes = (size_t)rows * ((size_t)ua2_ceil_div(a.K, kc) * kc + 16 / bytes) * bytes;
-  if (a_bytes > 96 * 1024) return 1;
+  if (rows_per_tile(a.dtype, a.K) < 1) return 1;   // a single row does not fit the LDS budget
   if (a.dtype == UA2_BF16) return launch_dt<UA2_BF16>(a, s);
   if (a.dtype == UA2_F32) return launch_dt<UA2_F32>(a, s);
   return 1;

@@ -221,8 +221,9 @@ __global__ __launch_bounds__(kThreads) void linear_kernel(const ua2_linear_args 
     v[t] = s;
   }
   EpiPre pre;
-  epilogue_prefetch<DT, EPI>(a, tile[0], row, col, pre);
-  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre);
+  const int m0e = blockIdx.y * 16;
+  epilogue_prefetch<DT, EPI>(a, tile[0], row, col, pre, m0e);
+  linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0e, min(16, a.M - m0e));
 }
 
 template <int DT, int PRO>

@@ -43,6 +43,19 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&f)
 }
 
 
+// Fixed-order accumulators: every code path that reduces an activation row uses these, so a row's
+// statistics are bit-identical whatever the batch around it (hipcc contracts a*b+c differently from one
+// loop shape to another when left to itself).
+__device__ __forceinline__ float sumsq4(float acc, const float4& t) {
+  acc = __fmaf_rn(t.x, t.x, acc); acc = __fmaf_rn(t.y, t.y, acc);
+  acc = __fmaf_rn(t.z, t.z, acc); acc = __fmaf_rn(t.w, t.w, acc);
+  return acc;
+}
+__device__ __forceinline__ float sum4(float acc, const float4& t) {
+  acc = __fadd_rn(acc, t.x); acc = __fadd_rn(acc, t.y); acc = __fadd_rn(acc, t.z); acc = __fadd_rn(acc, t.w);
+  return acc;
+}
+
 // ---- normalisation flavours of UA2_PRO_NORM -----------------------------------------------------
 struct NormStat { float mean, rstd; };
 __device__ __forceinline__ NormStat norm_stat(const ua2_linear_args& a, float sum, float sumsq) {
@@ -50,7 +63,7 @@ __device__ __forceinline__ NormStat norm_stat(const ua2_linear_args& a, float su
   const float ms = sumsq / (float)a.K;
   if (a.norm_kind == UA2_NORM_LAYERNORM) {
     s.mean = sum / (float)a.K;
-    s.rstd = 1.0f / sqrtf(fmaxf(ms - s.mean * s.mean, 0.f) + a.eps);
+    s.rstd = 1.0f / sqrtf(fmaxf(__fsub_rn(ms, __fmul_rn(s.mean, s.mean)), 0.f) + a.eps);
   } else {
     s.mean = 0.f;
     s.rstd = 1.0f / sqrtf(ms + a.eps);     // torch.rsqrt(mean(x*x) + eps)  (lit :886-887; Moshi: eps + mean, same sum)
@@ -60,7 +73,7 @@ __device__ __forceinline__ NormStat norm_stat(const ua2_linear_args& a, float su
 __device__ __forceinline__ float norm_apply(const ua2_linear_args& a, float x, float w, float b, const NormStat& s) {
   if (a.norm_kind == UA2_NORM_RMS_LIT) return __fmul_rn(__fmul_rn(x, s.rstd), w);      // (x*rstd)*w
   if (a.norm_kind == UA2_NORM_RMS_MOSHI) return __fmul_rn(x, __fmul_rn(w, s.rstd));    // x*(alpha*rstd)
-  return __fadd_rn(__fmul_rn(__fmul_rn(x - s.mean, s.rstd), w), b);                    // layer norm
+  return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, s.mean), s.rstd), w), b);                    // layer norm
 }
 
 // ---- epilogues (thread = one (row, col) of the 16 x 16 output tile; v[t] = reduced sums) ----
@@ -77,8 +90,8 @@ __device__ __forceinline__ int kv_table_row(const ua2_linear_args& a, int mr) { 
 
 // stage A: loads that depend on nothing (issue BEFORE the weight burst)
 template <int DT, int EPI>
-__device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
-  const int mr = blockIdx.y * 16 + row;
+__device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
+  const int mr = m0 + row;
   if (mr >= a.M) return;
   const int n = tile0 * 16 + col;
   if constexpr (EPI == UA2_EPI_STORE) {
@@ -93,9 +106,9 @@ __device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, in
 // stage B: loads that depend on stage A (issue AFTER the weight burst: they queue behind it and are
 // only needed by the epilogue)
 template <int DT, int EPI>
-__device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
+__device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
   if constexpr (EPI == UA2_EPI_QKV_ROPE) {
-    const int mr = blockIdx.y * 16 + row;
+    const int mr = m0 + row;
     if (mr >= a.M) return;
     const int hs = a.kv.head_size, half = hs / 2;
     const int n0 = tile0 * 16;
@@ -109,17 +122,17 @@ __device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, in
   }
 }
 template <int DT, int EPI>
-__device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p) {
-  epilogue_prefetch_a<DT, EPI>(a, tile0, row, col, p);
-  epilogue_prefetch_b<DT, EPI>(a, tile0, row, col, p);
+__device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
+  epilogue_prefetch_a<DT, EPI>(a, tile0, row, col, p, m0);
+  epilogue_prefetch_b<DT, EPI>(a, tile0, row, col, p, m0);
 }
 
 // NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.
 template <int DT, int EPI, int NT>
 __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&v)[NT], const int (&tile)[NT],
-                                                int row, int col, const EpiPre& p) {
-  const int mr = blockIdx.y * 16 + row;
-  const bool rvalid = mr < a.M;
+                                                int row, int col, const EpiPre& p, int m0, int rows) {
+  const int mr = m0 + row;
+  const bool rvalid = row < rows;
 
   if constexpr (EPI == UA2_EPI_STORE) {
     const int n = tile[0] * 16 + col;
