@@ -121,11 +121,23 @@ typedef struct ua2_linear_args {
   int32_t norm_kind;      /* enum ua2_norm_kind */
   const float* out_scale; /* RESIDUAL, optional [N]: y = resid + out_scale[n] * xW^T  (LayerScale, transformer.py:97) */
   int32_t rope_mode;      /* enum ua2_rope_mode */
+  void* workspace;        /* optional device scratch of >= ua2_linear_workspace_bytes(dtype, M, K): enables the
+                             large-M kernel (normalised operand rows packed once, 128-row tiles).  Results are
+                             bit-identical with or without it; without it M > 16 streams the weights once per
+                             16-row tile. */
+  size_t workspace_bytes;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
-/* Test hook: route every ua2_linear through the general-M kernel (1) or let the launcher pick the
- * decode-regime kernel when it applies (0, default).  Returns the previous setting. */
+/* Bytes of ua2_linear_args.workspace that a launch with these M, K needs (the operand rows in MFMA
+ * fragment order, rows padded to 16, K padded to the chunk size). */
+size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K);
+/* Test hook, returns the previous setting.  0 (default): the launcher picks — row-tiled decode-regime
+ * kernel for one row tile, large-M kernels when a workspace is supplied and M spans more than one.
+ * 1: the general-M fallback kernel only (different summation order: NOT bit-comparable with the others).
+ * 2: never the large-M kernels.  3: a large-M kernel whenever a workspace is supplied, even for M = 1
+ * (4: always its skinny form, 5: always its 128-row tiled form).
+ * Modes 0, 2, 3, 4 and 5 produce bit-identical results (tests/test_gpu_invariance.py). */
 int ua2_debug_force_general_linear(int on);
 
 /* Measurement helper (bench.py roofline leg): launches args[0..n) back to back `iters` times on

@@ -1,0 +1,102 @@
+"""BASELINE.json configs 3-5 at the real model size, as parity-by-property tests: the CPU oracle
+cannot run these sizes in seconds, but every sequence of a batch must reproduce its own B = 1 run bit for bit
+(the B = 1 path is pinned against the oracle in test_gpu_fullsize.py / test_gpu_lm.py), whatever the batch
+composition, prompt raggedness, continuous-batching retirements or which linear kernel the row count selects
+(decode kernel <= 16 rows, skinny kernel, 128-row GEMM).
+  config 3: 32 x (15 text + 53 reason + 128 semantic)-frame prompts, 32 text tokens each (ASR-shaped);
+  config 4: 64 ragged prompts (24..48), 60..300 frames each, sequences retire as they finish (batched TTS);
+  config 5: 500 frames from a 35-token prompt (TTM-shaped: the KV cache crosses 8 page boundaries)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    import bench
+    return bench.build_model(torch.device("cuda"), seed=0), bench
+
+
+def _text_rows(ids):
+    t = torch.zeros(len(ids), 9, dtype=torch.long)
+    m = torch.zeros(len(ids), 9, dtype=torch.bool)
+    t[:, -1] = ids
+    m[:, -1] = True
+    return t, m
+
+
+def _audio_rows(n, va, g):
+    t = torch.zeros(n, 9, dtype=torch.long)
+    m = torch.zeros(n, 9, dtype=torch.bool)
+    t[:, :8] = torch.randint(0, va, (n, 8), generator=g)
+    m[:, :8] = True
+    return t, m
+
+
+def _single(m, prompt, frames, mode):
+    t, mk = prompt
+    dev = torch.device("cuda")
+    L = t.shape[0]
+    m.reset_caches()
+    tt, mm = t.unsqueeze(0).to(dev), mk.unsqueeze(0).to(dev)
+    m.forward_prefix(tt[:, :-1], tokens_mask=mm, input_pos=torch.arange(L - 1, device=dev).unsqueeze(0))
+    m.begin_decode(tt[:, -1:], mm[:, -1:], torch.tensor([L - 1], device=dev))
+    return m.generate_frames(frames, 1, mode, max_pos=L + frames).clone()[:, 0]
+
+
+def test_config3_asr_shaped_batch_of_32(full_model):
+    m, bench = full_model
+    va = bench.SEM_CARD + bench.REASON_CARD
+    B, frames = 32, 32
+    prompts = []
+    for i in range(B):
+        g = torch.Generator().manual_seed(1000 + i)
+        parts = [_text_rows(torch.randint(0, 128000, (15,), generator=g)), _audio_rows(53, va, g), _audio_rows(128, va, g)]
+        prompts.append((torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])))
+    assert prompts[0][0].shape[0] == 196
+    m.setup_caches(B, dtype=torch.bfloat16, max_seq_length=2048, max_rows=B * 195, log_frames=64)
+    out = m.generate_ragged(prompts, [frames] * B, mode=1)      # text feedback (evaluation/asr_task.py:668-682)
+    out = [o.cpu() for o in out]
+    assert all(o.shape == (frames, 9) for o in out)
+    for b in (0, 13, 31):
+        assert torch.equal(out[b], _single(m, prompts[b], frames, 1).cpu()), b
+    # different prompts -> different transcripts (the batch is not collapsing onto one row)
+    assert len({tuple(o[:, 0].tolist()) for o in out}) > B // 2
+
+
+def test_config4_ragged_tts_batch_with_retirement(full_model):
+    m, bench = full_model
+    B = 64
+    rs = np.random.RandomState(0)
+    lens = rs.randint(24, 49, size=B)
+    nfr = rs.randint(60, 301, size=B)
+    prompts = []
+    for i in range(B):
+        g = torch.Generator().manual_seed(2000 + i)
+        prompts.append(_text_rows(torch.randint(0, 128000, (int(lens[i]),), generator=g)))
+    m.setup_caches(B, dtype=torch.bfloat16, max_seq_length=2048, max_rows=4096, log_frames=320)
+    out = [o.cpu() for o in m.generate_ragged(prompts, nfr.tolist(), mode=0, reason_eos=-1, reason_card=bench.REASON_CARD)]
+    assert [o.shape[0] for o in out] == nfr.tolist()
+    check = sorted({0, 21, 63, int(np.argmax(nfr)), int(np.argmin(nfr))})
+    for b in check:
+        ref = _single(m, prompts[b], int(nfr[b]), 0).cpu()
+        assert torch.equal(out[b], ref), (b, int(lens[b]), int(nfr[b]), int((out[b] != ref).any(dim=1).nonzero()[0]))
+    assert (torch.stack([o[:60] for o in out])[:, :, 1:] < bench.SEM_CARD + bench.REASON_CARD).all()
+
+
+def test_config5_500_frames_long_cache(full_model):
+    m, bench = full_model
+    g = torch.Generator().manual_seed(5)
+    prompt = _text_rows(torch.randint(0, 128000, (35,), generator=g))
+    m.setup_caches(1, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=512)
+    long = _single(m, prompt, 500, 0).cpu()
+    assert long.shape == (500, 9)
+    assert int(m._st["row_pos"][0]) == 34 + 500
+    short = _single(m, prompt, 74, 0).cpu()
+    assert torch.equal(long[:74], short)                       # a longer run extends a shorter one
+    again = _single(m, prompt, 500, 0).cpu()
+    assert torch.equal(long, again)
+    # not a fixed point: the tail still moves (the cache past page 1 is really attended to)
+    assert len({tuple(r.tolist()) for r in long[-50:]}) > 5

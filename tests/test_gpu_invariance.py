@@ -49,3 +49,105 @@ def test_linear_rows_do_not_see_each_other(dtype, N, K):
         # a row keeps its value wherever it sits in the batch
         got = run(5, slice(7, 12), pro, epi)
         assert torch.equal(got, single[7:12])
+
+
+@pytest.fixture
+def linear_mode():
+    """ua2_debug_force_general_linear: 2 = row-tiled decode kernel only, 4 / 5 = skinny / tiled large-M kernel."""
+    from uniaudio2_amd._lib import lib
+
+    def set_mode(m):
+        lib.ua2_debug_force_general_linear(m)
+    yield set_mode
+    lib.ua2_debug_force_general_linear(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N,K", SHAPES + [(200, 72), (48, 4096)])
+def test_large_m_kernel_is_bit_identical_to_the_decode_kernel(dtype, N, K, linear_mode):
+    """ua2_gemm.hip reproduces ua2_gemv.hip's summation order: same bits for every row, every epilogue, at
+    row counts from 1 to 300 (ragged last row-block, ragged last column tile, K not a multiple of the chunk)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_GELU, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_CAST, PRO_NORM
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(N * 13 + K)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    w1 = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    p0, p1 = ops.pack_linear(w, dtype), ops.pack_linear(w1, dtype)
+    nw, nb = (1.0 + 0.1 * torch.randn(K, generator=g)).to(dev), (0.1 * torch.randn(K, generator=g)).to(dev)
+    Mmax = 300
+    x = torch.randn(Mmax, K, generator=g).to(dev)
+    res = torch.randn(Mmax, N, generator=g).to(dev)
+    forbid = torch.randint(0, 8, (Mmax,), generator=g).int().to(dev)
+    ws = ops.linear_workspace(dtype, Mmax, K, dev)
+    npart = (N + 15) // 16
+
+    def run(M, pro, epi, norm_kind=0):
+        y = torch.zeros(M, N, device=dev)
+        pm = torch.zeros(M, npart, device=dev)
+        pi = torch.zeros(M, npart, dtype=torch.int32, device=dev)
+        kw = dict(dtype=dtype, M=M, N=N, K=K, w0=p0, prologue=pro, epilogue=epi, x=x[:M], y=y, workspace=ws)
+        if pro == PRO_NORM:
+            kw.update(norm_w=nw, eps=1e-5, norm_kind=norm_kind, norm_b=nb)
+        if epi == EPI_SWIGLU:
+            kw.update(w1=p1)
+        if epi == EPI_RESIDUAL:
+            kw.update(resid=res[:M].contiguous())
+        if epi == EPI_STORE:
+            kw.update(part_max=pm, part_idx=pi, forbid=forbid)
+        ops.linear(**kw)
+        torch.cuda.synchronize()
+        return y, pm, pi
+
+    combos = [(PRO_CAST, EPI_STORE, 0), (PRO_NORM, EPI_STORE, 0), (PRO_NORM, EPI_SWIGLU, 0), (PRO_CAST, EPI_RESIDUAL, 0),
+              (PRO_NORM, EPI_GELU, 2), (PRO_NORM, EPI_STORE, 1)]
+    for pro, epi, nk in combos:
+        for M in (1, 5, 40, 130, 300):
+            linear_mode(2)
+            ref = run(M, pro, epi, nk)
+            for mode in (4, 5):             # skinny form, 128-row tiled form
+                linear_mode(mode)
+                got = run(M, pro, epi, nk)
+                for r, o, name in zip(ref, got, ("y", "part_max", "part_idx")):
+                    assert torch.equal(r, o), (pro, epi, nk, M, mode, name, (r.float() - o.float()).abs().max().item())
+        linear_mode(0)                      # the launcher's own choice (cost model between the two forms)
+        got = run(300, pro, epi, nk)
+        for r, o in zip(ref, got):
+            assert torch.equal(r, o)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("nh,nkv,hs,C", [(24, 8, 128, 3072), (32, 8, 64, 2048)])
+def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mode):
+    """Fused RMSNorm + QKV + RoPE + paged KV-cache append through both kernels: q_out and the cache pages agree
+    bit for bit (a 200-token prefill of one sequence)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_QKV_ROPE, PRO_NORM
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(hs)
+    M = 200
+    nq = (nh + 2 * nkv) * hs
+    w = ops.pack_linear((torch.randn(nq, C, generator=g) * C ** -0.5).to(dev), dtype, rope_head_size=hs)
+    x = torch.randn(M, C, generator=g).to(dev)
+    nw = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    pos = torch.arange(M, dtype=torch.int32, device=dev)
+    seq = torch.zeros(M, dtype=torch.int32, device=dev)
+    ang = torch.rand(2048, hs // 2, generator=g) * 6.28
+    cos, sin = ang.cos().to(dev), ang.sin().to(dev)
+    pt = torch.arange(32, dtype=torch.int32, device=dev).flip(0).contiguous().view(1, 32)
+    ws = ops.linear_workspace(dtype, M, C, dev)
+    outs = []
+    for mode in (2, 4, 5):
+        linear_mode(mode)
+        kp = torch.zeros(32, nkv, 64, hs, dtype=dtype, device=dev)
+        vp = torch.zeros_like(kp)
+        q = torch.zeros(M, nh * hs, device=dev)
+        ops.linear(dtype=dtype, M=M, N=nq, K=C, w0=w, prologue=PRO_NORM, epilogue=EPI_QKV_ROPE, x=x, norm_w=nw,
+                   row_pos=pos, row_seq=seq, rope_cos=cos, rope_sin=sin, q_out=q, kv=ops.kv_geom(kp, vp, pt, nh, nkv, hs),
+                   workspace=ws)
+        torch.cuda.synchronize()
+        outs.append((q, kp, vp))
+    for other in outs[1:]:
+        for r, o in zip(outs[0], other):
+            assert torch.equal(r, o)
+    assert outs[0][1].float().abs().sum() > 0

@@ -37,7 +37,8 @@ class LinearArgs(C.Structure):
                 ("w0", vp), ("w1", vp), ("y", vp), ("ldy", i32), ("resid", vp), ("ldr", i32),
                 ("part_max", vp), ("part_idx", vp), ("forbid", vp), ("row_pos", vp), ("row_seq", vp),
                 ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom),
-                ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32)]
+                ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32),
+                ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
 class AttnArgs(C.Structure):
@@ -80,6 +81,7 @@ _EXPORTS = {
     "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
+    "ua2_linear_workspace_bytes": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
     "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

@@ -1,0 +1,443 @@
+// Large-M form of ua2_linear: prefill of long prompts and batched decode (SURVEY.md §8d configs 3-5:
+// 32 x 196-row prefill, 64 live sequences per GPU).
+//
+// Replaces the same reference code as ua2_linear.hip / ua2_gemv.hip (lit_model.py:382-511 qkv/proj,
+// :591-595 LLaMAMLP, :883-890 RMSNorm; model_new.py:617-641 heads) when many rows share a launch.
+//
+// Contract: bit-identical, row by row, with the decode-regime kernel (ua2_gemv.hip).  That kernel sums a
+// row's dot product as `waves` partial MFMA chains over contiguous chunk ranges, added in wave order,
+// with `waves` a function of (dtype, N, K) only.  Here one wave owns a 64 x 64 output patch and walks
+// the whole of K; at each of those range boundaries it retires the running chain into a second
+// accumulator set (total += chain; chain = 0), which reproduces the same sums in the same order without
+// splitting K across waves.  The price is 2x accumulator registers (128 of the 512 VGPRs); the gain is a
+// proper GEMM: every weight byte is read once per 128 rows instead of once per 16.
+//
+// Two launches:
+//   prep:  one workgroup per row applies the prologue (cast | RMSNorm | LayerNorm) exactly as the
+//          decode kernel stages a row — same thread partition, same fixed-order statistics — and
+//          writes the operand rows in MFMA fragment order [M/16][K/KC][64 lanes][16 B] (the layout
+//          ua2_pack_linear gives the weights), so both GEMM operands stream as 1 KiB fragment blocks.
+//   gemm:  workgroup = 4 waves (2 x 2) = 128 rows x 128 columns (SwiGLU: 64 columns of each matrix);
+//          K advances two chunks per stage through a double-buffered 64 KiB LDS ring (global -> registers
+//          issued before the stage's MFMAs, registers -> LDS after); every wave reads its 4 + 4
+//          fragments per chunk from LDS with conflict-free 16-byte reads and issues 16 MFMAs.
+//          Workgroup ids are remapped so that each XCD works on a compact patch of (row-block,
+//          column-block) pairs: the fragments an L2 fetches are reused by its 32 CUs.
+// Bound: MFMA (2*M*N*K flop over (M + N)*K operand bytes); see DESIGN.md §5 for the measured fraction.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "ua2_common.h"
+#include "ua2_linear_common.h"
+
+namespace {
+
+// ---- prep: prologue + fragment-order packing of the activation rows ---------------------------------
+template <int DT, int PRO>
+__global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a, void* __restrict__ apack) {
+  constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
+  __shared__ float ssq[16], ssum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nw = nthreads >> 6;
+  const int m = blockIdx.x;                      // grid covers ceil(M/16)*16 rows; rows >= M are zero-filled
+  const int nchunks = (a.K + KC - 1) / KC;
+  const bool live = m < a.M;
+  const float* xr = a.x + (size_t)(live ? m : 0) * a.ldx;
+  const bool ln = (PRO == UA2_PRO_NORM) && a.norm_kind == UA2_NORM_LAYERNORM;
+  NormStat st{0.f, 1.f};
+  if constexpr (PRO == UA2_PRO_NORM) {
+    // identical to the decode kernel's pass 1: thread t owns k = 4t, 4t + 4*nthreads, ...
+    float ss = 0.f, sm = 0.f;
+    for (int k = tid * 4; k < a.K; k += nthreads * 4) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + k);
+      ss = sumsq4(ss, t);
+      sm = sum4(sm, t);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ss += __shfl_xor(ss, o); sm += __shfl_xor(sm, o); }
+    if (lane == 0) { ssq[wave] = ss; ssum[wave] = sm; }
+    __syncthreads();
+    float t = 0.f, u = 0.f;
+    for (int w = 0; w < nw; ++w) { t += ssq[w]; u += ssum[w]; }
+    st = norm_stat(a, u, t);
+  }
+  char* base = reinterpret_cast<char*>(apack) + (size_t)(m >> 4) * nchunks * 1024 + (size_t)(m & 15) * 16;
+  for (int k = tid * 4; k < nchunks * KC; k += nthreads * 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && k < a.K) {
+      t = *reinterpret_cast<const float4*>(xr + k);
+      if constexpr (PRO == UA2_PRO_NORM) {
+        const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ln) b = *reinterpret_cast<const float4*>(a.norm_b + k);
+        t.x = norm_apply(a, t.x, w.x, b.x, st);
+        t.y = norm_apply(a, t.y, w.y, b.y, st);
+        t.z = norm_apply(a, t.z, w.z, b.z, st);
+        t.w = norm_apply(a, t.w, w.w, b.w, st);
+      }
+    }
+    // fragment address of element k of row m: chunk c, lane = g*16 + (m & 15), element e
+    const int c = k / KC, r = k - c * KC, g = r / EPL, e = r - g * EPL;
+    char* dst = base + (size_t)c * 1024 + (size_t)g * 256 + (size_t)e * BYTES;
+    if constexpr (DT == UA2_BF16) {
+      uint2 p;
+      p.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
+      p.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
+      *reinterpret_cast<uint2*>(dst) = p;
+    } else {
+      *reinterpret_cast<float4*>(dst) = t;
+    }
+  }
+}
+
+// ---- the GEMM ------------------------------------------------------------------------------------------
+constexpr int kBMT = 8;     // 16-row tiles per workgroup (128 rows)
+constexpr int kWM = 4;      // row tiles per wave
+constexpr int kKS = 2;      // chunks per LDS stage
+constexpr int kGroupM = 8;  // row-blocks per L2 patch
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
+                                                      const int mblocks, const int nblocks) {
+  constexpr int KC = Elem<DT>::KC;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  constexpr int WN = 4 / NT;          // column tiles per wave, per matrix
+  constexpr int BNT = 2 * WN;         // column tiles per workgroup, per matrix
+  constexpr int TILES = kBMT + NT * BNT;            // fragment streams per chunk (16)
+  constexpr int LOADS = TILES * kKS * 64 / 256;     // 16-byte pieces per thread per stage (8)
+  __shared__ u32x4 lds[2][TILES][kKS][64];          // 64 KiB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nchunks = (a.K + KC - 1) / KC;
+  const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
+
+  // workgroup id -> (row-block pm, column-block pn): XCD x gets a contiguous id range (ids are dealt
+  // round-robin to the 8 XCDs), inside which row-blocks vary fastest within groups of kGroupM
+  int pid = blockIdx.x;
+  const int total = gridDim.x;
+  if (total % 8 == 0) pid = (pid & 7) * (total >> 3) + (pid >> 3);
+  const int per_group = kGroupM * nblocks;
+  const int group = pid / per_group, first_m = group * kGroupM;
+  const int gsz = min(mblocks - first_m, kGroupM);
+  const int pm = first_m + (pid % per_group) % gsz;
+  const int pn = (pid % per_group) / gsz;
+
+  // the stage loader: piece j of thread t is lane (t & 63) of fragment block j*4 + wave
+  const u32x4* src[LOADS];
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) {
+    const int blk = j * 4 + wave, tile = blk / kKS, kc = blk % kKS;
+    const u32x4* p;
+    if (tile < kBMT) {
+      const int mt = min(pm * kBMT + tile, mtiles - 1);
+      p = apack + (size_t)mt * nchunks * 64;
+    } else {
+      const int idx = tile - kBMT, mat = idx / BNT;
+      const int nt = min(pn * BNT + idx % BNT, ntiles - 1);
+      p = reinterpret_cast<const u32x4*>(mat ? a.w1 : a.w0) + (size_t)nt * nchunks * 64;
+    }
+    src[j] = p + (size_t)kc * 64 + lane;
+  }
+  const int nstages = (nchunks + kKS - 1) / kKS;
+  // two register staging sets: stage s+1 and s+2 are in flight while stage s is multiplied (one set
+  // would expose a full memory round trip per stage; measured 1.1 us/stage before, see profiles/r1_notes.md)
+  u32x4 stg0[LOADS], stg1[LOADS];
+  auto fetch = [&](u32x4 (&stg)[LOADS], int s) {
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+      const int kc = (j * 4 + wave) % kKS;
+      const int c = min(s * kKS + kc, nchunks - 1);          // clamped: a chunk past K is loaded but never used
+      stg[j] = src[j][(size_t)(c - kc) * 64];
+    }
+  };
+  auto commit = [&](int buf, const u32x4 (&stg)[LOADS]) {
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+      const int blk = j * 4 + wave;
+      lds[buf][blk / kKS][blk % kKS][lane] = stg[j];
+    }
+  };
+
+  f32x4 chain[NT][kWM][WN], tot[NT][kWM][WN];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mi = 0; mi < kWM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) {
+        chain[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tot[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  auto retire = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mi = 0; mi < kWM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[t][mi][ni][r] = __fadd_rn(tot[t][mi][ni][r], chain[t][mi][ni][r]);
+          chain[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+  };
+  int seg = 1;                                   // next range boundary: chunk (seg * nchunks) / nw
+  int boundary = (seg * nchunks) / nw;
+
+  auto compute = [&](int buf, int s) {
+#pragma unroll
+    for (int kc = 0; kc < kKS; ++kc) {
+      const int c = s * kKS + kc;
+      if (c < nchunks) {
+        while (seg < nw && c == boundary) {      // `while`: empty ranges (nw > nchunks) retire zeros, as the decode kernel adds them
+          retire();
+          ++seg;
+          boundary = (seg * nchunks) / nw;
+        }
+        u32x4 fa[kWM], fb[NT][WN];
+#pragma unroll
+        for (int mi = 0; mi < kWM; ++mi) fa[mi] = lds[buf][wm * kWM + mi][kc][lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) fb[t][ni] = lds[buf][kBMT + t * BNT + wn * WN + ni][kc][lane];
+#pragma unroll
+        for (int mi = 0; mi < kWM; ++mi) {
+          AFrag<DT> af;
+          af.v = __builtin_bit_cast(decltype(af.v), fa[mi]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) af.mma(fb[t][ni], chain[t][mi][ni]);
+        }
+      }
+    }
+  };
+
+  fetch(stg0, 0);
+  commit(0, stg0);
+  if (nstages > 1) fetch(stg0, 1);
+  if (nstages > 2) fetch(stg1, 2);
+  __syncthreads();
+  for (int s = 0; s < nstages; s += 2) {
+    compute(0, s);                               // even stage: lds[0]; stg0 = stage s+1, stg1 = stage s+2
+    if (s + 1 < nstages) commit(1, stg0);
+    __syncthreads();
+    if (s + 3 < nstages) fetch(stg0, s + 3);
+    if (s + 1 < nstages) compute(1, s + 1);      // odd stage: lds[1]
+    if (s + 2 < nstages) commit(0, stg1);
+    __syncthreads();
+    if (s + 4 < nstages) fetch(stg1, s + 4);
+  }
+  while (seg <= nw) { retire(); ++seg; }         // the last range (and any empty ones after it)
+
+  // ---- epilogue: lane holds D[row = 4*(lane >> 4) + r][col = lane & 15] of each 16 x 16 tile ----
+  const int col = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < kWM; ++mi) {
+    const int m0 = (pm * kBMT + wm * kWM + mi) * 16;
+    if (m0 >= a.M) continue;                      // wave-uniform
+    const int rows = min(16, a.M - m0);
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+      const int nt = pn * BNT + wn * WN + ni;
+      if (nt >= ntiles) continue;                 // wave-uniform
+      int tile[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tile[t] = nt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = tot[t][mi][ni][r];
+        EpiPre pre;
+        epilogue_prefetch<DT, EPI>(a, nt, row, col, pre, m0);
+        linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0, rows);
+      }
+    }
+  }
+}
+
+
+// ---- skinny form (a few dozen rows: batched decode) ---------------------------------------------------
+// The decode kernel's own structure with the LDS row tile replaced by the packed operand in L2: workgroup =
+// one 16-column weight tile x up to 64 rows, K split over `nw` waves exactly as ua2_gemv.hip splits it, every
+// weight fragment loaded once (non-temporal, straight from HBM) and used for MT row tiles; partial sums meet
+// in LDS and are added in wave order.  HBM-bound on the weights like the decode kernel; the operand rows
+// (M x K, a few hundred KiB) are re-read by every workgroup from L2.
+constexpr int kSkinnyMT = 4;
+
+template <int DT, int EPI, int CPW>
+__global__ __launch_bounds__(1024) void skinny_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack) {
+  constexpr int KC = Elem<DT>::KC;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  constexpr int MT = kSkinnyMT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);               // [nw][NT][MT][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int nchunks = (a.K + KC - 1) / KC;
+  const int mtiles = (a.M + 15) / 16;
+  const int nt = blockIdx.x, mt0 = blockIdx.y * MT;
+  const u32x4* wp[NT];
+  wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)nt * nchunks * 64 + lane;
+  if constexpr (NT == 2) wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)nt * nchunks * 64 + lane;
+  const u32x4* ap[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) ap[mi] = apack + (size_t)min(mt0 + mi, mtiles - 1) * nchunks * 64 + lane;
+  const int c0 = (wave * nchunks) / nw, c1 = ((wave + 1) * nchunks) / nw;
+  const int last = max(c1 - 1, 0);
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[t][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = c0; cb < c1; cb += CPW) {
+    u32x4 wf[NT][CPW], af[MT][CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      const size_t off = (size_t)min(cb + u, last) * 64;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + off);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[mi][u] = ap[mi][off];
+    }
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      if (cb + u < c1) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          AFrag<DT> f;
+          f.v = __builtin_bit_cast(decltype(f.v), af[mi][u]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) f.mma(wf[t][u], acc[t][mi]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(&red[(((wave * NT + t) * MT) + mi) * 256 + lane * 4]) = acc[t][mi];
+  __syncthreads();
+  if (tid >= 256) return;
+  const int row = tid >> 4, col = tid & 15;
+  const int srcl = (((row >> 2) << 4) + col) * 4 + (row & 3);
+  int tile[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tile[t] = nt;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int m0 = (mt0 + mi) * 16;
+    if (m0 >= a.M) break;                                    // uniform over the workgroup
+    float v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float sacc = 0.f;
+      for (int w = 0; w < nw; ++w) sacc += red[(((w * NT + t) * MT) + mi) * 256 + srcl];
+      v[t] = sacc;
+    }
+    EpiPre pre;
+    epilogue_prefetch<DT, EPI>(a, nt, row, col, pre, m0);
+    linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0, min(16, a.M - m0));
+  }
+}
+
+template <int DT, int EPI>
+void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t s) {
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  auto kern = skinny_kernel<DT, EPI, 4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const size_t smem = (size_t)geo.waves * NT * kSkinnyMT * 256 * sizeof(float);
+  const dim3 grid(ua2_ceil_div(a.N, 16), ua2_ceil_div(ua2_ceil_div(a.M, 16), kSkinnyMT));
+  hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.workspace));
+}
+
+template <int DT, int PRO>
+void launch_prep(const ua2_linear_args& a, int nthreads, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_prep_kernel<DT, PRO>), dim3(ua2_ceil_div(a.M, 16) * 16), dim3(nthreads), 0, s, a, a.workspace);
+}
+
+template <int DT, int EPI>
+void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  constexpr int BNT = 2 * (4 / NT);
+  const int mblocks = ua2_ceil_div(ua2_ceil_div(a.M, 16), kBMT), nblocks = ua2_ceil_div(ua2_ceil_div(a.N, 16), BNT);
+  hipLaunchKernelGGL((gemm_kernel<DT, EPI>), dim3(mblocks * nblocks), dim3(256), 0, s, a,
+                     reinterpret_cast<const u32x4*>(a.workspace), nw, mblocks, nblocks);
+}
+
+// Which of the two forms is faster — both give the same bits, so this is purely a cost model, fitted on
+// tools/ubench/gemm_shapes.py (profiles/r1_gemm_shapes.txt):
+//   skinny: the weights stream once per 64 rows at ~5 TB/s (+4 us per pass, +8 us for the two launches);
+//   tiled : 1.1 us per two-chunk stage when the grid is small (latency-bound), ~700 TFLOP/s bf16 when large.
+// UA2_SKINNY_MAX_ROWS=n overrides (skinny iff M <= n) for experiments.
+bool choose_skinny(const ua2_linear_args& a, int nt) {
+  static const int forced = [] {
+    const char* e = getenv("UA2_SKINNY_MAX_ROWS");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0) return a.M <= forced;
+  const double bytes = a.dtype == UA2_BF16 ? 2.0 : 4.0, kc = a.dtype == UA2_BF16 ? 32.0 : 16.0;
+  const double w_bytes = (double)a.N * a.K * bytes * nt;
+  const double t_skinny = 8.0 + (double)ua2_ceil_div(a.M, 16 * kSkinnyMT) * (w_bytes / 5.0e6 + 4.0);
+  const double flop_rate = a.dtype == UA2_BF16 ? 700.0e6 : 45.0e6;    // flop per us
+  const double t_tiled = std::max(5.0 + 1.1 * (a.K / kc) / kKS, 2.0 * a.M * a.N * a.K * nt / flop_rate);
+  return t_skinny <= t_tiled;
+}
+
+template <int DT>
+int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
+  const int nt = a.epilogue == UA2_EPI_SWIGLU ? 2 : 1;
+  const ua2_gemv_geometry geo = ua2_pick_gemv_geometry(a.dtype, a.N, a.K, nt);
+  if (a.prologue == UA2_PRO_NORM) launch_prep<DT, UA2_PRO_NORM>(a, geo.waves * 64, s);
+  else launch_prep<DT, UA2_PRO_CAST>(a, geo.waves * 64, s);
+  UA2_LAUNCH_CHECK();
+  const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
+  if (skinny_ok && (force == 4 || (force != 5 && choose_skinny(a, nt)))) {
+    switch (a.epilogue) {
+      case UA2_EPI_STORE: launch_skinny<DT, UA2_EPI_STORE>(a, geo, s); break;
+      case UA2_EPI_RESIDUAL: launch_skinny<DT, UA2_EPI_RESIDUAL>(a, geo, s); break;
+      case UA2_EPI_SWIGLU: launch_skinny<DT, UA2_EPI_SWIGLU>(a, geo, s); break;
+      case UA2_EPI_QKV_ROPE: launch_skinny<DT, UA2_EPI_QKV_ROPE>(a, geo, s); break;
+      case UA2_EPI_GELU: launch_skinny<DT, UA2_EPI_GELU>(a, geo, s); break;
+      default: return 1;
+    }
+    UA2_LAUNCH_CHECK();
+    return 0;
+  }
+  switch (a.epilogue) {
+    case UA2_EPI_STORE: launch_gemm<DT, UA2_EPI_STORE>(a, geo.waves, s); break;
+    case UA2_EPI_RESIDUAL: launch_gemm<DT, UA2_EPI_RESIDUAL>(a, geo.waves, s); break;
+    case UA2_EPI_SWIGLU: launch_gemm<DT, UA2_EPI_SWIGLU>(a, geo.waves, s); break;
+    case UA2_EPI_QKV_ROPE: launch_gemm<DT, UA2_EPI_QKV_ROPE>(a, geo.waves, s); break;
+    case UA2_EPI_GELU: launch_gemm<DT, UA2_EPI_GELU>(a, geo.waves, s); break;
+    default: return 1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K) {
+  if (M <= 0 || K <= 0 || (dtype != UA2_BF16 && dtype != UA2_F32)) return 0;
+  const int kc = dtype == UA2_BF16 ? 32 : 16;
+  return (size_t)((M + 15) / 16) * (size_t)((K + kc - 1) / kc) * 1024;
+}
+
+int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force) {
+  if (a.prologue != UA2_PRO_CAST && a.prologue != UA2_PRO_NORM) return 1;
+  if (!a.workspace || a.workspace_bytes < ua2_linear_workspace_bytes(a.dtype, a.M, a.K)) return 1;
+  const int rt = ua2_gemv_rows_per_tile(a.dtype, a.K);
+  if (rt < 1) return 1;                          // the decode kernel cannot take this K at all: nothing to be identical with
+  if (!force && a.M <= rt) return 1;             // one row tile: the decode kernel (operand rows live in LDS)
+  if (a.dtype == UA2_BF16) return launch_dt<UA2_BF16>(a, s, force);
+  return launch_dt<UA2_F32>(a, s, force);
+}

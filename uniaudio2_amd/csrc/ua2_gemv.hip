@@ -243,12 +243,15 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
 
 constexpr size_t kLdsABudget = 112 * 1024;   // activation tile budget (of 160 KiB; the rest holds the reduction buffers)
 
-int rows_per_tile(int dtype, int K) {
+}  // namespace
+int ua2_gemv_rows_per_tile(int dtype, int K) {
   const int kc = dtype == UA2_BF16 ? 32 : 16, bytes = dtype == UA2_BF16 ? 2 : 4;
   const size_t row_bytes = ((size_t)ua2_ceil_div(K, kc) * kc + 16 / bytes) * bytes;
   const int r = (int)(kLdsABudget / row_bytes);
   return r > 16 ? 16 : r;
 }
+namespace {
+int rows_per_tile(int dtype, int K) { return ua2_gemv_rows_per_tile(dtype, K); }
 
 struct Geometry {
   int waves, cpw;
@@ -350,6 +353,12 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+ua2_gemv_geometry ua2_pick_gemv_geometry(int dtype, int N, int K, int nt) {
+  const int kc = dtype == UA2_BF16 ? 32 : 16;
+  const Geometry g = pick_geometry(ua2_ceil_div(K, kc), ua2_ceil_div(N, 16), nt);
+  return ua2_gemv_geometry{g.waves, g.cpw};
+}
 
 // Returns 0 if launched, 1 if this problem is outside the decode regime (caller uses the general
 // kernel), negative on error.

@@ -301,7 +301,11 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     ua2_set_error("ua2_linear: bad dtype %d", a.dtype);
     return -1;
   }
-  if (!g_force_general) {
+  if (g_force_general != 1) {
+    if (g_force_general != 2) {
+      const int rc = ua2_gemm_try_launch(a, s, g_force_general >= 3 ? g_force_general : 0);  // many rows: packed operand, 128-row tiles
+      if (rc <= 0) return rc;
+    }
     const int rc = ua2_gemv_try_launch(a, s);  // decode regime: LDS-staged activations, all loads up front
     if (rc <= 0) return rc;
   }

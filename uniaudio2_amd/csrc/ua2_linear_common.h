@@ -3,6 +3,18 @@
 #pragma once
 #include "ua2_common.h"
 
+// ---- launch geometry of the decode-regime kernel (ua2_gemv.hip) --------------------------------
+// A function of (dtype, N, K, matrices per launch) only.  It fixes the order in which a row's dot
+// product is summed: `waves` partial sums over contiguous chunk ranges [w*nchunks/waves,
+// (w+1)*nchunks/waves), each an MFMA chain starting from zero, added in wave order.  The large-M kernel
+// (ua2_gemm.hip) reproduces exactly that order, which is what makes the two bit-identical per row.
+struct ua2_gemv_geometry { int waves, cpw; };
+ua2_gemv_geometry ua2_pick_gemv_geometry(int dtype, int N, int K, int nt);
+int ua2_gemv_rows_per_tile(int dtype, int K);
+// large-M path; returns 1 when not applicable (no workspace, ATTN prologue, few rows)
+// force: 0 = only when M spans more than one row tile; 3 = whenever possible; 4 / 5 = likewise, skinny / tiled form
+int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force);
+
 // ---- fragments ----------------------------------------------------------------------------
 
 template <int DT> struct AFrag;
@@ -147,24 +159,24 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
       if (col == 0 && rvalid) {
-        const int nb = gridDim.x;
-        a.part_max[(size_t)mr * nb + blockIdx.x] = bv;
-        a.part_idx[(size_t)mr * nb + blockIdx.x] = bi;
+        const int nb = (a.N + 15) / 16;
+        a.part_max[(size_t)mr * nb + tile[0]] = bv;
+        a.part_idx[(size_t)mr * nb + tile[0]] = bi;
       }
     }
   } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
     const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = (a.out_scale ? a.out_scale[n] * v[0] : v[0]) + p.resid;
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = __fadd_rn(a.out_scale ? __fmul_rn(a.out_scale[n], v[0]) : v[0], p.resid);
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {
       const float gte = v[0];
       const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
-      a.y[(size_t)mr * a.ldy + n] = sg * v[1];
+      a.y[(size_t)mr * a.ldy + n] = __fmul_rn(sg, v[1]);
     }
   } else if constexpr (EPI == UA2_EPI_GELU) {
     const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = 0.5f * v[0] * (1.0f + erff(v[0] * 0.70710678118654752440f));
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = __fmul_rn(__fmul_rn(0.5f, v[0]), __fadd_rn(1.0f, erff(__fmul_rn(v[0], 0.70710678118654752440f))));
   } else {  // UA2_EPI_QKV_ROPE — weight rows were permuted at pack time (ua2_pack_linear rope_head_size):
     // tile r of a head holds dims [8r, 8r+8) in columns 0-7 and their rotation partners
     // [hs/2+8r, hs/2+8r+8) in columns 8-15, so the half-split rotation closes inside one tile.

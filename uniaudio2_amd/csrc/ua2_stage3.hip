@@ -26,6 +26,8 @@ struct ua2_stage3 {
   float *xa, *text, *xb, *hbuf, *xg, *hfin, *q, *act, *yattn, *xd, *curr_h;
   float *text_logits, *audio_logits, *pmax_t, *pmax_a;
   int32_t *pidx_t, *pidx_a;
+  void* gemm_ws;               // operand scratch of the large-M linear kernel (max_rows x widest K)
+  size_t gemm_ws_bytes;
   int32_t npart_t, npart_a;
   int32_t grid_pages;
   int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
@@ -45,7 +47,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -65,8 +67,17 @@ Carve carve(const ua2_stage3_desc& d) {
   const size_t npt = (d.vt + 15) / 16, npa = (d.va + 15) / 16, Bm = d.max_batch;
   c.text_logits = take(Bm * d.vt); c.audio_logits = take(Bm * d.n_cb * d.va);
   c.pmax_t = take(Bm * npt); c.pidx_t = take(Bm * npt); c.pmax_a = take(Bm * npa); c.pidx_a = take(Bm * npa);
+  c.gemm_ws_floats = ua2_linear_workspace_bytes(d.dtype, (int64_t)R, (int64_t)std::max(std::max(C, Cd), std::max(qmax, actmax))) / sizeof(float);
+  c.gemm_ws = take(c.gemm_ws_floats);
   c.total = off;
   return c;
+}
+
+// every ua2_linear of the executor may use the large-M kernel (same results, weights read once per 128 rows)
+void fresh_args(const ua2_stage3* h, ua2_linear_args& a) {
+  memset(&a, 0, sizeof(a));
+  a.workspace = h->gemm_ws;
+  a.workspace_bytes = h->gemm_ws_bytes;
 }
 
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
@@ -79,7 +90,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     kv.max_pages = g.max_pages; kv.n_kv = g.n_kv; kv.n_head = g.n_head; kv.head_size = g.head_size;
 
     ua2_linear_args a;
-    memset(&a, 0, sizeof(a));
+    fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_QKV_ROPE;
     a.M = R; a.N = nqkv; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][0][l]; a.eps = g.eps;
     a.w0 = h->ptrs[gi][0][l]; a.row_pos = row_pos; a.row_seq = row_seq; a.rope_cos = g.rope_cos;
@@ -91,19 +102,19 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.y = h->yattn; at.kv = kv;
     if (int rc = ua2_attn_launch(at, s)) return rc;
 
-    memset(&a, 0, sizeof(a));
+    fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
     a.M = R; a.N = C; a.K = qn; a.x = h->yattn; a.ldx = qn;
     a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
-    memset(&a, 0, sizeof(a));
+    fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_SWIGLU;
     a.M = R; a.N = g.inter; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][1][l]; a.eps = g.eps;
     a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.y = h->act; a.ldy = g.inter;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
-    memset(&a, 0, sizeof(a));
+    fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
     a.M = R; a.N = C; a.K = g.inter; a.x = h->act; a.ldx = g.inter; a.w0 = h->ptrs[gi][4][l];
     a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
@@ -176,6 +187,7 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->xd = b + c.xd; h->curr_h = b + c.curr_h; h->text_logits = b + c.text_logits;
   h->audio_logits = b + c.audio_logits; h->pmax_t = b + c.pmax_t; h->pidx_t = (int32_t*)(b + c.pidx_t);
   h->pmax_a = b + c.pmax_a; h->pidx_a = (int32_t*)(b + c.pidx_a);
+  h->gemm_ws = b + c.gemm_ws; h->gemm_ws_bytes = c.gemm_ws_floats * sizeof(float);
   h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
   h->grid_pages = d->backbone.max_pages;
   *out = h;
@@ -237,7 +249,7 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
   const int C = d.backbone.n_embd, Cd = d.decoder.n_embd, w = d.n_cb + 1;
   ua2_linear_args a;
   // text_logits = lm_head(last_h); greedy text sample             (model_new.py:617,623)
-  memset(&a, 0, sizeof(a));
+  fresh_args(h, a);
   a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
   a.M = R; a.N = d.vt; a.K = C; a.x = h->hfin; a.ldx = C; a.w0 = d.lm_head; a.y = h->text_logits; a.ldy = d.vt;
   a.part_max = h->pmax_t; a.part_idx = h->pidx_t;
@@ -265,12 +277,12 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
   if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
   const float* curr = h->hfin;
   for (int i = 0; i < d.n_cb; ++i) {                               // model_new.py:630-641
-    memset(&a, 0, sizeof(a));
+    fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, 1, s)) return rc;
-    memset(&a, 0, sizeof(a));
+    fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
     a.w0 = h->audio_head[i]; a.y = h->audio_logits + (size_t)i * d.va; a.ldy = d.n_cb * d.va;

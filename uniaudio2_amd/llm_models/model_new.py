@@ -249,6 +249,87 @@ class Model_stage3(nn.Module):
                   "ua2_stage3_frame")
         return st["frame_log"][start:start + n_frames, :batch]
 
+    # ---- ragged batches / continuous batching (the reference has neither: SURVEY.md A.17, §8e) ------
+    @torch.inference_mode()
+    def forward_prefix_ragged(self, tokens_list, mask_list):
+        """Prefill of prompts of different lengths in one pass.  tokens_list[b] (L_b, 9), mask_list[b] (L_b, 9):
+        the rows to cache for sequence b (callers pass prompt[:-1] as with forward_prefix); sequence b takes
+        page-table row b and positions 0..L_b-1.  Rows are issued time-major in chunks of `max_rows`, so a chunk
+        only ever needs K/V written by itself or by earlier chunks."""
+        self._need()
+        st = self._st
+        dev = st["device"]
+        assert len(tokens_list) == len(mask_list) <= st["B"]
+        tk = torch.cat([t.reshape(-1, t.shape[-1]) for t in tokens_list]).to(dev)
+        mk = torch.cat([m.reshape(-1, m.shape[-1]) for m in mask_list]).to(dev)
+        ps = torch.cat([torch.arange(t.shape[0], device=dev) for t in tokens_list])
+        sq = torch.cat([torch.full((t.shape[0],), b, device=dev) for b, t in enumerate(tokens_list)])
+        order = torch.argsort(ps, stable=True)
+        tk, mk, ps, sq = tk[order], mk[order], ps[order], sq[order]
+        self._set_grid_pages(int(ps.max().item()))
+        R, mr = tk.shape[0], st["max_rows"]
+        for s0 in range(0, R, mr):
+            n = self._load_rows(tk[s0:s0 + mr], mk[s0:s0 + mr], ps[s0:s0 + mr], sq[s0:s0 + mr])
+            check(lib.ua2_stage3_trunk(self._h, n, ops.stream()), "ua2_stage3_trunk")
+        return None
+
+    @torch.inference_mode()
+    def retire_rows(self, keep, batch: int):
+        """Continuous batching: of the `batch` live sequences (rows 0..batch-1 of the decode state) keep those at
+        indices `keep`, in that order, as rows 0..len(keep)-1.  The per-row decode state and the page-table rows
+        of the three trunk caches are permuted together (a permutation, so no page is lost); the local decoder's
+        8-slot cache is rewritten every frame and needs nothing.  A row's results do not depend on its index or
+        on its neighbours (tests/test_gpu_invariance.py), so retiring never changes what the survivors generate."""
+        self._need()
+        st = self._st
+        keep = [int(k) for k in keep]
+        assert len(set(keep)) == len(keep) and all(0 <= k < batch for k in keep)
+        gone = [r for r in range(batch) if r not in set(keep)]
+        perm = torch.tensor(keep + gone, dtype=torch.long, device=st["device"])
+        for k in ("tokens", "mask", "row_pos", "forbid", "out_tokens"):
+            st[k][:batch] = st[k][:batch][perm]
+        for g in (self.audio_understanding_expert, self.backbone, self.audio_generation_expert):
+            pt = g.kv_cache.page_table
+            pt[:batch] = pt[:batch][perm]
+        return len(keep)
+
+    @torch.inference_mode()
+    def generate_ragged(self, prompts, n_frames, mode: int = 0, reason_eos: int = -1, reason_card: int = 0):
+        """Batched fixed-length generation with continuous batching: prompts[b] = (tokens (L_b, 9), mask (L_b, 9)),
+        n_frames[b] frames for sequence b (deterministic stop).  All sequences decode
+        together; a sequence leaves the batch the frame it finishes.  Returns a list of (n_frames[b], 9) int32
+        id tensors (device), each bit-identical to the sequence's own B = 1 run."""
+        self._need()
+        st = self._st
+        dev = st["device"]
+        B = len(prompts)
+        assert B <= st["B"] and len(n_frames) == B
+        self.reset_caches()
+        for g in (self.audio_understanding_expert, self.backbone, self.audio_generation_expert):   # undo earlier retirements
+            kv = g.kv_cache
+            kv.page_table.copy_(torch.arange(kv.page_table.numel(), dtype=torch.int32, device=dev).view_as(kv.page_table))
+        self.forward_prefix_ragged([t[:-1] for t, _ in prompts], [m[:-1] for _, m in prompts])
+        last_t = torch.stack([t[-1] for t, _ in prompts]).to(dev)
+        last_m = torch.stack([m[-1] for _, m in prompts]).to(dev)
+        pos = torch.tensor([t.shape[0] - 1 for t, _ in prompts], device=dev)
+        self.begin_decode(last_t.unsqueeze(1), last_m.unsqueeze(1), pos)
+        active = list(range(B))
+        out = [[] for _ in range(B)]
+        t_now = 0
+        max_pos = max(int(p) + int(n) for p, n in zip(pos.tolist(), n_frames)) + 1
+        while active:
+            n_act = len(active)
+            step = min(int(n_frames[b]) for b in active) - t_now
+            if step > 0:
+                log = self.generate_frames(step, n_act, mode, reason_eos, reason_card, max_pos=max_pos).clone()
+                for r, b in enumerate(active):
+                    out[b].append(log[:, r])
+                t_now += step
+            keep = [r for r, b in enumerate(active) if int(n_frames[b]) > t_now]
+            self.retire_rows(keep, n_act)
+            active = [active[r] for r in keep]
+        return [torch.cat(o) if o else torch.zeros(0, st["ncb"] + 1, dtype=torch.int32, device=dev) for o in out]
+
     def begin_decode(self, tokens, tokens_mask, input_pos, forbid_prefix=0):
         """Loads the first decode frame (the last prompt frame, tts_task.py:253-255) into the device state."""
         self._need()

@@ -59,7 +59,7 @@ def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
 def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None, ldx=None, norm_w=None, eps=1e-5,
            attn_o=None, attn_ml=None, w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
            forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True,
-           norm_b=None, norm_kind=0, out_scale=None, rope_mode=0):
+           norm_b=None, norm_kind=0, out_scale=None, rope_mode=0, workspace=None):
     a = LinearArgs()
     a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
     a.M, a.N, a.K = M, N, K
@@ -73,11 +73,19 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
     a.row_pos, a.row_seq = ptr(row_pos), ptr(row_seq)
     a.rope_cos, a.rope_sin, a.q_out = ptr(rope_cos), ptr(rope_sin), ptr(q_out)
     a.norm_b, a.norm_kind, a.out_scale, a.rope_mode = ptr(norm_b), norm_kind, ptr(out_scale), rope_mode
+    if workspace is not None:
+        a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     if kv is not None:
         a.kv = kv
     if not launch:
         return a
     check(lib.ua2_linear(C.byref(a), stream()), "ua2_linear")
+
+
+def linear_workspace(dtype, M, K, device):
+    """Scratch that lets ua2_linear take its large-M kernel for up to M rows of width K."""
+    n = lib.ua2_linear_workspace_bytes(dtype_code(dtype), M, K)
+    return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 def linear_chain_timed(args_list, iters):
