@@ -35,7 +35,10 @@ enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 enum ua2_prologue {
   UA2_PRO_CAST = 0, /* x as is                                   (lit_model.py:511,595; model_new.py:617,631) */
   UA2_PRO_NORM = 1, /* RMSNorm(x)*w, fp32 math                    (lit_model.py:883-890 before :424 / :591)    */
-  UA2_PRO_ATTN = 2  /* merge of the per-page attention partials   (softmax tail of lit_model.py:529-531)        */
+  UA2_PRO_ATTN = 2, /* merge of the per-page attention partials   (softmax tail of lit_model.py:529-531)        */
+  UA2_PRO_LOCAL_ATTN = 3 /* M == 1 only: the operand row IS the short-context attention of ua2_attn_local, computed
+                       in the kernel (x = q [1, n_head*head_size], kv, row_pos, row_seq as for ua2_attn_local;
+                       K == n_head*head_size).  Bit-identical to ua2_attn_local followed by UA2_PRO_CAST. */
 };
 
 /* What happens to the GEMM result (the ops the reference runs right after the Linear). */
@@ -167,6 +170,10 @@ typedef struct ua2_attn_args {
 } ua2_attn_args;
 
 int ua2_attn(const ua2_attn_args* a, void* stream);
+/* Short-context form for the local (depth) decoder (model_new.py:629-641): every row attends to positions
+ * 0..row_pos[r], row_pos[r] < 8, all in the first cache page of its sequence.  Uses q, row_pos, row_seq, kv, y
+ * of ua2_attn_args ([R, n_head*head_size] fp32 out); exact-operation softmax in position order. */
+int ua2_attn_local(const ua2_attn_args* a, void* stream);
 
 /* Frame embedding (model_new.py:594-600, 604, 665-673): for each row,
  * audio_sum = sum_i mask[i] * audio_emb[tok[i] + i*V_a]  (i = 0..n_cb-1, in order), text = wte[tok[n_cb]]. */

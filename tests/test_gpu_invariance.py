@@ -151,3 +151,48 @@ def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mo
         for r, o in zip(outs[0], other):
             assert torch.equal(r, o)
     assert outs[0][1].float().abs().sum() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("nh,nkv,hs", [(32, 8, 64), (4, 2, 32), (8, 4, 128)])
+def test_local_attention_and_its_fusion_into_the_o_projection(dtype, nh, nkv, hs):
+    """ua2_attn_local against a torch fp32 softmax(q k^T / sqrt(hs)) v on the cache contents, and the decode
+    kernel's UA2_PRO_LOCAL_ATTN prologue (M = 1) against ua2_attn_local + UA2_PRO_CAST: same bits, so a sequence
+    decodes identically alone (fused) and in a batch (stand-alone kernel)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST, PRO_LOCAL_ATTN
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(hs + nh)
+    R, C = 5, nh * hs
+    q = torch.randn(R, C, generator=g).to(dev)
+    kp = torch.randn(R, nkv, 64, hs, generator=g).to(device=dev, dtype=dtype)
+    vp = torch.randn(R, nkv, 64, hs, generator=g).to(device=dev, dtype=dtype)
+    pt = torch.arange(R, dtype=torch.int32, device=dev).flip(0).contiguous().view(R, 1)
+    pos = torch.tensor([0, 3, 7, 1, 5], dtype=torch.int32, device=dev)
+    geom = ops.kv_geom(kp, vp, pt, nh, nkv, hs)
+    y = torch.zeros(R, C, device=dev)
+    ops.attn_local(dtype=dtype, R=R, q=q, row_pos=pos, row_seq=None, kv=geom, y=y)
+    torch.cuda.synchronize()
+    G = nh // nkv
+    for r in range(R):
+        n = int(pos[r]) + 1
+        page = int(pt[r, 0])
+        k = kp[page, :, :n].float().repeat_interleave(G, dim=0)          # (nh, n, hs)
+        v = vp[page, :, :n].float().repeat_interleave(G, dim=0)
+        qq = q[r].view(nh, 1, hs)
+        p = torch.softmax((qq @ k.transpose(1, 2)) / hs ** 0.5, dim=-1)
+        ref = (p @ v).reshape(C)
+        assert (y[r] - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()), r
+    # fusion: row by row through the O-projection
+    w = ops.pack_linear((torch.randn(C, C, generator=g) * C ** -0.5).to(dev), dtype)
+    res = torch.randn(R, C, generator=g).to(dev)
+    for r in range(R):
+        a = torch.zeros(1, C, device=dev)
+        b = torch.zeros(1, C, device=dev)
+        ops.linear(dtype=dtype, M=1, N=C, K=C, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=y[r:r + 1].contiguous(), y=a,
+                   resid=res[r:r + 1].contiguous())
+        ops.linear(dtype=dtype, M=1, N=C, K=C, w0=w, prologue=PRO_LOCAL_ATTN, epilogue=EPI_RESIDUAL, x=q[r:r + 1].contiguous(), y=b,
+                   resid=res[r:r + 1].contiguous(), row_pos=pos[r:r + 1].contiguous(),
+                   row_seq=torch.tensor([r], dtype=torch.int32, device=dev), kv=geom)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (r, (a - b).abs().max().item())

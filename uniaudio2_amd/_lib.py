@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libua2hip.so")
 
 UA2_F32, UA2_BF16 = 0, 1
-PRO_CAST, PRO_NORM, PRO_ATTN = 0, 1, 2
+PRO_CAST, PRO_NORM, PRO_ATTN, PRO_LOCAL_ATTN = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE, EPI_GELU = 0, 1, 2, 3, 4
 NORM_RMS_LIT, NORM_RMS_MOSHI, NORM_LAYERNORM = 0, 1, 2
 ROPE_HALF_SPLIT, ROPE_INTERLEAVED, ROPE_NONE = 0, 1, 2
@@ -84,6 +84,7 @@ _EXPORTS = {
     "ua2_linear_workspace_bytes": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
     "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),
+    "ua2_attn_local": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]),
     "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),

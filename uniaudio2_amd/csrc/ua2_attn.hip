@@ -11,7 +11,10 @@
 // copies); softmax statistics are per page (flash-decoding split), un-normalised partials go to
 // HBM (a few KB) and are merged by the O-projection's prologue (UA2_PRO_ATTN) in page order, so
 // the summation order depends only on the position, never on the batch.
+#include <algorithm>
+
 #include "ua2_common.h"
+#include "ua2_attn_local.h"
 
 namespace {
 
@@ -410,6 +413,40 @@ int launch_fused(const ua2_attn_args& a, hipStream_t s) {
   return 0;
 }
 
+// ---- short-context (local decoder) form: one workgroup per row, 128 / HS heads per wave pass ----
+template <int DT, int HS>
+__global__ __launch_bounds__(1024) void attn_local_kernel(const ua2_attn_args a) {
+  using LA = LocalAttn<DT, HS>;
+  const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int pos = a.row_pos[r];
+  const int page = a.kv.page_table[(size_t)(a.row_seq ? a.row_seq[r] : r) * a.kv.max_pages];
+  const float* q_row = a.q + (size_t)r * a.kv.n_head * HS;
+  for (int h0 = wave * LA::HPW; h0 < a.kv.n_head; h0 += nw * LA::HPW) {
+    const int h = h0 + lane / LA::LPH, d = (lane % LA::LPH) * 2;
+    LA la;
+    la.issue(a.kv, q_row, page, h, d);
+    const float2 o = la.finish(pos);
+    *reinterpret_cast<float2*>(a.y + (size_t)r * a.kv.n_head * HS + (size_t)h * HS + d) = o;
+  }
+}
+
+template <int DT>
+int launch_local(const ua2_attn_args& a, hipStream_t s) {
+  const int hpw = 128 / a.kv.head_size;
+  const int waves = std::min(16, std::max(1, a.kv.n_head / hpw));
+  switch (a.kv.head_size) {
+    case 32: hipLaunchKernelGGL((attn_local_kernel<DT, 32>), dim3(a.R), dim3(waves * 64), 0, s, a); break;
+    case 64: hipLaunchKernelGGL((attn_local_kernel<DT, 64>), dim3(a.R), dim3(waves * 64), 0, s, a); break;
+    case 128: hipLaunchKernelGGL((attn_local_kernel<DT, 128>), dim3(a.R), dim3(waves * 64), 0, s, a); break;
+    default:
+      ua2_set_error("ua2_attn_local: head_size %d not supported (32, 64, 128)", a.kv.head_size);
+      return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DT>
 int launch_hs(const ua2_attn_args& a, hipStream_t s) {
   const int gp = a.grid_pages > 0 ? a.grid_pages : a.kv.max_pages;
@@ -444,6 +481,21 @@ int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
   if (a.dtype == UA2_F32) return launch_hs<UA2_F32>(a, s);
   ua2_set_error("ua2_attn: bad dtype %d", a.dtype);
   return -1;
+}
+
+int ua2_attn_local_launch(const ua2_attn_args& a, hipStream_t s) {
+  UA2_CHECK(a.R > 0 && a.q && a.row_pos && a.y && a.kv.k_pool && a.kv.v_pool && a.kv.page_table, "ua2_attn_local: bad arguments");
+  UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head % (128 / std::max(a.kv.head_size, 1)) == 0,
+            "ua2_attn_local: n_head=%d n_kv=%d head_size=%d not supported", a.kv.n_head, a.kv.n_kv, a.kv.head_size);
+  if (a.dtype == UA2_BF16) return launch_local<UA2_BF16>(a, s);
+  if (a.dtype == UA2_F32) return launch_local<UA2_F32>(a, s);
+  ua2_set_error("ua2_attn_local: bad dtype %d", a.dtype);
+  return -1;
+}
+
+extern "C" int ua2_attn_local(const ua2_attn_args* a, void* stream) {
+  UA2_CHECK(a != nullptr, "ua2_attn_local: NULL args");
+  return ua2_attn_local_launch(*a, (hipStream_t)stream);
 }
 
 extern "C" int ua2_attn(const ua2_attn_args* a, void* stream) {

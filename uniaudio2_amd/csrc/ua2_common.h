@@ -79,6 +79,7 @@ static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) 
 // internal launchers used by both the op-level ABI and the frame executor
 int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s);
+int ua2_attn_local_launch(const ua2_attn_args& a, hipStream_t s);
 extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
                                const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
                                int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,

@@ -16,10 +16,36 @@
 
 #include "ua2_common.h"
 #include "ua2_linear_common.h"
+#include "ua2_attn_local.h"
 
 namespace {
 
 constexpr int kMaxWaves = 16;
+
+// UA2_PRO_LOCAL_ATTN: this wave's share of the row's short-context attention, written straight into the LDS
+// operand row.  `burst` issues the wave's weight loads; it is called after the first pass's small loads are out
+// (a wave's loads return in order: q / K / V must not queue behind the weight stream).
+template <int DT, int HS, typename Burst>
+__device__ __forceinline__ void local_attn_prologue(const ua2_linear_args& a, char* a_lds, int m, int wave, int nw, int lane,
+                                                    Burst&& burst) {
+  using LA = LocalAttn<DT, HS>;
+  constexpr int BYTES = Elem<DT>::BYTES;
+  const int pos = a.row_pos[m];
+  const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages];
+  const float* q_row = a.x + (size_t)m * a.ldx;
+  bool streamed = false;
+  for (int h0 = wave * LA::HPW; h0 < a.kv.n_head; h0 += nw * LA::HPW) {
+    const int h = h0 + lane / LA::LPH, d = (lane % LA::LPH) * 2;
+    LA la;
+    la.issue(a.kv, q_row, page, h, d);
+    if (!streamed) { burst(); streamed = true; }
+    const float2 o = la.finish(pos);
+    char* dst = a_lds + ((size_t)h * HS + d) * BYTES;
+    if constexpr (DT == UA2_BF16) *reinterpret_cast<unsigned*>(dst) = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
+    else *reinterpret_cast<float2*>(dst) = o;
+  }
+  if (!streamed) burst();
+}
 
 // MR = multi-round: <= 8 waves per workgroup, several rounds of CPW chunks per wave, next round's
 // weights prefetched (double buffer); !MR = single burst: up to 16 waves, everything up front.
@@ -61,7 +87,7 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   // the epilogue needs goes out BEFORE the weight burst (it then completes in one L2 round trip
   // while the weights are still streaming), never behind it.
   constexpr int XPT = 2;  // float4 per thread kept in registers on the single-row fast path
-  const bool one = (rows == 1) && (a.K <= XPT * 4 * nthreads);
+  const bool one = (PRO != UA2_PRO_LOCAL_ATTN) && (rows == 1) && (a.K <= XPT * 4 * nthreads);
   float4 xv[XPT], nv[XPT], nb[XPT];
   const bool ln = (PRO == UA2_PRO_NORM) && a.norm_kind == UA2_NORM_LAYERNORM;
   if (one) {
@@ -85,10 +111,21 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   if (tid < 256) epilogue_prefetch_a<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre, m0);
 
   u32x4 wf[NT][CPW];
+  auto burst = [&]() {
 #pragma unroll
-  for (int u = 0; u < CPW; ++u)
+    for (int u = 0; u < CPW; ++u)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(c0 + u, last) * 64);
+      for (int t = 0; t < NT; ++t) wf[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)min(c0 + u, last) * 64);
+  };
+  if constexpr (PRO == UA2_PRO_LOCAL_ATTN) {
+    switch (a.kv.head_size) {
+      case 32: local_attn_prologue<DT, 32>(a, a_lds, m0, wave, nw, lane, burst); break;
+      case 64: local_attn_prologue<DT, 64>(a, a_lds, m0, wave, nw, lane, burst); break;
+      default: local_attn_prologue<DT, 128>(a, a_lds, m0, wave, nw, lane, burst); break;
+    }
+  } else {
+    burst();
+  }
   if (tid < 256) epilogue_prefetch_b<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre, m0);
 
   // ---- stage the activation rows into LDS (operand dtype) ----
@@ -103,7 +140,9 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
       *reinterpret_cast<float4*>(dst) = t;
     }
   };
-  if (one) {
+  if constexpr (PRO == UA2_PRO_LOCAL_ATTN) {
+    // operand row already in LDS
+  } else if (one) {
     NormStat st{0.f, 1.f};
     if constexpr (PRO == UA2_PRO_NORM) {
       float ss = 0.f, sm = 0.f;
@@ -348,6 +387,8 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
   } else if (a.prologue == UA2_PRO_CAST) {
     if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_RESIDUAL>(a, s);
     if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_STORE>(a, s);
+  } else if (a.prologue == UA2_PRO_LOCAL_ATTN) {
+    if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_LOCAL_ATTN, UA2_EPI_RESIDUAL>(a, s);
   }
   return 1;  // combination not specialised here: the caller falls back to the general kernel
 }

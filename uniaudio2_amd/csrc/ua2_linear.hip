@@ -275,6 +275,18 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
   UA2_CHECK(a.w0 != nullptr, "ua2_linear: w0 is NULL");
   const int epl = a.dtype == UA2_BF16 ? 8 : 4;
   UA2_CHECK(a.K % epl == 0, "ua2_linear: K=%d must be a multiple of %d", a.K, epl);
+  if (a.prologue == UA2_PRO_LOCAL_ATTN) {
+    const int kc = a.dtype == UA2_BF16 ? 32 : 16;
+    UA2_CHECK(a.M == 1 && a.epilogue == UA2_EPI_RESIDUAL, "ua2_linear: LOCAL_ATTN is the M == 1 O-projection only (use ua2_attn_local + CAST otherwise)");
+    UA2_CHECK(a.x && a.row_pos && a.kv.k_pool && a.kv.v_pool && a.kv.page_table && a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 &&
+                  (a.kv.head_size == 32 || a.kv.head_size == 64 || a.kv.head_size == 128) &&
+                  a.kv.n_head % (128 / a.kv.head_size) == 0 && a.K == a.kv.n_head * a.kv.head_size && a.K % kc == 0,
+              "ua2_linear: bad LOCAL_ATTN arguments");
+    UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
+    const int rc = ua2_gemv_try_launch(a, s);
+    UA2_CHECK(rc <= 0, "ua2_linear: LOCAL_ATTN problem outside the decode kernel's range");
+    return rc;
+  }
   if (a.prologue != UA2_PRO_ATTN) {
     UA2_CHECK(a.x != nullptr && a.ldx % 4 == 0, "ua2_linear: x NULL or ldx %% 4 != 0");
   } else {

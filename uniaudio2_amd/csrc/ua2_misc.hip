@@ -3,6 +3,8 @@
 // is that each replaces a chain of 5-10 tiny PyTorch launches in the reference with one.
 #include <stdarg.h>
 
+#include <algorithm>
+
 #include "ua2_common.h"
 
 static thread_local char g_err[512] = "";
@@ -19,17 +21,71 @@ extern "C" int ua2_version(void) { return UA2_VERSION; }
 namespace {
 
 // model_new.py:594-600 (_embed_audio_tokens + masked sum over the 8 streams), :604 (wte)
+// One workgroup per row; a thread owns 8 consecutive channels (16 B of a bf16 table row, 32 B of an fp32
+// one).  The token ids are read once, then all ncb + 1 table rows are requested before the first is summed:
+// the gathers are independent HBM misses and must overlap (issued one by one they cost ~1 us each).
+template <int DT, int NCB>
+__global__ __launch_bounds__(512) void embed_frame_kernel(int C, int ncb, int va, const int32_t* __restrict__ tokens,
+                                                          const uint8_t* __restrict__ mask, const void* __restrict__ audio_emb,
+                                                          const void* __restrict__ wte, float* __restrict__ audio_sum,
+                                                          float* __restrict__ text) {
+  const int m = blockIdx.x;
+  const int32_t* tk = tokens + (size_t)m * (ncb + 1);
+  const uint8_t* mk = mask + (size_t)m * (ncb + 1);
+  int32_t id[NCB + 1];
+  bool on[NCB];
+#pragma unroll
+  for (int i = 0; i <= NCB; ++i) id[i] = tk[i];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) on[i] = mk[i] != 0;
+  for (int c = threadIdx.x * 8; c < C; c += blockDim.x * 8) {
+    float e[NCB + 1][8];
+#pragma unroll
+    for (int i = 0; i <= NCB; ++i) {
+      const void* tab = i < NCB ? audio_emb : wte;
+      const size_t row = i < NCB ? (size_t)id[i] + (size_t)i * va : (size_t)id[NCB];
+      if constexpr (DT == UA2_BF16) {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(tab) + row * C + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          e[i][2 * q] = bf2f((unsigned short)(raw[q] & 0xffffu));
+          e[i][2 * q + 1] = bf2f((unsigned short)(raw[q] >> 16));
+        }
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(tab) + row * C + c);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(tab) + row * C + c + 4);
+        e[i][0] = a.x; e[i][1] = a.y; e[i][2] = a.z; e[i][3] = a.w;
+        e[i][4] = b.x; e[i][5] = b.y; e[i][6] = b.z; e[i][7] = b.w;
+      }
+    }
+    float s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s[q] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCB; ++i) s[q] += on[i] ? e[i][q] : 0.f;   // (audio_embeds * mask).sum(dim=2): i = 0..7 in order
+    }
+    float* as = audio_sum + (size_t)m * C + c;
+    float* tx = text + (size_t)m * C + c;
+    *reinterpret_cast<float4*>(as) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(as + 4) = make_float4(s[4], s[5], s[6], s[7]);
+    *reinterpret_cast<float4*>(tx) = make_float4(e[NCB][0], e[NCB][1], e[NCB][2], e[NCB][3]);
+    *reinterpret_cast<float4*>(tx + 4) = make_float4(e[NCB][4], e[NCB][5], e[NCB][6], e[NCB][7]);
+  }
+}
+
+// generic codebook count (scalar; the model has 8)
 template <int DT>
-__global__ void embed_frame_kernel(int C, int ncb, int va, const int32_t* __restrict__ tokens,
-                                   const uint8_t* __restrict__ mask, const void* __restrict__ audio_emb,
-                                   const void* __restrict__ wte, float* __restrict__ audio_sum,
-                                   float* __restrict__ text) {
+__global__ void embed_frame_any_kernel(int C, int ncb, int va, const int32_t* __restrict__ tokens,
+                                       const uint8_t* __restrict__ mask, const void* __restrict__ audio_emb,
+                                       const void* __restrict__ wte, float* __restrict__ audio_sum,
+                                       float* __restrict__ text) {
   const int m = blockIdx.x;
   const int32_t* tk = tokens + (size_t)m * (ncb + 1);
   const uint8_t* mk = mask + (size_t)m * (ncb + 1);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
-    for (int i = 0; i < ncb; ++i) {  // (audio_embeds * mask).sum(dim=2): i = 0..7 in order
+    for (int i = 0; i < ncb; ++i) {
       const float e = load_elem<DT>(audio_emb, ((size_t)tk[i] + (size_t)i * va) * C + c);
       s += mk[i] ? e : 0.f;
     }
@@ -39,28 +95,47 @@ __global__ void embed_frame_kernel(int C, int ncb, int va, const int32_t* __rest
 }
 
 // lit_model.py:883-890 (ln_f, :164) + model_new.py:607,610,613 blends
-__global__ void rmsnorm_blend_kernel(int C, const float* __restrict__ x, const float* __restrict__ w, float eps,
-                                     const float* __restrict__ other, const uint8_t* __restrict__ mask, int mask_ld,
-                                     int col_a, int col_b, float* __restrict__ out1, float* __restrict__ out2) {
+// One workgroup of 256 threads per row, float4 per thread per step, the row kept in registers between the
+// statistic and the scaling (C <= 4096; wider rows are re-read).  Fixed summation order: thread-local fma
+// chain over its float4s in ascending order, xor-shuffle tree, four wave partials left to right.
+__global__ __launch_bounds__(256) void rmsnorm_blend_kernel(int C, const float* __restrict__ x, const float* __restrict__ w, float eps,
+                                                            const float* __restrict__ other, const uint8_t* __restrict__ mask, int mask_ld,
+                                                            int col_a, int col_b, float* __restrict__ out1, float* __restrict__ out2) {
+  constexpr int KEEP = 4;
   __shared__ float part[4];
   const int m = blockIdx.x;
   const float* xr = x + (size_t)m * C;
+  const float fa = (col_a >= 0) ? (float)mask[(size_t)m * mask_ld + col_a] : 1.f;
+  const float fb = other ? (float)mask[(size_t)m * mask_ld + col_b] : 0.f;
+  float4 keep[KEEP];
   float ss = 0.f;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) ss += xr[c] * xr[c];
+  int it = 0;
+  for (int c = threadIdx.x * 4; c < C; c += 1024, ++it) {
+    const float4 t = *reinterpret_cast<const float4*>(xr + c);
+    if (it < KEEP) keep[it] = t;
+    ss = __fmaf_rn(t.x, t.x, ss); ss = __fmaf_rn(t.y, t.y, ss); ss = __fmaf_rn(t.z, t.z, ss); ss = __fmaf_rn(t.w, t.w, ss);
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
   __syncthreads();
   const float tot = ((part[0] + part[1]) + part[2]) + part[3];
   const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
-  const float fa = (col_a >= 0) ? (float)mask[(size_t)m * mask_ld + col_a] : 1.f;
-  const float fb = other ? (float)mask[(size_t)m * mask_ld + col_b] : 0.f;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float n = __fmul_rn(__fmul_rn(xr[c], rstd), w[c]);
-    float o1 = __fmul_rn(n, fa);
-    if (other) o1 = __fadd_rn(o1, __fmul_rn(other[(size_t)m * C + c], fb));
-    out1[(size_t)m * C + c] = o1;
-    if (out2) out2[(size_t)m * C + c] = n;
+  it = 0;
+  for (int c = threadIdx.x * 4; c < C; c += 1024, ++it) {
+    const float4 t = it < KEEP ? keep[it] : *reinterpret_cast<const float4*>(xr + c);
+    const float4 wv = *reinterpret_cast<const float4*>(w + c);
+    float4 n, o1;
+    n.x = __fmul_rn(__fmul_rn(t.x, rstd), wv.x); n.y = __fmul_rn(__fmul_rn(t.y, rstd), wv.y);
+    n.z = __fmul_rn(__fmul_rn(t.z, rstd), wv.z); n.w = __fmul_rn(__fmul_rn(t.w, rstd), wv.w);
+    o1.x = __fmul_rn(n.x, fa); o1.y = __fmul_rn(n.y, fa); o1.z = __fmul_rn(n.z, fa); o1.w = __fmul_rn(n.w, fa);
+    if (other) {
+      const float4 ov = *reinterpret_cast<const float4*>(other + (size_t)m * C + c);
+      o1.x = __fadd_rn(o1.x, __fmul_rn(ov.x, fb)); o1.y = __fadd_rn(o1.y, __fmul_rn(ov.y, fb));
+      o1.z = __fadd_rn(o1.z, __fmul_rn(ov.z, fb)); o1.w = __fadd_rn(o1.w, __fmul_rn(ov.w, fb));
+    }
+    *reinterpret_cast<float4*>(out1 + (size_t)m * C + c) = o1;
+    if (out2) *reinterpret_cast<float4*>(out2 + (size_t)m * C + c) = n;
   }
 }
 
@@ -108,10 +183,16 @@ extern "C" int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, in
                                float* text, void* stream) {
   UA2_CHECK(M > 0 && C > 0 && tokens && mask && audio_emb && wte && audio_sum && text, "ua2_embed_frame: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == UA2_BF16)
-    hipLaunchKernelGGL((embed_frame_kernel<UA2_BF16>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+  const bool fast = n_cb == 8 && C % 8 == 0;
+  const int nthr = std::min(512, std::max(64, (C / 8 + 63) / 64 * 64));
+  if (dtype == UA2_BF16 && fast)
+    hipLaunchKernelGGL((embed_frame_kernel<UA2_BF16, 8>), dim3(M), dim3(nthr), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+  else if (dtype == UA2_F32 && fast)
+    hipLaunchKernelGGL((embed_frame_kernel<UA2_F32, 8>), dim3(M), dim3(nthr), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+  else if (dtype == UA2_BF16)
+    hipLaunchKernelGGL((embed_frame_any_kernel<UA2_BF16>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
   else if (dtype == UA2_F32)
-    hipLaunchKernelGGL((embed_frame_kernel<UA2_F32>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+    hipLaunchKernelGGL((embed_frame_any_kernel<UA2_F32>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
   else {
     ua2_set_error("ua2_embed_frame: bad dtype %d", dtype);
     return -1;
@@ -123,7 +204,7 @@ extern "C" int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, in
 extern "C" int ua2_rmsnorm_blend(int32_t M, int32_t C, const float* x, const float* w, float eps, const float* other,
                                  const uint8_t* mask, int32_t mask_ld, int32_t col_a, int32_t col_b, float* out1,
                                  float* out2, void* stream) {
-  UA2_CHECK(M > 0 && C > 0 && x && w && out1, "ua2_rmsnorm_blend: bad arguments");
+  UA2_CHECK(M > 0 && C > 0 && C % 4 == 0 && x && w && out1, "ua2_rmsnorm_blend: bad arguments (C must be a multiple of 4)");
   UA2_CHECK((col_a < 0 && !other) || mask, "ua2_rmsnorm_blend: mask needed");
   hipLaunchKernelGGL(rmsnorm_blend_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, C, x, w, eps, other, mask,
                      mask_ld, col_a, col_b, out1, out2);

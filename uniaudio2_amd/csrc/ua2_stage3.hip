@@ -80,8 +80,9 @@ void fresh_args(const ua2_stage3* h, ua2_linear_args& a) {
   a.workspace_bytes = h->gemm_ws_bytes;
 }
 
+// local = the depth decoder: positions < kLocalCtx, short-context attention (fused into the O-projection when R == 1)
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
-            const int32_t* row_seq, int grid_pages, hipStream_t s) {
+            const int32_t* row_seq, int grid_pages, hipStream_t s, bool local = false) {
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   for (int l = 0; l < g.n_layer; ++l) {
@@ -97,15 +98,18 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
-    ua2_attn_args at;
-    memset(&at, 0, sizeof(at));
-    at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.y = h->yattn; at.kv = kv;
-    if (int rc = ua2_attn_launch(at, s)) return rc;
-
+    const bool fuse_attn = local && R == 1;
+    if (!fuse_attn) {
+      ua2_attn_args at;
+      memset(&at, 0, sizeof(at));
+      at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.y = h->yattn; at.kv = kv;
+      if (int rc = local ? ua2_attn_local_launch(at, s) : ua2_attn_launch(at, s)) return rc;
+    }
     fresh_args(h, a);
-    a.dtype = dt; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
-    a.M = R; a.N = C; a.K = qn; a.x = h->yattn; a.ldx = qn;
+    a.dtype = dt; a.prologue = fuse_attn ? UA2_PRO_LOCAL_ATTN : UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
+    a.M = R; a.N = C; a.K = qn; a.x = fuse_attn ? h->q : h->yattn; a.ldx = qn;
     a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
+    if (fuse_attn) { a.row_pos = row_pos; a.row_seq = row_seq; a.kv = kv; }
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -281,7 +285,7 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
     if (int rc = ua2_linear_launch(a, s)) return rc;
-    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, 1, s)) return rc;
+    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, 1, s, d.n_cb <= 8)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;

@@ -106,6 +106,14 @@ def attn(*, dtype, R, q, row_pos, row_seq, kv, attn_o=None, attn_ml=None, grid_p
     check(lib.ua2_attn(C.byref(a), stream()), "ua2_attn")
 
 
+def attn_local(*, dtype, R, q, row_pos, row_seq, kv, y):
+    """Short-context attention of the depth decoder (row_pos < 8, first cache page): y [R, n_head*head_size] fp32."""
+    a = AttnArgs()
+    a.dtype, a.R = dtype_code(dtype), R
+    a.q, a.row_pos, a.row_seq, a.y, a.kv = ptr(q), ptr(row_pos), ptr(row_seq), ptr(y), kv
+    check(lib.ua2_attn_local(C.byref(a), stream()), "ua2_attn_local")
+
+
 def embed_frame(dtype, tokens, mask, audio_emb, wte, va):
     M, w = tokens.shape
     Cc = audio_emb.shape[1]
