@@ -148,6 +148,36 @@ def codec_leg(dev):
             "rvq_encode_us_125x6x8192x32": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "config": "placeholder init_channel=32, hop 960"}
 
 
+def batched_leg(model, dev, B=64, frames=24):
+    """Information beside the B = 1 headline: one GPU decoding B = 64 sequences together
+    (32..33-token prompts, greedy, same kernels; rows bit-identical to their B = 1 runs, tests/test_gpu_configs.py).
+    Re-plans the caches for 64 sequences, so it runs last."""
+    model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=2048, max_rows=B * PROMPT_LEN, log_frames=frames + 8)
+    g = torch.Generator().manual_seed(99)
+    t = torch.zeros(B, PROMPT_LEN, 9, dtype=torch.long)
+    t[:, :, -1] = torch.randint(0, 128000, (B, PROMPT_LEN), generator=g)
+    m = torch.zeros(B, PROMPT_LEN, 9, dtype=torch.bool)
+    m[:, :, -1] = True
+    t, m = t.to(dev), m.to(dev)
+    pos = torch.arange(PROMPT_LEN - 1, device=dev).unsqueeze(0).repeat(B, 1)
+    res = {}
+    for rep in range(2):                                   # first pass captures the graph
+        model.reset_caches()
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        model.forward_prefix(t[:, :-1], tokens_mask=m, input_pos=pos)
+        e1.record()
+        model.begin_decode(t[:, -1:], m[:, -1:], torch.tensor([PROMPT_LEN - 1], device=dev))
+        model.generate_frames(frames, B, 0, reason_eos=-1, reason_card=REASON_CARD, max_pos=PROMPT_LEN + frames)
+        e2.record()
+        torch.cuda.synchronize()
+        res = {"B": B, "prefill_rows": B * (PROMPT_LEN - 1), "prefill_ms": round(e0.elapsed_time(e1), 2),
+               "decode_ms_per_frame": round(e1.elapsed_time(e2) / frames, 3),
+               "audio_tokens_per_s": round(8 * B * frames / (e1.elapsed_time(e2) * 1e-3), 1)}
+    return res
+
+
 def cpu_baseline_leg(model, tokens, mask, frames=6):
     """The CPU oracle (fp32 port of the reference algorithm as shipped: full-2048 masked prefill,
     repeat_interleave GQA, lm_head + 8-step local decoder every frame) on this host's cores, same
@@ -247,6 +277,8 @@ def main():
         res["cpu_baseline"] = cb
         n = cpu_ids.shape[0]
         res["cpu_fp32_vs_gpu_bf16_same_ids_frames"] = int((cpu_ids[:, 0].int() == log[:n, 0].cpu().int()).all(-1).sum())
+    if rank == 0 and world == 1 and not a.no_roofline:
+        res["batched_decode"] = batched_leg(model, dev)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -197,6 +197,13 @@ int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const float* part_max
                      int32_t* out_tokens, int32_t out_ld, int32_t out_col,
                      const void* emb, int32_t emb_row_offset, int32_t C, float* next_h, void* stream);
 
+/* Classifier-free guidance (model_new.py:618-622, 634-637) over a (conditional, unconditional) pair of logit rows:
+ * guided = l1 + (l0 - l1) * scale, written to BOTH rows ([2, ld] fp32), and the per-16-column arg-max partials of
+ * both rows ([2, ceil(V/16)], same format and tie rule as UA2_EPI_STORE; columns < forbid[0] excluded) rebuilt
+ * from it, so ua2_argmax_embed / ua2_sample_topk run unchanged and both rows continue from the same token. */
+int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
+                int32_t* part_idx, void* stream);
+
 /* Top-k sampling tail (model_new.py:146-187 with topk > 1: temperature, forbid_prefix, keep logits >= the
  * k-th largest, exponential-race multinomial draw) + next-step embedding gather.  Philox4x32-10 keyed by
  * (seed, counter[0] = draw index on device, row, stream_id): reproducible under graph replay; it does not
@@ -251,6 +258,15 @@ typedef struct ua2_conv1d_args {
 int ua2_conv1d(const ua2_conv1d_args* a, void* stream);
 /* torch.nn.AvgPool1d(kernel_size=k) over the last axis of [rows, Tin] (scalar24k.py:118). */
 int ua2_avgpool1d(const float* x, float* y, int64_t rows, int32_t Tin, int32_t k, void* stream);
+
+/* Depthwise (groups == channels) 1-D convolution / transposed convolution, exact fp32, taps in ascending order:
+ *   conv:   y[b,c,t] = bias[c] + sum_j w[c,j] * x[b,c, t*stride + j*dilation - pad_left]      (zero outside)
+ *   convtr: y[b,c,t] = bias[c] + sum_{ti*stride + j == t + pad_left} w[c,j] * x[b,c,ti]        (pad_left = left trim)
+ * Replaces the channel-wise resamplers of tools/tokenizer/MimiCodec/model/modules/resample.py:13-119
+ * (nn.Conv1d / nn.ConvTranspose1d with groups = dimension). x [B,C,Tin], w [C,K], y [B,C,Tout]. */
+int ua2_dwconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t C, int32_t Tin,
+                 int32_t Tout, int32_t K, int32_t stride, int32_t dilation, int32_t pad_left, int32_t transposed,
+                 void* stream);
 
 /* ---- whole-frame executor -------------------------------------------------------------- */
 
@@ -313,6 +329,8 @@ void ua2_stage3_destroy(ua2_stage3* h);
 int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages);
 /* Sampling mode of the heads: topk == 1 -> greedy (default); topk > 1 -> ua2_sample_topk with this temperature / seed. */
 int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed);
+/* cfg_scale > 1: frames of exactly two rows (conditional, unconditional) sample from the guided logits (ua2_cfg_mix). */
+int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale);
 
 /* model_new.py:594-613 (embed-merge -> U-expert -> backbone -> G-expert -> blend) for R rows
  * described by tokens/mask/row_pos/row_seq.  Used for prefill (forward_prefix, :456-497; the

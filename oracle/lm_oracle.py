@@ -205,28 +205,34 @@ class Stage3Oracle:
         return self._trunk(tokens, tokens_mask[:, :-1], input_pos, None)
 
     @torch.inference_mode()
-    def generate_frame(self, tokens, tokens_mask, input_pos, input_pos_maxp1=None, forbid_prefix=0):
+    def generate_frame(self, tokens, tokens_mask, input_pos, input_pos_maxp1=None, forbid_prefix=0, cfg_scale=1.0):
         """model_new.py:568-645 with topk=1, temperature=1 (greedy).  tokens (B,1,9); input_pos (B,) or (1,).
         Returns (B, 9) int32 [text, a0..a7].  Tie-break = lowest index (the reference resolves exact
-        ties with the RNG, :141-143; the golden vectors record that no tie occurred)."""
+        ties with the RNG, :141-143; the golden vectors record that no tie occurred).
+        cfg_scale > 1 with B > 1 (:618-622, 634-637): row 0 is the conditional prompt, rows 1.. the unconditional one;
+        the samplers see l[1:] + (l[0:1] - l[1:]) * cfg_scale and every row continues from that sample."""
         B = tokens.size(0)
+        cfg = cfg_scale > 1.0 and B > 1
+        mix = (lambda l: l[1:] + (l[0:1] - l[1:]) * cfg_scale) if cfg else (lambda l: l)
+        rep = (lambda t: t.repeat(2, 1)) if cfg else (lambda t: t)
         pos = input_pos.view(-1, 1).expand(B, 1) if input_pos.numel() in (1, B) else input_pos
         h_final = self._trunk(tokens, tokens_mask, pos, input_pos_maxp1)
         last_h = h_final[:, -1, :]
         text_logits = F.linear(self.qa(last_h), self.lm_head)          # :617
+        text_logits = mix(text_logits)
         self.last_text_logits = text_logits
-        out = [text_logits.argmax(-1, keepdim=True)]
+        out = [rep(text_logits.argmax(-1, keepdim=True))]
         curr_h = last_h.unsqueeze(1)
         alog = []
         for i in range(self.ncb):                                      # :630-641
             d_in = F.linear(self.qa(curr_h), self.projection)
             d_h = self.decoder.forward(d_in, torch.full((B, 1), i, dtype=torch.long), None)
-            lg = torch.mm(self.qa(d_h[:, -1, :]), self.audio_head[i])   # :632
+            lg = mix(torch.mm(self.qa(d_h[:, -1, :]), self.audio_head[i]))   # :632
             alog.append(lg)
             lg2 = lg.clone()
             if forbid_prefix > 0:
                 lg2[:, :forbid_prefix] = float("-inf")                  # :168-170
-            tok = lg2.argmax(-1, keepdim=True)
+            tok = rep(lg2.argmax(-1, keepdim=True))
             out.append(tok)
             curr_h = self.audio_embeddings[tok + i * self.va]           # :662-663
         self.last_audio_logits = torch.stack(alog, dim=1)               # (B, 8, V_a)
@@ -242,7 +248,8 @@ def shapes_from_configs(cfgs: Dict[str, dict]):
                 decoder=pick(cfgs.get("Llama-3.2-300M") or cfgs["Llama-3.2-4Layer"]))
 
 
-def run_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=None, reason_card=0, collect_logits=False):
+def run_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=None, reason_card=0, collect_logits=False,
+                    cfg_scale=1.0):
     """The generators' loop (evaluation/tts_task.py:244-282 "audio" feedback;
     evaluation/asr_task.py:658-682 "text" feedback) at fixed length (no EOS exit)."""
     B, L, _ = tokens.shape
@@ -257,7 +264,7 @@ def run_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=None, r
     for f in range(frames):
         if forbid_switch is not None and f == forbid_switch:
             forbid = reason_card
-        s = model.generate_frame(ct, cm, curr_pos, maxp1, forbid_prefix=forbid)
+        s = model.generate_frame(ct, cm, curr_pos, maxp1, forbid_prefix=forbid, **({"cfg_scale": cfg_scale} if cfg_scale != 1.0 else {}))
         samples.append(s)
         if collect_logits:
             tl.append(model.last_text_logits.clone()); al.append(model.last_audio_logits.clone())

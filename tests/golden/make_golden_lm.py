@@ -104,7 +104,7 @@ class LogitTap:
 
 
 @torch.inference_mode()
-def run_loop(mn, model, tokens, mask, frames, feedback, forbid_switch=None, reason_card=40):
+def run_loop(mn, model, tokens, mask, frames, feedback, forbid_switch=None, reason_card=40, cfg_scale=1.0):
     """tokens (B, L, 9) long, mask (B, L, 9) bool.  feedback in {"audio", "text"}.
 
     Protocol = evaluation/tts_task.py:244-282 ("audio": feed back the 8 sampled audio ids,
@@ -127,7 +127,7 @@ def run_loop(mn, model, tokens, mask, frames, feedback, forbid_switch=None, reas
             if forbid_switch is not None and f == forbid_switch:
                 forbid = reason_card
             s = model.generate_frame(curr_tokens, curr_mask, input_pos=curr_pos, input_pos_maxp1=maxp1,
-                                     temperature=1.0, topk=1, forbid_prefix=forbid)
+                                     temperature=1.0, topk=1, forbid_prefix=forbid, cfg_scale=cfg_scale)
             samples.append(s.clone())
             forbids.append(forbid)
             text_tok, audio = s[:, 0:1].long(), s[:, 1:].long()
@@ -139,8 +139,9 @@ def run_loop(mn, model, tokens, mask, frames, feedback, forbid_switch=None, reas
                 curr_mask = torch.cat([torch.zeros_like(audio).bool(), torch.ones(B, 1).bool()], dim=1).unsqueeze(1)
             curr_pos = curr_pos + 1
             maxp1 += 1
-    text_logits = torch.stack(tap.text)                      # (F, B, Vt)
-    audio_logits = torch.stack(tap.audio).view(frames, 8, B, -1).permute(0, 2, 1, 3)  # (F, B, 8, Va)
+    Bl = 1 if cfg_scale > 1.0 and B > 1 else B                # with guidance the samplers see one mixed row (model_new.py:618-622)
+    text_logits = torch.stack(tap.text)                      # (F, Bl, Vt)
+    audio_logits = torch.stack(tap.audio).view(frames, 8, Bl, -1).permute(0, 2, 1, 3)  # (F, Bl, 8, Va)
     return dict(samples=torch.stack(samples).int().numpy(),          # (F, B, 9)
                 forbid=np.asarray(forbids, dtype=np.int32),
                 text_logits=text_logits.numpy(), audio_logits=audio_logits.contiguous().numpy(),
@@ -191,6 +192,14 @@ def main():
     t, m = torch.stack([t0, t1]), torch.stack([m0, m1])
     r = run_loop(mn, model, t, m, 12, "audio", forbid_switch=5)
     out.update({f"tts2_{k}": v for k, v in r.items()}); out["tts2_tokens"] = t.numpy(); out["tts2_mask"] = m.numpy()
+
+    # case 4: classifier-free guidance pair (model_new.py:618-622, 634-637): row 0 conditional, row 1 unconditional
+    # (a shorter real prompt left-padded by the caller in the reference; here simply a different prompt of the same
+    # length), cfg_scale 1.5, both rows continue from the guided sample
+    t0, m0 = text_prompt(g, 10, vt); t1, m1 = text_prompt(g, 10, vt)
+    tc, mc = torch.stack([t0, t1]), torch.stack([m0, m1])
+    rc = run_loop(mn, model, tc, mc, 10, "audio", forbid_switch=4, cfg_scale=1.5)
+    out.update({f"cfg2_{k}": v for k, v in rc.items()}); out["cfg2_tokens"] = tc.numpy(); out["cfg2_mask"] = mc.numpy()
 
     # determinism: rerun case 3
     r2 = run_loop(mn, model, t, m, 12, "audio", forbid_switch=5)

@@ -45,3 +45,30 @@ def checksum(sd):
         s += float(t.sum())
         a += float(t.abs().sum())
     return [s, a]
+
+
+def mimi_state_dict(shapes, seed):
+    """Shape- and name-driven synthetic checkpoint for the MimiCodec family (make_golden_mimi.py and its tests):
+    fan-in scaled weights, gains around 1, LayerScale large enough to matter, positive codebook usage counts."""
+    out = OrderedDict()
+    for i, (k, shp) in enumerate(shapes.items()):
+        t = seeded_tensor(shp, seed * 7919 + i, std=1.0)
+        if k.endswith("_initialized"):
+            t = torch.ones(shp)
+        elif k.endswith("cluster_usage"):
+            t = 1.0 + 0.5 * t.abs()
+        elif k.endswith("embedding_sum"):
+            t = t
+        elif k.endswith("scale"):
+            t = 0.5 + 0.1 * t
+        elif "norm" in k and (k.endswith("weight") or k.endswith("alpha")):
+            t = 1.0 + 0.1 * t
+        elif k.endswith("bias"):
+            t = 0.1 * t
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = t / max(fan_in, 1) ** 0.5
+        out[k] = t
+    return out

@@ -52,7 +52,7 @@ def build_oracle(sd, mode, batch=1):
 
 
 def product_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=None, reason_card=0, fast=False,
-                        collect_logits=False):
+                        collect_logits=False, cfg_scale=1.0):
     """Same protocol as oracle.lm_oracle.run_decode_loop, through the product's reference-compatible API
     (fast=False: forward_prefix + generate_frame per frame) or its on-device loop (fast=True)."""
     dev = next(model.parameters()).device
@@ -67,8 +67,11 @@ def product_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=Non
     ct, cm = tokens[:, -1:], mask[:, -1:]
     if fast:
         assert forbid_switch is None
+        model.set_cfg(cfg_scale)
         model.begin_decode(ct, cm, curr_pos)
-        log = model.generate_frames(frames, B, 0 if feedback == "audio" else 1, reason_eos=-1, reason_card=reason_card)
+        mode = (2 if cfg_scale > 1.0 else 0) if feedback == "audio" else 1
+        log = model.generate_frames(frames, B, mode, reason_eos=-1, reason_card=reason_card)
+        model.set_cfg(1.0)
         return dict(samples=log.cpu())
     forbid = 0
     samples, tl, al = [], [], []
@@ -76,7 +79,7 @@ def product_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=Non
         if forbid_switch is not None and f == forbid_switch:
             forbid = reason_card
         s = model.generate_frame(ct, cm, input_pos=curr_pos, input_pos_maxp1=maxp1, temperature=1.0, topk=1,
-                                 forbid_prefix=forbid)
+                                 forbid_prefix=forbid, cfg_scale=cfg_scale)
         samples.append(s.cpu())
         if collect_logits:
             tl.append(model.buffer("text_logits", B).cpu().clone())

@@ -90,3 +90,43 @@ def test_residual_vq_mirror_and_stage2_subgraph():
     # cross-fade degenerates to concatenation-with-crop; what is checked is plumbing: CPU float output, cropped length
     assert wave.device.type == "cpu" and wave.dim() == 2 and wave.shape[0] == 1
     assert wave.shape[1] == 500 * 16 and torch.isfinite(wave).all()
+
+
+def test_mimicodec_encode_decode_vs_reference():
+    """MimiCodec assembly (SEANet -> transformer -> learnt down-sampler -> split RVQ; RVQ lookup -> channel-wise
+    up-sampler -> transformer -> SEANet) against outputs of the reference model on the same synthetic checkpoint
+    (tests/golden/make_golden_mimi.py): latent before the quantizer within 1e-4 of its scale, codes identical wherever
+    the nearest-codeword margin is not an fp32 near-tie, and decode(reference codes) within 1e-4 RMS (north_star)."""
+    import json
+    import os
+    from weights import mimi_state_dict, seeded_tensor
+    from uniaudio2_amd.tools.tokenizer.MimiCodec.model.models.MimiCodec import MimiCodec
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    meta = json.load(open(os.path.join(here, "mimi_toy.json")))
+    g = np.load(os.path.join(here, "mimi_toy.npz"))
+    m = MimiCodec(**meta["config"])
+    shapes = {k: tuple(s) for k, s in meta["keys"]}
+    m.load_state_dict(mimi_state_dict(shapes, 77))
+    m = m.to("cuda").eval()
+    wav = seeded_tensor((2, 1, 640), 4321, std=0.3).cuda()
+    z = m.downsample(m.encoder_transformer(m.encoder(wav))[0])
+    lat = torch.from_numpy(g["latent"]).cuda()
+    assert z.shape == lat.shape
+    assert (z - lat).abs().max().item() < 1e-4 * max(1.0, lat.abs().max().item())
+    # codes: quantise the REFERENCE latent so that a last-bit latent difference cannot move a decision
+    codes = m.quantizer.encode(lat)
+    ref_codes = torch.from_numpy(g["codes"]).cuda()
+    assert codes.shape == ref_codes.shape and codes.dtype == torch.int64
+    agree = (codes == ref_codes).float().mean().item()
+    assert agree > 0.98, agree            # cdist-vs-fma near-ties may flip (and then change the levels after them)
+    assert torch.equal(m.encode(wav)[:, 0], m.quantizer.rvq_first.encode(z)[:, 0])
+    # decode side on the reference's codes
+    zq = m.quantizer.decode(ref_codes)
+    assert (zq - torch.from_numpy(g["zq"]).cuda()).abs().max().item() < 1e-5 * max(1.0, float(np.abs(g["zq"]).max()))
+    up = m.upsample(zq)
+    assert (up - torch.from_numpy(g["up"]).cuda()).abs().max().item() < 1e-5 * max(1.0, float(np.abs(g["up"]).max()))
+    rec = m.decode(ref_codes)
+    ref = torch.from_numpy(g["rec"]).cuda()
+    assert rec.shape == ref.shape
+    rms = ((rec - ref) ** 2).mean().sqrt().item()
+    assert rms < 1e-4, rms

@@ -167,6 +167,24 @@ def test_batch_rows_equal_single_runs_ragged(golden, sd, dtype):
     assert torch.equal(log[:, 1], singles[1].int())
 
 
+def test_classifier_free_guidance_matches_reference(golden, sd):
+    """model_new.py:618-622, 634-637 through ua2_cfg_mix: golden `cfg2` (B = 2, cfg_scale 1.5, forbid switch at frame 4):
+    identical ids on both rows, guided logits within fp32 op-order noise; the on-device loop (mode 2) agrees."""
+    d, _ = golden
+    tokens, mask = torch.from_numpy(d["cfg2_tokens"]).long(), torch.from_numpy(d["cfg2_mask"]).bool()
+    m = build_product_model(sd, torch.float32, batch=2)
+    r = product_decode_loop(m, tokens, mask, 10, "audio", forbid_switch=4, reason_card=40, collect_logits=True, cfg_scale=1.5)
+    assert np.array_equal(r["samples"].numpy(), d["cfg2_samples"])
+    assert np.abs(r["text_logits"][:, :1].numpy() - d["cfg2_text_logits"]).max() < 2e-4
+    assert np.abs(r["audio_logits"][:, :1].numpy() - d["cfg2_audio_logits"]).max() < 2e-4
+    assert torch.equal(r["text_logits"][:, 0], r["text_logits"][:, 1])          # both rows hold the guided logits
+    fast = product_decode_loop(m, tokens, mask, 4, "audio", fast=True, cfg_scale=1.5)["samples"]
+    assert np.array_equal(fast.numpy(), d["cfg2_samples"][:4])
+    # guidance off again: the pair decodes as two independent rows
+    a = product_decode_loop(m, tokens, mask, 3, "audio")["samples"]
+    assert not torch.equal(a[:, 0], a[:, 1])
+
+
 def test_generators_end_to_end_fp32(golden, sd):
     """Generator.generate_asr-style text loop and the device-side reason_eos -> forbid_prefix switch."""
     import types

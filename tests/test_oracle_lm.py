@@ -56,6 +56,19 @@ def test_oracle_matches_reference_ids_and_logits(golden, toy_sd, case, frames, f
     np.testing.assert_allclose(r["audio_logits"].numpy(), d[f"{case}_audio_logits"], atol=2e-5, rtol=0)
 
 
+def test_oracle_classifier_free_guidance_pair(golden, toy_sd):
+    """model_new.py:618-622, 634-637 — golden `cfg2`: B = 2, cfg_scale 1.5, the samplers see one mixed row."""
+    d, _ = golden
+    tokens = torch.from_numpy(d["cfg2_tokens"]).long()
+    mask = torch.from_numpy(d["cfg2_mask"]).bool()
+    r = run_decode_loop(make_oracle(toy_sd, "fp32", 2), tokens, mask, 10, "audio", forbid_switch=4,
+                        reason_card=40, collect_logits=True, cfg_scale=1.5)
+    assert not d["cfg2_ties"].any()
+    assert np.array_equal(r["samples"].numpy(), d["cfg2_samples"])
+    assert np.abs(r["text_logits"].numpy() - d["cfg2_text_logits"]).max() < 2e-4
+    assert np.abs(r["audio_logits"].numpy() - d["cfg2_audio_logits"]).max() < 2e-4
+
+
 def test_oracle_batch_rows_equal_single_runs(golden, toy_sd):
     """Per-sequence positions: each row of a B=2 run equals its own B=1 run (batch invariance
     the product must also have; the reference can only batch aligned rows)."""

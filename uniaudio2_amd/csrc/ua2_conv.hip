@@ -131,7 +131,50 @@ __global__ void avgpool1d_kernel(const float* __restrict__ x, float* __restrict_
   }
 }
 
+// Depthwise (groups == channels) conv / transposed conv of the Mimi resamplers (resample.py:13-119 with
+// channel_wise=True: ConvTrUpsample1d in MimiCodec.py:68; k = 2*stride taps per channel).  One output per
+// thread, taps in ascending order with fma: a few bytes per flop, HBM-bound and tiny (512 channels x T).
+__global__ void dwconv1d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ y, int64_t total, int C, int Tin, int Tout, int K, int stride, int dilation,
+                                int pad_left, int transposed) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % Tout);
+    const int64_t bc = idx / Tout;
+    const int c = (int)(bc % C);
+    const float* xr = x + bc * Tin;
+    const float* wr = w + (size_t)c * K;
+    float acc = bias ? bias[c] : 0.f;
+    if (!transposed) {
+      for (int j = 0; j < K; ++j) {
+        const int ti = t * stride + j * dilation - pad_left;
+        if (ti >= 0 && ti < Tin) acc = __fmaf_rn(wr[j], xr[ti], acc);
+      }
+    } else {  // y_full[u] = sum_{ti*stride + j == u} w[j] x[ti];  pad_left = samples trimmed on the left
+      const int u = t + pad_left;
+      for (int j = 0; j < K; ++j) {
+        const int r = u - j;
+        if (r >= 0 && r % stride == 0 && r / stride < Tin) acc = __fmaf_rn(wr[j], xr[r / stride], acc);
+      }
+    }
+    y[idx] = acc;
+  }
+}
+
 }  // namespace
+
+extern "C" int ua2_dwconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t C, int32_t Tin,
+                            int32_t Tout, int32_t K, int32_t stride, int32_t dilation, int32_t pad_left, int32_t transposed,
+                            void* stream) {
+  UA2_CHECK(x && w && y && B > 0 && C > 0 && Tin > 0 && Tout > 0 && K >= 1 && stride >= 1 && dilation >= 1 && pad_left >= 0,
+            "ua2_dwconv1d: bad arguments");
+  UA2_CHECK(!transposed || dilation == 1, "ua2_dwconv1d: transposed form has no dilation");
+  const int64_t total = (int64_t)B * C * Tout;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(dwconv1d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, total, C, Tin, Tout, K,
+                     stride, dilation, pad_left, transposed);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
   UA2_CHECK(a && a->x && a->w && a->y, "ua2_conv1d: NULL argument");

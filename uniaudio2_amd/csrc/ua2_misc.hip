@@ -176,6 +176,39 @@ __global__ void argmax_embed_kernel(int n_part, const float* __restrict__ pmax, 
   }
 }
 
+
+// model_new.py:618-622, 634-637: classifier-free guidance over the (conditional, unconditional) logit rows
+//   guided = l1 + (l0 - l1) * scale      (each operation rounded once, as torch evaluates it)
+// Both rows are overwritten with `guided`, and the per-16-column arg-max partials of both rows are rebuilt
+// from it (same format and tie rule as the UA2_EPI_STORE epilogue), so the sampling tail runs unchanged and
+// gives both rows the same token.
+__global__ __launch_bounds__(256) void cfg_mix_kernel(float* __restrict__ logits, int ld, int V, float scale,
+                                                      const int32_t* __restrict__ forbid, float* __restrict__ pmax,
+                                                      int32_t* __restrict__ pidx) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int nb = (V + 15) / 16;
+  const int fb = forbid ? forbid[0] : 0;
+  float g = -INFINITY;
+  if (n < V) {
+    const float l0 = logits[n], l1 = logits[ld + n];
+    g = __fadd_rn(l1, __fmul_rn(__fsub_rn(l0, l1), scale));
+    logits[n] = g;
+    logits[ld + n] = g;
+  }
+  float bv = (n < V && n >= fb) ? g : -INFINITY;
+  int bi = n;
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 15) == 0 && n < V) {
+    pmax[n / 16] = bv; pidx[n / 16] = bi;
+    pmax[nb + n / 16] = bv; pidx[nb + n / 16] = bi;
+  }
+}
+
 }  // namespace
 
 extern "C" int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, int32_t va, const int32_t* tokens,
@@ -226,6 +259,15 @@ extern "C" int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const floa
     ua2_set_error("ua2_argmax_embed: bad dtype %d", dtype);
     return -1;
   }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
+                           int32_t* part_idx, void* stream) {
+  UA2_CHECK(logits && part_max && part_idx && V > 0 && ld >= V, "ua2_cfg_mix: bad arguments");
+  hipLaunchKernelGGL(cfg_mix_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ld, V, scale, forbid,
+                     part_max, part_idx);
   UA2_LAUNCH_CHECK();
   return 0;
 }

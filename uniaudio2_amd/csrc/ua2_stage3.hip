@@ -38,7 +38,8 @@ struct ua2_stage3 {
   // local decoder (they only share read-only inputs)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
-  std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
+  float cfg_scale = 1.f;       // > 1: classifier-free guidance over a (conditional, unconditional) row pair
+  std::map<std::tuple<int, int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
 };
 
 namespace {
@@ -98,7 +99,8 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
-    const bool fuse_attn = local && R == 1;
+    static const bool no_fuse = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
+    const bool fuse_attn = local && R == 1 && !no_fuse;
     if (!fuse_attn) {
       ua2_attn_args at;
       memset(&at, 0, sizeof(at));
@@ -241,6 +243,12 @@ extern "C" int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temper
   return 0;
 }
 
+extern "C" int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale) {
+  UA2_CHECK(h != nullptr && cfg_scale >= 1.f, "ua2_stage3_set_cfg: NULL handle or cfg_scale < 1");
+  h->cfg_scale = cfg_scale;
+  return 0;
+}
+
 extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
   UA2_CHECK(h != nullptr, "ua2_stage3_trunk: NULL handle");
   return trunk_impl(h, R, false, (hipStream_t)stream);
@@ -271,12 +279,19 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
     UA2_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
   }
   if (int rc = ua2_linear_launch(a, side)) return rc;
+  // model_new.py:618-622: with guidance the sampler sees l[1] + (l[0] - l[1]) * cfg_scale and both rows take its sample
+  const bool cfg = h->cfg_scale > 1.f && R > 1;
+  UA2_CHECK(!cfg || R == 2, "ua2_stage3_heads: classifier-free guidance needs exactly the (conditional, unconditional) pair, R=%d", R);
+  if (cfg)
+    if (int rc = ua2_cfg_mix(h->text_logits, d.vt, d.vt, h->cfg_scale, nullptr, h->pmax_t, h->pidx_t, side)) return rc;
   if (h->topk == 1) {
     if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
                                   side)) return rc;
   } else {   // model_new.py:623 sample_topk(text_logits, topk, temperature)
-    if (int rc = ua2_sample_topk(d.dtype, R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature, nullptr,
-                                 h->seed, d.counters + 1, 0, d.out_tokens, w, 0, nullptr, 0, C, nullptr, side)) return rc;
+    for (int rep = 0; rep < (cfg ? 2 : 1); ++rep)   // guidance: the same draw (row key 0) written to both rows
+      if (int rc = ua2_sample_topk(d.dtype, cfg ? 1 : R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature,
+                                   nullptr, h->seed, d.counters + 1, 0, d.out_tokens + (size_t)rep * w, w, 0, nullptr, 0, C,
+                                   nullptr, side)) return rc;
   }
   if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
   const float* curr = h->hfin;
@@ -292,13 +307,17 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
     a.w0 = h->audio_head[i]; a.y = h->audio_logits + (size_t)i * d.va; a.ldy = d.n_cb * d.va;
     a.part_max = h->pmax_a; a.part_idx = h->pidx_a; a.forbid = d.forbid;
     if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (cfg)   // model_new.py:634-637
+      if (int rc = ua2_cfg_mix(h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->cfg_scale, d.forbid, h->pmax_a,
+                               h->pidx_a, s)) return rc;
     if (h->topk == 1) {
       if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
                                     i * d.va, C, h->curr_h, s)) return rc;
     } else {   // model_new.py:639 audio_sample_topk(ci_logits, topk, temperature, forbid_prefix)
-      if (int rc = ua2_sample_topk(d.dtype, R, h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->topk,
-                                   h->temperature, d.forbid, h->seed, d.counters + 1, 1 + i, d.out_tokens, w, 1 + i,
-                                   d.audio_emb, i * d.va, C, h->curr_h, s)) return rc;
+      for (int rep = 0; rep < (cfg ? 2 : 1); ++rep)
+        if (int rc = ua2_sample_topk(d.dtype, cfg ? 1 : R, h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->topk,
+                                     h->temperature, d.forbid, h->seed, d.counters + 1, 1 + i, d.out_tokens + (size_t)rep * w, w,
+                                     1 + i, d.audio_emb, i * d.va, C, h->curr_h + (size_t)rep * C, s)) return rc;
     }
     curr = h->curr_h;
   }
@@ -332,9 +351,10 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
     return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, st);
   };
   if (!use_graph) return body(s);
-  int tbits;
+  int tbits, cbits;
   memcpy(&tbits, &h->temperature, sizeof(int));
-  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages, (int)h->topk, tbits);
+  memcpy(&cbits, &h->cfg_scale, sizeof(int));
+  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages, (int)h->topk, tbits, cbits);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;

@@ -118,6 +118,7 @@ class Model_stage3(nn.Module):
         self._h, self._st = h, st
         self._grid_pages = None
         self._sampling = None
+        self._cfg = 1.0
 
     def _destroy(self):
         if self._h is not None:
@@ -193,8 +194,7 @@ class Model_stage3(nn.Module):
         or (B,) per sequence.  Returns (B, 9) int32 [text, a0..a7] on device."""
         self._need()
         self.set_sampling(topk, temperature)
-        if cfg_scale > 1.0 and tokens.size(0) > 1:
-            raise NotImplementedError("classifier-free guidance logit mixing (model_new.py:618-622) is not built yet")
+        self.set_cfg(cfg_scale if tokens.size(0) > 1 else 1.0)
         if temperature <= 0:
             raise ValueError("temperature must be > 0")
         st = self._st
@@ -226,6 +226,16 @@ class Model_stage3(nn.Module):
         if getattr(self, "_sampling", None) != key:
             check(lib.ua2_stage3_set_sampling(self._h, key[0], key[1], key[2]), "ua2_stage3_set_sampling")
             self._sampling = key
+
+    def set_cfg(self, cfg_scale: float = 1.0):
+        """Classifier-free guidance (model_new.py:618-622, 634-637): with cfg_scale > 1 a frame of two rows
+        (conditional, unconditional) samples from l[1] + (l[0] - l[1]) * cfg_scale and both rows take that sample.
+        Applies to generate_frame and generate_frames (mode 2 continues every row from row 0)."""
+        self._need()
+        cfg_scale = max(float(cfg_scale), 1.0)
+        if getattr(self, "_cfg", 1.0) != cfg_scale:
+            check(lib.ua2_stage3_set_cfg(self._h, cfg_scale), "ua2_stage3_set_cfg")
+            self._cfg = cfg_scale
 
     # ---- MI355X-native fast path ---------------------------------------------------------------
     @torch.inference_mode()

@@ -206,6 +206,16 @@ def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None,
     return y
 
 
+def dwconv1d(x, w, *, stride=1, dilation=1, pad_left=0, Tout=None, bias=None, transposed=False):
+    """Depthwise conv / transposed conv: x [B,C,Tin] fp32, w [C,K] fp32 -> [B,C,Tout] (ua2_dwconv1d)."""
+    B, Cc, Tin = x.shape
+    K = w.shape[-1]
+    y = torch.empty(B, Cc, Tout, dtype=torch.float32, device=x.device)
+    check(lib.ua2_dwconv1d(ptr(x.contiguous()), ptr(w.contiguous()), ptr(bias), ptr(y), B, Cc, Tin, Tout, K, stride, dilation,
+                           pad_left, int(transposed), stream()), "ua2_dwconv1d")
+    return y
+
+
 def avgpool1d(x, k):
     B, Cc, T = x.shape
     y = torch.empty(B, Cc, T // k, dtype=torch.float32, device=x.device)

@@ -3,13 +3,15 @@
 Mirror of the reference's llm_modules/conv.py == tools/tokenizer/MimiCodec/model/modules/conv.py
 (StreamingConv1d :168-254, StreamingConvTranspose1d :265-329, NormConv1d :111-132,
 NormConvTranspose1d :135-158; same attribute tree, so the same state-dict keys `conv.conv.weight`,
-`convtr.convtr.weight`).  Scope: what the Mimi instance uses (MimiCodec.py:47-50) — norm "none",
-pad_mode "constant"; the non-streaming (whole-sequence) forward.  Arithmetic: ua2_conv1d.
+`convtr.convtr.weight`).  Scope: what the Mimi instance uses (MimiCodec.py:47-50, 67-68) — norm "none",
+pad_mode "constant" (SEANet) or "replicate" (the down-sampler), groups 1 or channel-wise (the up-sampler);
+the non-streaming (whole-sequence) forward.  Arithmetic: ua2_conv1d / ua2_dwconv1d.
 """
 import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ...... import ops
 from ......_lib import ACT_ELU, ACT_NONE
@@ -42,15 +44,21 @@ class StreamingConv1d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1, groups=1, bias=True, causal=False,
                  norm="none", norm_kwargs=None, pad_mode="constant"):
         super().__init__()
-        if pad_mode != "constant" or groups != 1:
-            raise NotImplementedError("only pad_mode='constant', groups=1 (the Mimi configuration) are on the hot path")
-        self.conv = NormConv1d(in_channels, out_channels, kernel_size, stride, dilation=dilation, bias=bias, causal=causal, norm=norm)
+        if pad_mode not in ("constant", "replicate"):
+            raise NotImplementedError("pad_mode 'constant' / 'replicate' (the Mimi configuration) are on the hot path")
+        if groups not in (1, in_channels) or (groups != 1 and in_channels != out_channels):
+            raise NotImplementedError("groups must be 1 or channel-wise (in == out == groups)")
+        self.conv = NormConv1d(in_channels, out_channels, kernel_size, stride, dilation=dilation, groups=groups, bias=bias,
+                               causal=causal, norm=norm)
         self.causal, self.pad_mode = causal, pad_mode
         self._w = None
 
     def prepare(self):
         c = self.conv.conv
-        self._w, self._k = ops.pack_conv_weight(c.weight.detach().float())
+        if c.groups == 1:
+            self._w, self._k = ops.pack_conv_weight(c.weight.detach().float())
+        else:
+            self._w, self._k = c.weight.detach().float().reshape(c.out_channels, -1).contiguous(), c.kernel_size[0]
         self._bias = c.bias.detach().float().contiguous() if c.bias is not None else None
 
     def forward(self, x, pre_act=ACT_NONE, residual=None):
@@ -70,6 +78,12 @@ class StreamingConv1d(nn.Module):
             pad_l = padding_total - pad_r
             pad_r += extra
         tout = (T + pad_l + pad_r - k_eff) // s + 1
+        if self.pad_mode == "replicate" and (pad_l or pad_r):     # conv.py:80-94 pad1d: edge values, then a plain conv
+            x = F.pad(x, (pad_l, pad_r), mode="replicate")
+            pad_l = 0
+        if c.groups != 1:
+            assert pre_act == ACT_NONE and residual is None
+            return ops.dwconv1d(x, self._w, stride=s, dilation=d, pad_left=pad_l, Tout=tout, bias=self._bias)
         return ops.conv1d(x, self._w, k, c.out_channels, stride=s, dilation=d, pad_left=pad_l, Tout=tout, bias=self._bias,
                           pre_act=pre_act, residual=residual)
 
@@ -78,14 +92,20 @@ class StreamingConvTranspose1d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, groups=1, bias=True, causal=False, norm="none",
                  trim_right_ratio=1.0, norm_kwargs=None):
         super().__init__()
-        self.convtr = NormConvTranspose1d(in_channels, out_channels, kernel_size, stride, bias=bias, causal=causal, norm=norm)
+        if groups not in (1, in_channels) or (groups != 1 and in_channels != out_channels):
+            raise NotImplementedError("groups must be 1 or channel-wise (in == out == groups)")
+        self.convtr = NormConvTranspose1d(in_channels, out_channels, kernel_size, stride, groups=groups, bias=bias, causal=causal,
+                                          norm=norm)
         self.causal, self.trim_right_ratio = causal, trim_right_ratio
         assert self.causal or self.trim_right_ratio == 1.0, "`trim_right_ratio` != 1.0 only makes sense for causal convolutions"
         self._w = None
 
     def prepare(self):
         c = self.convtr.convtr
-        self._w, self._m = ops.pack_convtr_weight(c.weight.detach().float(), c.stride[0])
+        if c.groups == 1:
+            self._w, self._m = ops.pack_convtr_weight(c.weight.detach().float(), c.stride[0])
+        else:
+            self._w, self._m = c.weight.detach().float().reshape(c.in_channels, -1).contiguous(), None
         self._bias = c.bias.detach().float().contiguous() if c.bias is not None else None
 
     def forward(self, x, pre_act=ACT_NONE):
@@ -102,5 +122,8 @@ class StreamingConvTranspose1d(nn.Module):
             pad_r = padding_total // 2
             pad_l = padding_total - pad_r
         full = (x.shape[-1] - 1) * s + k
+        if c.groups != 1:
+            assert pre_act == ACT_NONE
+            return ops.dwconv1d(x, self._w, stride=s, pad_left=pad_l, Tout=full - pad_l - pad_r, bias=self._bias, transposed=True)
         return ops.conv1d(x, self._w, self._m, c.out_channels, pad_left=self._m - 1, Tout=full - pad_l - pad_r,
                           bias=self._bias, pre_act=pre_act, out_phases=s, out_trim_left=pad_l)
