@@ -133,3 +133,60 @@ def test_generate_tts_chunked_loop_equals_reference_loop(n_reason, n_sem):
     gen._model.cursor = 0
     gen.generate_tts(torch.tensor([1]), "tts", text_token=torch.tensor([2]), topk=50, temperature=0.9)
     assert gen._model.sampling == (50, 0.9)                    # forwarded to the device sampler
+
+
+def test_instruct_tts_prompt_layout_and_loop():
+    """insturct_tts_task.py:201-219 (prompt + <caption> + <transcription> text frames), :171-198 (CFG twin = text_pad)."""
+    from uniaudio2_amd.evaluation.insturct_tts_task import Generator
+    g = Generator.__new__(Generator)
+    for k, v in vars(TA).items():
+        setattr(g, k, v)
+    g.empty_token = 0
+    g.special_token_dict = g.get_special_token()
+    prompt, cap, text = torch.tensor([128000, 11, 128001]), torch.tensor([31, 32]), torch.tensor([21, 22, 23])
+    data, mask = g.prepare_instruct_tts_task(prompt, cap, text)
+    assert data.shape == (3 + 4 + 5, 9) and mask[:, -1].eq(1).all() and mask[:, :-1].eq(0).all()
+    assert data[:, -1].tolist() == [128000, 11, 128001, 128015, 31, 32, 128016, 128011, 21, 22, 23, 128012]
+    cd, cm = g.prepare_instruct_tts_task_for_cfg(prompt, cap, text)
+    assert cd.shape == data.shape and cd[:, -1].eq(TA.text_pad_token).all() and torch.equal(cm, mask)
+    # the loop: scripted frames, CFG pair -> mode 2, conditional row read
+    gen_rng = torch.Generator().manual_seed(3)
+    frames = [torch.randint(0, 4096, (1, 8), generator=gen_rng, dtype=torch.int32) for _ in range(4)]
+    frames.append(torch.full((1, 8), TA.reason_eos, dtype=torch.int32))
+    frames += [torch.randint(4100, 12292, (1, 8), generator=gen_rng, dtype=torch.int32) for _ in range(6)]
+    frames.append(torch.full((1, 8), TA.semantic_eos + TA.audio_reason_card, dtype=torch.int32))
+    frames += [torch.zeros(1, 8, dtype=torch.int32)] * 8
+    log = torch.zeros(len(frames), 2, 9, dtype=torch.int32)
+    log[:, 0, 1:] = torch.cat(frames)
+    log[:, 1, 1:] = 77                                           # unconditional row: never read
+    gen = Generator(_ScriptedModel(log), TA, text_tokenizer_path="ids", is_cfg=True)
+    r, s = gen.generate_instruct_tts(prompt, "instruct_tts", text_token=text, caption=cap, topk=1)
+    rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+    assert torch.equal(r, rr) and torch.equal(s, rs)
+    assert gen._model.batch == 2 and all(c[1] == 2 and c[2] == 2 for c in gen._model.calls)
+
+
+def test_speech_s2s_condition_sequence_and_loop():
+    """speech_s2s.py:233-281 + multi_task_inference.py:421-423: the source utterance's reason / semantic tokens with
+    their bos / eos frames (semantic ids offset by the reason cardinality) after the prompt; never guided."""
+    from uniaudio2_amd.evaluation.speech_s2s import Generator, S2S_KEYS, S2S_TYPES
+    frames = [torch.randint(0, 4096, (1, 8), dtype=torch.int32) for _ in range(3)]
+    frames.append(torch.full((1, 8), TA.reason_eos, dtype=torch.int32))
+    frames += [torch.randint(4100, 12292, (1, 8), dtype=torch.int32) for _ in range(3)]
+    frames.append(torch.full((1, 8), TA.semantic_eos + TA.audio_reason_card, dtype=torch.int32))
+    frames += [torch.zeros(1, 8, dtype=torch.int32)] * 8
+    log = torch.zeros(len(frames), 1, 9, dtype=torch.int32)
+    log[:, 0, 1:] = torch.cat(frames)
+    gen = Generator(_ScriptedModel(log), TA, text_tokenizer_path="ids", is_cfg=True)
+    reason, sem = torch.arange(8 * 3).view(8, 3), torch.arange(8 * 5).view(8, 5)
+    d = {"reason_seq_1": reason, "semantic_seq_1": sem, "reason_seq_2": reason, "semantic_seq_2": sem}
+    prompt = torch.tensor([128000, 7, 128001])
+    data, mask = gen.get_condition_seq(d, S2S_KEYS[:-2], S2S_TYPES[:-2], prompt)
+    assert data.shape == (3 + 5 + 7, 9)
+    assert data[3, :8].eq(TA.reason_bos).all() and data[7, :8].eq(TA.reason_eos).all()
+    assert torch.equal(data[4:7, :8], reason.t()) and torch.equal(data[9:14, :8], sem.t() + TA.audio_reason_card)
+    assert data[8, :8].eq(TA.semantic_bos + TA.audio_reason_card).all() and data[14, :8].eq(TA.semantic_eos + TA.audio_reason_card).all()
+    r, s = gen.generate_audio(prompt, "speech_s2s", d=d, keys=S2S_KEYS[:-2], types=S2S_TYPES[:-2], topk=1)
+    rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+    assert torch.equal(r, rr) and torch.equal(s, rs)
+    assert all(c[1] == 1 and c[2] == 0 for c in gen._model.calls) and gen.is_cfg

@@ -111,10 +111,11 @@ def _load_config_and_llm(args):
 
 def _get_generator_class(task):
     task = task.strip().lower()
-    from .evaluation import asr_task, audiogen_task, musicgen_task, songen_task, tts_task
+    from .evaluation import asr_task, audiogen_task, insturct_tts_task, musicgen_task, songen_task, speech_s2s, tts_task
     table = {"asr": asr_task, "yue_asr": asr_task, "lyric_recognition": asr_task, "audio_caption": asr_task,
              "music_caption": asr_task, "audio_understanding": asr_task, "speech_s2t": asr_task,
-             "tts": tts_task, "yue_tts": tts_task, "tta": audiogen_task, "ttm": musicgen_task, "lts": songen_task}
+             "tts": tts_task, "yue_tts": tts_task, "tta": audiogen_task, "ttm": musicgen_task, "lts": songen_task,
+             "instruct_tts": insturct_tts_task, "instructtts": insturct_tts_task, "speech_s2s": speech_s2s}
     if task not in table:
         raise ValueError(f"Unknown task: {task}. Understanding: {UNDERSTANDING_TASKS}. Generation: {GENERATION_TASKS}.")
     return table[task].Generator
@@ -128,6 +129,10 @@ def _generation_method_name(task):
         return "generate_audio"
     if t == "lts":
         return "generate_LTS"
+    if t in ("instruct_tts", "instructtts"):
+        return "generate_instruct_tts"
+    if t == "speech_s2s":
+        return "generate_audio"
     raise ValueError(f"Unknown generation task: {task}")
 
 
@@ -194,6 +199,8 @@ def run_generation_stage1(args):
                                            is_cfg=args.use_cfg)
     tok = generator._text_tokenizer
     task_prompt = _get_prompt_tensor(args, tok, args.task)
+    if task == "speech_s2s":
+        return _run_speech_s2s(args, generator, task_prompt)
     if args.text and args.text.strip():
         items = [("utt_0", args.text.strip())]
     elif args.text_file and os.path.isfile(args.text_file):
@@ -206,9 +213,11 @@ def run_generation_stage1(args):
     gen_fn = getattr(generator, _generation_method_name(task))
     ids = [torch.tensor(tok.tokenize(t), dtype=torch.long) for _, t in items]
 
+    extra = (lambda i: {"caption": ids[i]}) if _generation_method_name(task) == "generate_instruct_tts" else (lambda i: {})   # :520-521
+
     def one(i):
         return gen_fn(task_prompt=task_prompt, task_name=task, text_token=ids[i], temperature=args.temperature,
-                      topk=args.topk, cfg_scale=args.cfg_scale)
+                      topk=args.topk, cfg_scale=args.cfg_scale, **extra(i))
 
     results = parallel.run_sharded(list(range(len(items))), [len(x) for x in ids], one)
     if int(os.environ.get("RANK", "0")) == 0:
@@ -217,6 +226,40 @@ def run_generation_stage1(args):
             torch.save(reason.cpu(), os.path.join(args.output_dir, f"{name}_reason.pt"))
             torch.save(semantic.cpu(), os.path.join(args.output_dir, f"{name}_semantic.pt"))
             print(f"[Stage1] {name} -> {name}_reason.pt, {name}_semantic.pt")
+    return args.output_dir
+
+
+def _run_speech_s2s(args, generator, task_prompt):
+    """multi_task_inference.py:414-483: source = *_reason.pt / *_semantic.pt pairs of --token_dir; output = generated pairs."""
+    import glob
+    from . import parallel
+    from .evaluation.speech_s2s import S2S_KEYS, S2S_TYPES
+    if (args.audio and os.path.isfile(args.audio)) or (args.audio_dir and os.path.isdir(args.audio_dir)):
+        raise NotImplementedError("encoding raw audio needs the codec's frozen SSL encoders (out of scope, SURVEY.md §8f); "
+                                  "pass --token_dir with the source *_reason.pt / *_semantic.pt")
+    if not (args.token_dir and os.path.isdir(args.token_dir)):
+        raise ValueError("speech_s2s requires --audio, --audio_dir, or --token_dir (source reason/semantic .pt).")
+    names = [os.path.basename(p).replace("_reason.pt", "") for p in sorted(glob.glob(os.path.join(args.token_dir, "*_reason.pt")))]
+    items = []
+    for name in names:
+        rp, sp = os.path.join(args.token_dir, f"{name}_reason.pt"), os.path.join(args.token_dir, f"{name}_semantic.pt")
+        if not os.path.isfile(sp):
+            print(f"[Skip] {name}: missing source {rp} or {sp}")
+            continue
+        reason, semantic = torch.load(rp, map_location="cpu"), torch.load(sp, map_location="cpu")
+        items.append((name, {"reason_seq_1": reason, "semantic_seq_1": semantic, "reason_seq_2": reason, "semantic_seq_2": semantic}))
+
+    def one(i):
+        return generator.generate_audio(task_prompt=task_prompt, task_name="speech_s2s", d=items[i][1], keys=S2S_KEYS[:-2],
+                                        types=S2S_TYPES[:-2], temperature=args.temperature, topk=args.topk, cfg_scale=args.cfg_scale)
+
+    results = parallel.run_sharded(list(range(len(items))), [int(d["semantic_seq_1"].shape[-1]) for _, d in items], one)
+    if int(os.environ.get("RANK", "0")) == 0:
+        for i, (name, _) in enumerate(items):
+            reason, semantic = results[i]
+            torch.save(reason.cpu(), os.path.join(args.output_dir, f"{name}_reason.pt"))
+            torch.save(semantic.cpu(), os.path.join(args.output_dir, f"{name}_semantic.pt"))
+            print(f"[Stage1] speech_s2s {name} -> {name}_reason.pt, {name}_semantic.pt")
     return args.output_dir
 
 
@@ -265,9 +308,11 @@ def main(argv=None):
         run_understanding(args)
         return
     if task in [t.lower() for t in GENERATION_TASKS]:
-        if task in ("instructtts", "instruct_tts", "speech_s2s"):
-            raise NotImplementedError(f"task {args.task}: generator variant not mirrored yet")
-        if not ((args.text and args.text.strip()) or (args.text_file and os.path.isfile(args.text_file))):
+        if task == "speech_s2s":
+            if not ((args.audio and os.path.isfile(args.audio)) or (args.audio_dir and os.path.isdir(args.audio_dir)) or
+                    (args.token_dir and os.path.isdir(args.token_dir))):
+                raise ValueError("speech_s2s requires --audio, --audio_dir, or --token_dir (source reason/semantic .pt).")
+        elif not ((args.text and args.text.strip()) or (args.text_file and os.path.isfile(args.text_file))):
             raise ValueError("For generation task provide --text or --text_file.")
         if not args.llm_train_config or not args.text_tokenizer_path:
             raise ValueError("Set --llm_train_config and --text_tokenizer_path.")
