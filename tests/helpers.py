@@ -24,20 +24,36 @@ def toy_state_dict(meta):
     return sd
 
 
-def shrink_product_registry():
-    """Same shrink the golden generator applies to the reference registry."""
-    from uniaudio2_amd.llm_models import config as cfg
-    for name, kw in TOY_LM.items():
-        keep = {k: v for k, v in kw.items() if k in cfg.Config.__dataclass_fields__}
-        for key in (name, name + "-Instruct"):
-            cfg.name_to_config[key].update(keep)
+class toy_registry:
+    """Context manager: the same shrink the golden generator applies to the reference registry, undone on exit so that
+    tests building the real sizes in the same process (bench.build_model) never see toy entries."""
+
+    def __enter__(self):
+        import copy
+        from uniaudio2_amd.llm_models import config as cfg
+        self.cfg, self.saved = cfg, copy.deepcopy(cfg.name_to_config)
+        for name, kw in TOY_LM.items():
+            keep = {k: v for k, v in kw.items() if k in cfg.Config.__dataclass_fields__}
+            for key in (name, name + "-Instruct"):
+                cfg.name_to_config[key].update(keep)
+        return self
+
+    def __exit__(self, *exc):
+        self.cfg.name_to_config.clear()
+        self.cfg.name_to_config.update(self.saved)
+        return False
+
+
+def build_toy_module():
+    """Model_stage3 at the toy sizes, on CPU, registry restored."""
+    from uniaudio2_amd.llm_models.model_new import Model_stage3, ModelArgs
+    with toy_registry():
+        return Model_stage3(ModelArgs(**TOY_MODEL_ARGS))
 
 
 def build_product_model(sd, dtype, batch=1, device="cuda", **setup_kw):
-    from uniaudio2_amd.llm_models.model_new import Model_stage3, ModelArgs
-    shrink_product_registry()
-    m = Model_stage3(ModelArgs(**TOY_MODEL_ARGS))
-    missing = m.load_state_dict(sd, strict=True)
+    m = build_toy_module()
+    m.load_state_dict(sd, strict=True)
     m = m.to(device)
     m.setup_caches(batch, dtype=dtype, **setup_kw)
     return m

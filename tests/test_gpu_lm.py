@@ -35,10 +35,8 @@ def _case(d, case):
 
 def test_state_dict_layout_matches_reference(golden):
     """The product accepts the reference checkpoint layout key for key (SURVEY.md §5 checkpoint row)."""
-    from helpers import shrink_product_registry
-    from uniaudio2_amd.llm_models.model_new import Model_stage3, ModelArgs
-    shrink_product_registry()
-    m = Model_stage3(ModelArgs(**TOY_MODEL_ARGS))
+    from helpers import build_toy_module
+    m = build_toy_module()
     mine = {k: list(v.shape) for k, v in m.state_dict().items()}
     ref = {k: s for k, s in golden[1]["keys"]}
     assert mine == ref
@@ -194,10 +192,8 @@ def test_generators_end_to_end_fp32(golden, sd):
     d, _ = golden
     ta = types.SimpleNamespace(text_pad_token=3, semantic_pad_token=0, semantic_eos=69, semantic_bos=68, reason_eos=39,
                                reason_bos=38, reason_pad_token=0, parallel_number=9, audio_reason_card=RC)
-    from helpers import shrink_product_registry
-    from uniaudio2_amd.llm_models.model_new import Model_stage3, ModelArgs
-    shrink_product_registry()
-    m = Model_stage3(ModelArgs(**TOY_MODEL_ARGS))
+    from helpers import build_toy_module
+    m = build_toy_module()
     m.load_state_dict(sd)
     m = m.to("cuda").float()
     gen = Generator(m, ta, text_tokenizer_path="ids")                # setup_caches(1) inside, fp32 parameters -> fp32 kernels

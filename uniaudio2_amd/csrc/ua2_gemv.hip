@@ -308,7 +308,8 @@ Geometry pick_geometry(int nchunks, int blocks, int nt) {
   // measured (tools/ubench/gemv_shapes.py, profiles/r1_gemv_geometry.txt): grids larger than the CU
   // count stream best as 8-wave workgroups walking K in double-buffered rounds of 4 chunks (two
   // workgroups per CU overlap each other's reduce/epilogue); smaller grids as one wide burst.
-  if (blocks > 256 && nchunks >= 96 && nchunks % 32 == 0) return Geometry{8, 4};
+  // (K = 2048 -> 64 chunks included: the local decoder's SwiGLU runs 13.1 us this way vs 16.0 us as one burst)
+  if (blocks > 256 && nchunks >= 64 && nchunks % 32 == 0) return Geometry{8, 4};
   const int cap = (nt == 2) ? 8 : 16;
   const int cpws[3] = {4, 8, 16};
   Geometry best{0, 0};
