@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel summary (count, total, avg, min, max, share) from a rocprofv3 rocpd sqlite database
 (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes DIR/NAME_results.db on ROCm 7.2).
-Usage: tools/rocpd_stats.py results.db [--by-grid] > profiles/xyz_kernel_stats.txt"""
+Usage: tools/rocpd_stats.py results.db [--by-grid] > profiles/xyz_kernel_stats.txt
+--by-grid splits a kernel symbol by launch configuration (grid and dynamic LDS bytes): the same template
+instantiation serves several problem shapes (e.g. the 3072-d and the 2048-d SwiGLU GEMV)."""
 import sqlite3
 import sys
 
@@ -10,12 +12,12 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     by_grid = "--by-grid" in sys.argv
     cur = db.cursor()
-    q = ("select s.kernel_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.end - d.start "
+    q = ("select s.kernel_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.end - d.start, d.group_segment_size "
          "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id")
     agg = {}
     tot = 0
-    for name, gx, gy, gz, dur in cur.execute(q):
-        key = (name, gx, gy, gz) if by_grid else (name,)
+    for name, gx, gy, gz, dur, lds in cur.execute(q):
+        key = (name, gx, gy, gz, lds) if by_grid else (name,)
         a = agg.setdefault(key, [0, 0, 1 << 62, 0])
         a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
         tot += dur
@@ -31,8 +33,8 @@ def main():
             pass
         name = name.replace("(anonymous namespace)::", "").replace("ua2_linear_args", "args")
         if by_grid:
-            name += f"  grid={key[1]}x{key[2]}x{key[3]}"
-        print(f"{a[0]:8d} {a[1]/1e6:10.3f} {a[1]/a[0]/1e3:9.2f} {a[2]/1e3:9.2f} {a[3]/1e3:9.2f} {100*a[1]/tot:6.2f}  {name[:150]}")
+            name += f"  grid={key[1]}x{key[2]}x{key[3]} lds={key[4]}"
+        print(f"{a[0]:8d} {a[1]/1e6:10.3f} {a[1]/a[0]/1e3:9.2f} {a[2]/1e3:9.2f} {a[3]/1e3:9.2f} {100*a[1]/tot:6.2f}  {name[:170]}")
 
 
 if __name__ == "__main__":
