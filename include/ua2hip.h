@@ -66,6 +66,9 @@ enum ua2_rope_mode {
 
 const char* ua2_last_error(void);
 int ua2_version(void);
+/* sizeof() of the ABI structs as this library was compiled, for a binding to check its own layout against:
+ * which = 0 ua2_kv_geom, 1 ua2_linear_args, 2 ua2_attn_args, 3 ua2_conv1d_args, 4 ua2_gpt_desc, 5 ua2_stage3_desc; else 0. */
+size_t ua2_struct_size(int which);
 
 /* Number of elements (of `dtype`) in the packed form of an [N,K] Linear weight. */
 size_t ua2_packed_elems(int dtype, int64_t N, int64_t K);

@@ -24,6 +24,10 @@ def test_packed_size_and_struct_layout():
     assert _lib.lib.ua2_packed_elems(_lib.UA2_BF16, 5120, 3072) == 5120 * 3072
     assert _lib.lib.ua2_packed_elems(_lib.UA2_BF16, 110, 128) == 112 * 128      # N padded to 16
     assert _lib.lib.ua2_packed_elems(_lib.UA2_F32, 16, 40) == 16 * 48           # K padded to 16
+    # the ctypes mirrors have the C structs' sizes (also enforced at import)
+    for i, st in enumerate(_lib.ABI_STRUCTS):
+        assert _lib.lib.ua2_struct_size(i) == __import__("ctypes").sizeof(st), st.__name__
+    assert _lib.lib.ua2_struct_size(99) == 0
     # the C side rejects a NULL args struct loudly instead of crashing
     assert _lib.lib.ua2_linear(None, None) != 0
     assert b"NULL" in _lib.lib.ua2_last_error()

@@ -190,3 +190,21 @@ def test_speech_s2s_condition_sequence_and_loop():
     rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
     assert torch.equal(r, rr) and torch.equal(s, rs)
     assert all(c[1] == 1 and c[2] == 0 for c in gen._model.calls) and gen.is_cfg
+
+
+def test_ragged_schedule_runs_every_sequence_exactly_its_frames():
+    """Continuous-batching plan of Model_stage3.generate_ragged."""
+    from uniaudio2_amd.llm_models.model_new import ragged_schedule
+    import random
+    rnd = random.Random(0)
+    for case in ([5], [3, 3, 3], [0, 2, 0], [60, 300, 61, 299, 60], [rnd.randint(0, 40) for _ in range(64)]):
+        done = [0] * len(case)
+        rows = list(range(len(case)))                    # rows[r] = original index of the sequence in row r
+        for step, active, keep in ragged_schedule(case):
+            assert active == rows and step >= 0
+            for b in active:
+                done[b] += step
+            assert all(done[active[r]] < case[active[r]] for r in keep)                    # survivors still have work
+            assert all(done[b] == case[b] for r, b in enumerate(active) if r not in keep)   # the retired are exactly done
+            rows = [rows[r] for r in keep]
+        assert done == list(case) and rows == []

@@ -81,6 +81,7 @@ _EXPORTS = {
     "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
+    "ua2_struct_size": (C.c_size_t, [C.c_int]),
     "ua2_dwconv1d": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ua2_cfg_mix": (C.c_int, [vp, i32, i32, C.c_float, vp, vp, vp, vp]),
     "ua2_stage3_set_cfg": (C.c_int, [vp, C.c_float]),
@@ -109,6 +110,9 @@ _EXPORTS = {
 }
 
 
+ABI_STRUCTS = (KvGeom, LinearArgs, AttnArgs, Conv1dArgs, GptDesc, Stage3Desc)
+
+
 def exported_symbols():
     """Every symbol include/ua2hip.h declares (checked by the CPU test-suite)."""
     return sorted(_EXPORTS)
@@ -124,6 +128,10 @@ def _load():
         fn = getattr(lib, name)           # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for i, st in enumerate(ABI_STRUCTS):    # a stale .so or a drifted binding must not corrupt kernel arguments silently
+        if lib.ua2_struct_size(i) != C.sizeof(st):
+            raise ImportError(f"{LIB_PATH}: sizeof({st.__name__}) is {lib.ua2_struct_size(i)} in the library but "
+                              f"{C.sizeof(st)} in the ctypes binding; rebuild (python -m uniaudio2_amd.build)")
     return lib
 
 

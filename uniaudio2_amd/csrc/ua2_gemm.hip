@@ -233,12 +233,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   while (seg <= nw) { retire(); ++seg; }         // the last range (and any empty ones after it)
 
   // ---- epilogue: lane holds D[row = 4*(lane >> 4) + r][col = lane & 15] of each 16 x 16 tile ----
+  // The epilogue's loads (residual; position -> RoPE table entry / page id) are gathered for the four rows of a
+  // tile before any of its stores, so the four dependent chains overlap instead of running one after the other
+  // (a store between two loads pins their order: 250 us of the 380 us QKV launch at M = 2048 before this).
   const int col = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < kWM; ++mi) {
     const int m0 = (pm * kBMT + wm * kWM + mi) * 16;
     if (m0 >= a.M) continue;                      // wave-uniform
     const int rows = min(16, a.M - m0);
+    EpiPre row_pre[4];
+    if constexpr (EPI == UA2_EPI_QKV_ROPE || EPI == UA2_EPI_STORE) {   // per-row part (position, table row, forbid): once per row tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epilogue_prefetch_a<DT, EPI>(a, 0, 4 * g + r, col, row_pre[r], m0);
+    }
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
       const int nt = pn * BNT + wn * WN + ni;
@@ -246,15 +254,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
       int tile[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) tile[t] = nt;
+      EpiPre pre[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 4 * g + r;
+        pre[r] = row_pre[r];
+        if constexpr (EPI != UA2_EPI_QKV_ROPE && EPI != UA2_EPI_STORE) epilogue_prefetch_a<DT, EPI>(a, nt, 4 * g + r, col, pre[r], m0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epilogue_prefetch_b<DT, EPI>(a, nt, 4 * g + r, col, pre[r], m0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
         float v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = tot[t][mi][ni][r];
-        EpiPre pre;
-        epilogue_prefetch<DT, EPI>(a, nt, row, col, pre, m0);
-        linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0, rows);
+        linear_epilogue<DT, EPI, NT>(a, v, tile, 4 * g + r, col, pre[r], m0, rows);
       }
     }
   }
@@ -328,6 +341,11 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const ua2_linear_args a, c
   int tile[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) tile[t] = nt;
+  EpiPre pre[MT];                                            // all row tiles' epilogue loads before any store
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mt0 + mi) * 16);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mt0 + mi) * 16);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int m0 = (mt0 + mi) * 16;
@@ -339,9 +357,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const ua2_linear_args a, c
       for (int w = 0; w < nw; ++w) sacc += red[(((w * NT + t) * MT) + mi) * 256 + srcl];
       v[t] = sacc;
     }
-    EpiPre pre;
-    epilogue_prefetch<DT, EPI>(a, nt, row, col, pre, m0);
-    linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0, min(16, a.M - m0));
+    linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre[mi], m0, min(16, a.M - m0));
   }
 }
 

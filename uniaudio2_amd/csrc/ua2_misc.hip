@@ -18,6 +18,18 @@ void ua2_set_error(const char* fmt, ...) {
 extern "C" const char* ua2_last_error(void) { return g_err; }
 extern "C" int ua2_version(void) { return UA2_VERSION; }
 
+extern "C" size_t ua2_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(ua2_kv_geom);
+    case 1: return sizeof(ua2_linear_args);
+    case 2: return sizeof(ua2_attn_args);
+    case 3: return sizeof(ua2_conv1d_args);
+    case 4: return sizeof(ua2_gpt_desc);
+    case 5: return sizeof(ua2_stage3_desc);
+    default: return 0;
+  }
+}
+
 namespace {
 
 // model_new.py:594-600 (_embed_audio_tokens + masked sum over the 8 streams), :604 (wte)

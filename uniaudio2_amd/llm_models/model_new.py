@@ -37,6 +37,20 @@ class ModelArgs:
     audio_num_codebooks: int
 
 
+def ragged_schedule(n_frames):
+    """Continuous-batching plan for fixed per-sequence frame counts: yields (step, active, keep) — run `step` frames with
+    the sequences `active` (original indices, in row order), then keep the rows at positions `keep` (in order) as rows
+    0..len(keep)-1.  Every sequence runs exactly n_frames[b] frames; a sequence leaves the batch the frame it finishes."""
+    active = list(range(len(n_frames)))
+    t_now = 0
+    while active:
+        step = min(int(n_frames[b]) for b in active) - t_now
+        t_now += step
+        keep = [r for r, b in enumerate(active) if int(n_frames[b]) > t_now]
+        yield step, list(active), keep
+        active = [active[r] for r in keep]
+
+
 class Model_stage3(nn.Module):
     """Stage 3: text-audio joint model (inference)."""
 
@@ -323,21 +337,15 @@ class Model_stage3(nn.Module):
         last_m = torch.stack([m[-1] for _, m in prompts]).to(dev)
         pos = torch.tensor([t.shape[0] - 1 for t, _ in prompts], device=dev)
         self.begin_decode(last_t.unsqueeze(1), last_m.unsqueeze(1), pos)
-        active = list(range(B))
         out = [[] for _ in range(B)]
-        t_now = 0
         max_pos = max(int(p) + int(n) for p, n in zip(pos.tolist(), n_frames)) + 1
-        while active:
+        for step, active, keep in ragged_schedule(n_frames):
             n_act = len(active)
-            step = min(int(n_frames[b]) for b in active) - t_now
             if step > 0:
                 log = self.generate_frames(step, n_act, mode, reason_eos, reason_card, max_pos=max_pos).clone()
                 for r, b in enumerate(active):
                     out[b].append(log[:, r])
-                t_now += step
-            keep = [r for r, b in enumerate(active) if int(n_frames[b]) > t_now]
             self.retire_rows(keep, n_act)
-            active = [active[r] for r in keep]
         return [torch.cat(o) if o else torch.zeros(0, st["ncb"] + 1, dtype=torch.int32, device=dev) for o in out]
 
     def begin_decode(self, tokens, tokens_mask, input_pos, forbid_prefix=0):
