@@ -126,9 +126,11 @@ def test_on_device_loop_equals_per_frame_api(golden, sd, dtype):
     assert torch.equal(a.int(), b.int())
     c = product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"]   # rerun: deterministic
     assert torch.equal(b, c)
+    # text loop: the on-device form skips the depth decoder (its samples are never fed back, asr_task.py:668-673):
+    # identical text ids, audio columns logged as zeros
     a = product_decode_loop(m, tokens[:1], mask[:1], 8, "text")["samples"]
     b = product_decode_loop(m, tokens[:1], mask[:1], 8, "text", fast=True)["samples"]
-    assert torch.equal(a.int(), b.int())
+    assert torch.equal(a.int()[:, :, 0], b.int()[:, :, 0]) and int(b[:, :, 1:].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -141,7 +141,7 @@ __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int re
   for (int m = threadIdx.x; m < R; m += blockDim.x) {
     const int32_t* own = out + (size_t)m * w;
     if (frame < log_frames)
-      for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = own[j];
+      for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = (audio_fb || j == 0) ? own[j] : 0;   // text loop: no audio ids exist
     // mode 2 (classifier-free-guidance pair, tts_task.py:256-258,278-280): every row continues from
     // the conditional row's sample
     const int32_t* o = (mode == 2) ? out : own;
@@ -254,7 +254,10 @@ extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
   return trunk_impl(h, R, false, (hipStream_t)stream);
 }
 
-extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
+// text_only: the text head and its sample only.  The on-device text loop (feedback mode 1, asr_task.py:668-682) feeds
+// back zeros for the audio streams, so what the depth decoder would sample is never read: skipping its 8 passes leaves
+// the text ids unchanged ("waste removal with identical outputs") and removes ~45 % of the frame.
+static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_batch, "ua2_stage3_heads: R=%d out of range", R);
   hipStream_t s = (hipStream_t)stream;
   const ua2_stage3_desc& d = h->d;
@@ -295,7 +298,7 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
   }
   if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
   const float* curr = h->hfin;
-  for (int i = 0; i < d.n_cb; ++i) {                               // model_new.py:630-641
+  for (int i = 0; i < (text_only ? 0 : d.n_cb); ++i) {             // model_new.py:630-641
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
@@ -329,6 +332,8 @@ extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) {
   return 0;
 }
 
+extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) { return heads_impl(h, R, false, stream); }
+
 extern "C" int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
                                    void* stream) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_rows && mode >= 0 && mode <= 2, "ua2_stage3_feedback: bad arguments");
@@ -346,7 +351,7 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
   hipStream_t s = (hipStream_t)stream;
   auto body = [&](hipStream_t st) -> int {
     if (int rc = trunk_impl(h, R, true, st)) return rc;
-    if (int rc = ua2_stage3_heads(h, R, st)) return rc;
+    if (int rc = heads_impl(h, R, mode == 1, st)) return rc;
     if (mode < 0) return 0;
     return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, st);
   };

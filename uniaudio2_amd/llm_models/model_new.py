@@ -257,7 +257,8 @@ class Model_stage3(nn.Module):
                         max_pos: Optional[int] = None, use_graph: bool = True) -> torch.Tensor:
         """Runs `n_frames` frames back to back from the state left by the previous frame (first
         call: after `begin_decode`).  mode 0 = audio feedback (evaluation/tts_task.py:259-280),
-        1 = text feedback (evaluation/asr_task.py:668-682).  Returns the log slice
+        1 = text feedback (evaluation/asr_task.py:668-682; the depth decoder is skipped there — its samples are
+        never fed back — so the audio columns of the log are zeros), 2 = guided pair.  Returns the log slice
         (n_frames, batch, 9) int32 (device)."""
         self._need()
         st = self._st
