@@ -9,7 +9,7 @@ from uniaudio2_amd import ops
 from uniaudio2_amd._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_CAST, PRO_NORM)
 
 dev = torch.device("cuda")
-L = 12
+L = int(os.environ.get("UA2_UBENCH_LAYERS", "12"))     # distinct weight sets in the chain (1 = the same weights every launch)
 dt = torch.bfloat16
 
 
