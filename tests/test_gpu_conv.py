@@ -84,3 +84,91 @@ def test_conv1d_pre_activation_repeat_and_pool():
     ref = F.conv1d(F.pad(torch.round(9 * x) / 9, (1, 1)), w)
     _close(ops.conv1d(x.cuda(), wp, 3, 64, pad_left=1, Tout=150, pre_act=ACT_ROUND9), ref)
     _close(ops.avgpool1d(x.cuda(), 2), F.avg_pool1d(x, 2), tol=1e-6)
+
+
+def test_streaming_convs_match_whole_sequence_reference_self_test():
+    """Port of the reference's own self-test (tools/tokenizer/MimiCodec/model/modules/streaming.py:306-358 `test()`):
+    RawStreamingConv1d / RawStreamingConvTranspose1d fed chunk by chunk inside `streaming()` reproduce their
+    whole-sequence outputs (relative L2 <= 1e-6) over the same grid of kernel sizes, strides, lengths and chunk sizes
+    (the 1043-sample case only with the two larger chunk sizes, to bound the launch count)."""
+    import itertools
+    from uniaudio2_amd.tools.tokenizer.MimiCodec.model.modules.streaming import RawStreamingConv1d, RawStreamingConvTranspose1d
+    torch.manual_seed(1234)
+    device = "cuda"
+    kernel_sizes = [1, 3, 4, 8, 15, 16]
+    strides = [1, 2, 3, 4, 5, 6, 7, 8, 9]
+    chin, chout = 6, 12
+    checked = 0
+    for kernel, stride in itertools.product(kernel_sizes, strides):
+        if stride > kernel:
+            continue
+        conv = RawStreamingConv1d(chin, chout, kernel, stride).to(device)
+        convtr = RawStreamingConvTranspose1d(chout, chin, kernel, stride).to(device)
+        for length in [4, 8, 32, 54, 65, 128, 1043]:
+            if length < kernel:
+                continue
+            batch_size = 3
+            x = torch.randn(batch_size, chin, length).to(device)
+            y = conv(x)
+            z = convtr(y)
+            # the whole-sequence results themselves against torch (exact-fp32 kernels vs MIOpen / rocBLAS order)
+            yt = torch.nn.functional.conv1d(x, conv.weight, conv.bias, stride=stride)
+            zt = torch.nn.functional.conv_transpose1d(yt, convtr.weight, convtr.bias, stride=stride)
+            assert (y - yt).norm() / yt.norm() <= 1e-5 and (z - zt).norm() / zt.norm() <= 1e-5
+            for chunk_size in ([5, 8] if length > 200 else [1, 3, 5, 8]):
+                ys, zs = [], []
+                with conv.streaming(batch_size), convtr.streaming(batch_size):
+                    for offset in range(0, length, chunk_size):
+                        chunk = x[..., offset:offset + chunk_size]
+                        ys.append(conv(chunk))
+                        zs.append(convtr(ys[-1]))
+                y_stream = torch.cat(ys, dim=-1)
+                z_stream = torch.cat(zs, dim=-1)
+                yy = y[..., :y_stream.shape[-1]]
+                zz = z[..., :z_stream.shape[-1]]
+                assert yy.shape == y_stream.shape, (yy.shape, y_stream.shape)
+                assert (y_stream - yy).norm() / yy.norm() <= 1e-6
+                assert int((length - kernel) / stride) + 1 == y_stream.shape[-1]
+                assert zz.shape == z_stream.shape, (zz.shape, z_stream.shape)
+                assert (z_stream - zz).norm() / zz.norm() <= 1e-6, (kernel, stride, length, chunk_size)
+                checked += 1
+            assert not conv.is_streaming and not convtr.is_streaming          # state dropped on exit
+    assert checked > 500
+
+
+def test_seanet_streaming_equals_whole_sequence():
+    """The causal SEANet decoder / encoder run frame by frame under `streaming()` (how low-latency decoding uses them,
+    SURVEY.md §8f rank 4) give the whole-sequence waveform / latent: conv.py:245-252 (left padding added once),
+    :306-329 (no trims while streaming) on top of the state machines above."""
+    from uniaudio2_amd.tools.tokenizer.MimiCodec.model.modules.seanet import SEANetDecoder, SEANetEncoder
+    import json
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    from make_golden_codec import SEANET_CFG, codec_state_dict
+    meta = json.load(open(os.path.join(here, "codec_toy.json")))
+    cfg = dict(SEANET_CFG)
+    dec, enc = SEANetDecoder(**cfg), SEANetEncoder(**cfg)
+    dec.load_state_dict(codec_state_dict({k: tuple(s) for k, s in meta["seanet_dec_keys"]}, 42))
+    enc.load_state_dict(codec_state_dict({k: tuple(s) for k, s in meta["seanet_enc_keys"]}, 41))
+    dec, enc = dec.cuda().eval(), enc.cuda().eval()
+    hop = dec.hop_length
+    z = torch.randn(2, cfg["dimension"], 12, device="cuda")
+    whole = dec(z)
+    outs = []
+    with dec.streaming(2):
+        for t in range(z.shape[-1]):
+            outs.append(dec(z[..., t:t + 1]))
+    stream = torch.cat(outs, dim=-1)
+    assert stream.shape[-1] == z.shape[-1] * hop
+    assert (stream - whole[..., :stream.shape[-1]]).norm() / whole.norm() <= 1e-5
+    wav = torch.randn(2, 1, hop * 10, device="cuda")
+    lat = enc(wav)
+    outs = []
+    with enc.streaming(2):
+        for t in range(0, wav.shape[-1], hop):
+            outs.append(enc(wav[..., t:t + hop]))
+    lat_s = torch.cat(outs, dim=-1)
+    assert lat_s.shape == lat.shape
+    assert (lat_s - lat).norm() / lat.norm() <= 1e-5

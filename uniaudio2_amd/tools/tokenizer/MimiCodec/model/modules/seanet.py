@@ -15,9 +15,10 @@ import torch.nn as nn
 from ...... import ops
 from ......_lib import ACT_ELU, ACT_NONE
 from .conv import StreamingConv1d, StreamingConvTranspose1d
+from .streaming import StreamingModule
 
 
-class SEANetResnetBlock(nn.Module):
+class SEANetResnetBlock(StreamingModule):
     def __init__(self, dim, kernel_sizes=(3, 1), dilations=(1, 1), activation="ELU", activation_params=None, norm="none",
                  norm_params=None, causal=False, pad_mode="constant", compress=2, true_skip=True):
         super().__init__()
@@ -62,7 +63,7 @@ def _run_sequential(model, x):
     return x
 
 
-class SEANetEncoder(nn.Module):
+class SEANetEncoder(StreamingModule):
     def __init__(self, channels=1, dimension=128, n_filters=32, n_residual_layers=3, ratios=(8, 5, 4, 2), activation="ELU",
                  activation_params=None, norm="none", norm_params=None, kernel_size=7, last_kernel_size=7,
                  residual_kernel_size=3, dilation_base=2, causal=False, pad_mode="constant", true_skip=True, compress=2,
@@ -89,7 +90,7 @@ class SEANetEncoder(nn.Module):
         return _run_sequential(self.model, x.float().contiguous())
 
 
-class SEANetDecoder(nn.Module):
+class SEANetDecoder(StreamingModule):
     def __init__(self, channels=1, dimension=128, n_filters=32, n_residual_layers=3, ratios=(8, 5, 4, 2), activation="ELU",
                  activation_params=None, final_activation=None, final_activation_params=None, norm="none", norm_params=None,
                  kernel_size=7, last_kernel_size=7, residual_kernel_size=3, dilation_base=2, causal=False, pad_mode="constant",
