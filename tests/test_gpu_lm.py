@@ -291,3 +291,23 @@ def test_model_topk_sampling_runs_and_is_reproducible(golden, sd):
     # same seed but the draw index keeps counting across utterances (like torch's global generator): streams differ
     assert not torch.equal(a, b)
     m.reset_caches()
+
+
+def test_multinomial_reference_self_test_distribution():
+    """The reference's second self-test (llm_utils/sampling.py:156-174): draws from ps = [5, 2, 12, 6, 8, 1, 0, 4] must
+    match ps / sum(ps) within 1.5e-2 — here through ua2_sample_topk with the whole support kept (logits = log ps, the
+    zero-probability class at -inf is never drawn) over 4000 independent rows instead of 1000 sequential draws."""
+    import ctypes as C
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import check, lib
+    ps = torch.tensor([5.0, 2.0, 12.0, 6.0, 8.0, 1.0, 0.0, 4.0])
+    V, M = ps.numel(), 4000
+    logits = torch.log(ps).unsqueeze(0).repeat(M, 1).contiguous().cuda()
+    out = torch.zeros(M, 1, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    check(lib.ua2_sample_topk(1, M, logits.data_ptr(), V, V, V, C.c_float(1.0), None, 1234, counter.data_ptr(), 0,
+                              out.data_ptr(), 1, 0, None, 0, 0, None, ops.stream()), "ua2_sample_topk")
+    cnts = torch.bincount(out[:, 0].cpu().long(), minlength=V).float()
+    assert cnts[6] == 0
+    diff = cnts / cnts.sum() - ps / ps.sum()
+    assert float(diff.abs().max()) < 1.5e-2, diff
