@@ -128,7 +128,24 @@ def codec_leg(dev):
                      upsample_kernel_sizes=[6, 10, 8, 8, 4], latent_hidden_dim=136, default_kernel_size=7,
                      delay_kernel_size=5, init_channel=32, res_kernel_size=7).to(dev).prepare()
     lat = torch.tanh(torch.randn(1, 136, 500, device=dev))
-    wav = sq.decode(lat)
+    # algorithmic work of one decode: every ua2_conv1d launch's 2 * B * Cout * Tout * Cin * K flops and its
+    # activation + weight bytes (counted by wrapping the op for one call)
+    work = {"flop": 0.0, "bytes": 0.0, "launches": 0}
+    real_conv1d = ops.conv1d
+
+    def counting_conv1d(x, w_packed, K, Cout, **kw):
+        y = real_conv1d(x, w_packed, K, Cout, **kw)
+        B_, Cin, Tin = x.shape
+        work["flop"] += 2.0 * B_ * Cout * y.shape[-1] * Cin * K
+        work["bytes"] += 4.0 * (x.numel() + y.numel() + (y.numel() if kw.get("residual") is not None else 0)) + 4.0 * w_packed.numel()
+        work["launches"] += 1
+        return y
+
+    ops.conv1d = counting_conv1d
+    try:
+        wav = sq.decode(lat)
+    finally:
+        ops.conv1d = real_conv1d
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -145,6 +162,11 @@ def codec_leg(dev):
         ops.rvq_encode(x, emb, embT)
     e1.record(); torch.cuda.synchronize()
     return {"scalar_decode_ms_per_20s_window": round(dec_ms, 3), "scalar_decode_rtf": round(dec_ms / 1e3 / (wav.shape[-1] / 24000.0), 6),
+            # exact-fp32 implicit GEMM on v_mfma_f32_16x16x4_f32: dense f32 MFMA peak = 1/16 of the bf16 one (2.5 PFLOP/s / 16)
+            "scalar_decode_conv_launches": work["launches"], "scalar_decode_gflop": round(work["flop"] / 1e9, 2),
+            "scalar_decode_tflops": round(work["flop"] / (dec_ms * 1e-3) / 1e12, 2),
+            "scalar_decode_frac_f32_mfma_peak": round(work["flop"] / (dec_ms * 1e-3) / (2.5e15 / 16), 4),
+            "scalar_decode_algorithmic_GBps": round(work["bytes"] / (dec_ms * 1e-3) / 1e9, 1),
             "rvq_encode_us_125x6x8192x32": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "config": "placeholder init_channel=32, hop 960"}
 
 

@@ -19,8 +19,9 @@
 //   transposed conv with stride P: P phase-convolutions, packed rows n = phase*Cout + co, written to
 //   y[co][t*P + phase - out_trim_left]  (the taps of a phase are W[ci][co][phase + m*P], m descending).
 //
-// Tiling: workgroup = 4 waves = 64 output rows x 64 time steps; wave w owns rows 16w..16w+15 and four
-// 16-wide time tiles (4 accumulators).  Input channels are consumed 16 at a time: their window
+// Tiling: workgroup = 4 waves = 64 output rows x 16*NTT time steps (NTT = 4, 2 or 1: the launcher shrinks the time
+// tile until the grid has >= 2 workgroups per CU — the 512-channel layers at 12.5 / 50 Hz have few time steps and ran
+// at 15 % of the f32 MFMA peak on 192 workgroups); wave w owns rows 16w..16w+15 and NTT 16-wide time tiles.  Input channels are consumed 16 at a time: their window
 // (zero-padded, pre-activated) is staged once in LDS and feeds K chunks of 16 reduction indices; the
 // weight fragments come pre-tiled (ua2_pack_linear fp32 layout over [rows][Cin_pad*K]) as one 16-byte
 // load per lane per chunk, reused by the 16 MFMAs of the four time tiles.
@@ -28,7 +29,6 @@
 
 namespace {
 
-constexpr int kBT = 64;       // time steps per workgroup
 constexpr int kBR = 64;       // output rows per workgroup
 constexpr int kCIG = 16;      // input channels per staging group
 constexpr int kMaxK = 32;
@@ -43,7 +43,9 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   }
 }
 
+template <int NTT>
 __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
+  constexpr int kBT = 16 * NTT;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = a.K, s = a.stride, d = a.dilation;
   const int W = (kBT - 1) * s + (K - 1) * d + 1;       // staged window per input channel
@@ -62,9 +64,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
 
   for (int kk = tid; kk < kCIG * K; kk += 256) koff[kk] = (kk / K) * Wp + (kk % K) * d;
 
-  f32x4 acc[4];
+  f32x4 acc[NTT];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool wave_active = r0 < rows;
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.w) + (size_t)(r0 / 16) * nchunks * 64 + lane;
   const float pre_alpha = (a.pre_act == UA2_ACT_PRELU && a.pre_alpha) ? a.pre_alpha[0] : 0.f;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
         const int4 ko = *reinterpret_cast<const int4*>(&koff[c * 16 + g * 4]);
         const int kov[4] = {ko.x, ko.y, ko.z, ko.w};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NTT; ++nt) {
           const int tb = (nt * 16 + tl) * s;
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xs[kov[e] + tb], acc[nt], 0, 0, 0);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
     const float bias = a.bias ? a.bias[co] : 0.f;
     const float alpha = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? co : 0] : 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NTT; ++nt) {
       const int t = t0 + nt * 16 + tl;
       const int to = t * a.out_phases + phase - a.out_trim_left;
       if (to < 0 || to >= a.Tout) continue;
@@ -183,17 +185,26 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
             "ua2_conv1d: bad geometry K=%d stride=%d dil=%d", a->K, a->stride, a->dilation);
   UA2_CHECK(a->out_phases == 1 || (a->stride == 1 && a->dilation == 1), "ua2_conv1d: phase mode needs stride=dilation=1");
   UA2_CHECK(a->post_act != UA2_ACT_PRELU || a->post_alpha, "ua2_conv1d: PReLU needs post_alpha");
-  const int W = (kBT - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+  const int tq = a->out_phases == 1 ? a->Tout : ua2_ceil_div(a->Tout + a->out_trim_left, a->out_phases);
+  const int row_blocks = ua2_ceil_div((int64_t)a->Cout * a->out_phases, kBR);
+  // largest time tile that still gives >= 512 workgroups (2 per CU); never below 16 steps
+  int ntt = 4;
+  while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt) * row_blocks * a->B < 512) ntt >>= 1;
+  const int bt = 16 * ntt;
+  const int W = (bt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
   const size_t smem = (size_t)kCIG * (W + 1) * sizeof(float) + (size_t)kCIG * a->K * sizeof(int);
   UA2_CHECK(smem <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const int tq = a->out_phases == 1 ? a->Tout : ua2_ceil_div(a->Tout + a->out_trim_left, a->out_phases);
-  const dim3 grid(ua2_ceil_div(tq, kBT), ua2_ceil_div((int64_t)a->Cout * a->out_phases, kBR), a->B);
-  hipLaunchKernelGGL(conv1d_kernel, grid, dim3(256), smem, (hipStream_t)stream, *a);
+  const dim3 grid(ua2_ceil_div(tq, bt), row_blocks, a->B);
+  if (ntt == 4) hipLaunchKernelGGL(conv1d_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, *a);
+  else if (ntt == 2) hipLaunchKernelGGL(conv1d_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(conv1d_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, *a);
   UA2_LAUNCH_CHECK();
   return 0;
 }
