@@ -11,7 +11,8 @@
 //
 // MI355X mapping: the search is an HBM/L2-bound scan of a small codebook (8192 x 32 fp32 = 1 MiB per
 // level) — not a GEMM: expanding |x-e|^2 into x.e products to reach MFMA would change the rounding
-// and lose bit-exactness.  A workgroup owns VB vectors (residuals in LDS); each lane owns codewords
+// and lose bit-exactness.  A workgroup owns VB vectors (8, 2 or 1: the launcher picks the largest that still gives
+// >= 256 workgroups — one 10-s clip is only 125 vectors and ran on 16 CUs with VB = 8; residuals in LDS); each lane owns codewords
 // c, c+256, ... and walks k with coalesced loads from the k-major codebook copy ([L][D][C]: 64 lanes
 // read 64 consecutive codewords of one k), reusing every loaded value for the VB vectors; the
 // arg-min is a wavefront shuffle reduction on (distance, index) pairs, then one LDS hop across the
@@ -20,13 +21,13 @@
 
 namespace {
 
-constexpr int kVB = 8;       // vectors per workgroup
 constexpr int kThreads = 256;
 
 __device__ __forceinline__ void argmin_pair(float& v, int& i, float ov, int oi) {
   if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
+template <int kVB>
 __global__ __launch_bounds__(kThreads) void rvq_encode_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                               const float* __restrict__ embT, int64_t N, int L, int C,
                                                               int D, int32_t* __restrict__ codes,
@@ -114,11 +115,15 @@ __global__ void rvq_decode_kernel(const int32_t* __restrict__ codes, const float
 extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C,
                               int32_t D, int32_t* codes, float* quantized, void* stream) {
   UA2_CHECK(x && emb && embT && codes && N > 0 && L > 0 && C > 0 && D > 0 && D <= 1024, "ua2_rvq_encode: bad arguments");
-  const size_t smem = (size_t)(2 * kVB * D + 4 * kVB) * sizeof(float) + (size_t)(4 * kVB + kVB) * sizeof(int);
+  int vb = 8;
+  while (vb > 1 && (N + vb - 1) / vb < 256) vb = vb == 8 ? 2 : 1;
+  const size_t smem = (size_t)(2 * vb * D + 4 * vb) * sizeof(float) + (size_t)(4 * vb + vb) * sizeof(int);
   UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
-  const int blocks = (int)((N + kVB - 1) / kVB);
-  hipLaunchKernelGGL(rvq_encode_kernel, dim3(blocks), dim3(kThreads), smem, (hipStream_t)stream, x, emb, embT, N, L, C, D,
-                     codes, quantized);
+  const int blocks = (int)((N + vb - 1) / vb);
+  hipStream_t s = (hipStream_t)stream;
+  if (vb == 8) hipLaunchKernelGGL(rvq_encode_kernel<8>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
+  else if (vb == 2) hipLaunchKernelGGL(rvq_encode_kernel<2>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
+  else hipLaunchKernelGGL(rvq_encode_kernel<1>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
   UA2_LAUNCH_CHECK();
   return 0;
 }
