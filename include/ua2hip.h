@@ -132,6 +132,13 @@ typedef struct ua2_linear_args {
                              bit-identical with or without it; without it M > 16 streams the weights once per
                              16-row tile. */
   size_t workspace_bytes;
+  /* Producer / consumer hand-over of the many-row operand, skipping the consumer's prep launch:
+     y_packed (UA2_EPI_SWIGLU; N % chunk == 0): the result, rounded to `dtype`, also (or, with y == NULL, only) in the
+       packed operand layout [ceil(M/16)][N/KC][64 lanes][16 B] of a following K = N launch;
+     x_packed (UA2_PRO_CAST, M spanning more than one row tile): the operand already in that layout (K = this launch's K).
+     Same bits as the unpacked route: the packed value is the same RNE cast the prep launch applies. */
+  void* y_packed;
+  const void* x_packed;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
@@ -170,6 +177,9 @@ typedef struct ua2_attn_args {
                              output [R, n_head*head_size]; attn_o / attn_ml / grid_pages are unused */
   int32_t window;         /* single-pass mode: > 0 = attend only to the last `window` positions (Moshi `context`,
                              transformer.py:405-406: delta < context); 0 = all positions <= row_pos */
+  void* y_packed;         /* single-pass mode / ua2_attn_local, optional: the output rounded to `dtype` in the packed
+                             operand layout of the O-projection (ua2_linear_args.x_packed), K = n_head*head_size;
+                             y may then be NULL */
 } ua2_attn_args;
 
 int ua2_attn(const ua2_attn_args* a, void* stream);

@@ -38,12 +38,12 @@ class LinearArgs(C.Structure):
                 ("part_max", vp), ("part_idx", vp), ("forbid", vp), ("row_pos", vp), ("row_seq", vp),
                 ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom),
                 ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32),
-                ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+                ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("attn_o", vp),
-                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp), ("window", i32)]
+                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp), ("window", i32), ("y_packed", vp)]
 
 
 class Conv1dArgs(C.Structure):

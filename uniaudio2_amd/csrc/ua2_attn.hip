@@ -381,7 +381,8 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
     float acc = 0.f;
 #pragma unroll 8
     for (int w = 0; w < NS; ++w) acc += wgt[w * kMaxG + h] * st_o[((size_t)w * G + h) * HS + d];
-    a.y[((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + d] = acc;
+    if (a.y) a.y[((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + d] = acc;
+    if (a.y_packed) store_packed_operand<DT>(a.y_packed, r, (kvh * G + h) * HS + d, a.kv.n_head * HS / Elem<DT>::KC, acc);
   }
 }
 
@@ -427,7 +428,11 @@ __global__ __launch_bounds__(1024) void attn_local_kernel(const ua2_attn_args a)
     LA la;
     la.issue(a.kv, q_row, page, h, d);
     const float2 o = la.finish(pos);
-    *reinterpret_cast<float2*>(a.y + (size_t)r * a.kv.n_head * HS + (size_t)h * HS + d) = o;
+    if (a.y) *reinterpret_cast<float2*>(a.y + (size_t)r * a.kv.n_head * HS + (size_t)h * HS + d) = o;
+    if (a.y_packed) {
+      store_packed_operand<DT>(a.y_packed, r, h * HS + d, a.kv.n_head * HS / Elem<DT>::KC, o.x);
+      store_packed_operand<DT>(a.y_packed, r, h * HS + d + 1, a.kv.n_head * HS / Elem<DT>::KC, o.y);
+    }
   }
 }
 
@@ -467,13 +472,14 @@ int launch_hs(const ua2_attn_args& a, hipStream_t s) {
 
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
   UA2_CHECK(a.R > 0, "ua2_attn: R=%d", a.R);
-  UA2_CHECK(a.q && a.row_pos && (a.y || (a.attn_o && a.attn_ml)) && a.kv.k_pool && a.kv.v_pool &&
+  UA2_CHECK(a.q && a.row_pos && (a.y || a.y_packed || (a.attn_o && a.attn_ml)) && a.kv.k_pool && a.kv.v_pool &&
                 a.kv.page_table,
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
-  UA2_CHECK(a.y || a.grid_pages <= a.kv.max_pages, "ua2_attn: grid_pages > max_pages");
-  if (a.y) {
+  UA2_CHECK(a.y || a.y_packed || a.grid_pages <= a.kv.max_pages, "ua2_attn: grid_pages > max_pages");
+  UA2_CHECK(!a.y_packed || (a.kv.n_head * a.kv.head_size) % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_attn: y_packed needs n_head*head_size %% chunk == 0");
+  if (a.y || a.y_packed) {
     if (a.dtype == UA2_BF16) return launch_fused<UA2_BF16>(a, s);
     if (a.dtype == UA2_F32) return launch_fused<UA2_F32>(a, s);
   }
@@ -484,7 +490,7 @@ int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
 }
 
 int ua2_attn_local_launch(const ua2_attn_args& a, hipStream_t s) {
-  UA2_CHECK(a.R > 0 && a.q && a.row_pos && a.y && a.kv.k_pool && a.kv.v_pool && a.kv.page_table, "ua2_attn_local: bad arguments");
+  UA2_CHECK(a.R > 0 && a.q && a.row_pos && (a.y || a.y_packed) && a.kv.k_pool && a.kv.v_pool && a.kv.page_table, "ua2_attn_local: bad arguments");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head % (128 / std::max(a.kv.head_size, 1)) == 0,
             "ua2_attn_local: n_head=%d n_kv=%d head_size=%d not supported", a.kv.n_head, a.kv.n_kv, a.kv.head_size);
   if (a.dtype == UA2_BF16) return launch_local<UA2_BF16>(a, s);

@@ -74,12 +74,22 @@ template <> __device__ __forceinline__ void store_elem<UA2_BF16>(void* p, size_t
   ((unsigned short*)p)[i] = f2bf(v);
 }
 
+// element (row m, column k) of an [M, K] operand in MFMA fragment order [M/16][K/KC][64 lanes][16 B]
+template <int DT>
+__device__ __forceinline__ void store_packed_operand(void* base, int m, int k, int nchunks, float v) {
+  constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL;
+  const int c = k / KC, r = k - c * KC, g = r / EPL, e = r - g * EPL;
+  const size_t elem = (((size_t)(m >> 4) * nchunks + c) * 64 + g * 16 + (m & 15)) * EPL + e;
+  store_elem<DT>(base, elem, v);
+}
+
 static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // internal launchers used by both the op-level ABI and the frame executor
 int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s);
 int ua2_attn_local_launch(const ua2_attn_args& a, hipStream_t s);
+int ua2_gemv_rows_per_tile(int dtype, int K);   // rows one decode-kernel workgroup holds in LDS (ua2_gemv.hip)
 extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
                                const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
                                int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,

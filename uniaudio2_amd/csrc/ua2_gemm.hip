@@ -372,7 +372,7 @@ void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t 
   }
   const size_t smem = (size_t)geo.waves * NT * kSkinnyMT * 256 * sizeof(float);
   const dim3 grid(ua2_ceil_div(a.N, 16), ua2_ceil_div(ua2_ceil_div(a.M, 16), kSkinnyMT));
-  hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.workspace));
+  hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace));
 }
 
 template <int DT, int PRO>
@@ -386,7 +386,7 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   constexpr int BNT = 2 * (4 / NT);
   const int mblocks = ua2_ceil_div(ua2_ceil_div(a.M, 16), kBMT), nblocks = ua2_ceil_div(ua2_ceil_div(a.N, 16), BNT);
   hipLaunchKernelGGL((gemm_kernel<DT, EPI>), dim3(mblocks * nblocks), dim3(256), 0, s, a,
-                     reinterpret_cast<const u32x4*>(a.workspace), nw, mblocks, nblocks);
+                     reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), nw, mblocks, nblocks);
 }
 
 // Which of the two forms is faster — both give the same bits, so this is purely a cost model, fitted on
@@ -412,8 +412,13 @@ template <int DT>
 int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
   const int nt = a.epilogue == UA2_EPI_SWIGLU ? 2 : 1;
   const ua2_gemv_geometry geo = ua2_pick_gemv_geometry(a.dtype, a.N, a.K, nt);
-  if (a.prologue == UA2_PRO_NORM) launch_prep<DT, UA2_PRO_NORM>(a, geo.waves * 64, s);
-  else launch_prep<DT, UA2_PRO_CAST>(a, geo.waves * 64, s);
+  if (a.x_packed) {
+    // the producer already wrote the operand in fragment order
+  } else if (a.prologue == UA2_PRO_NORM) {
+    launch_prep<DT, UA2_PRO_NORM>(a, geo.waves * 64, s);
+  } else {
+    launch_prep<DT, UA2_PRO_CAST>(a, geo.waves * 64, s);
+  }
   UA2_LAUNCH_CHECK();
   const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
   if (skinny_ok && (force == 4 || (force != 5 && choose_skinny(a, nt)))) {
@@ -450,7 +455,7 @@ extern "C" size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K) {
 
 int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force) {
   if (a.prologue != UA2_PRO_CAST && a.prologue != UA2_PRO_NORM) return 1;
-  if (!a.workspace || a.workspace_bytes < ua2_linear_workspace_bytes(a.dtype, a.M, a.K)) return 1;
+  if (!a.x_packed && (!a.workspace || a.workspace_bytes < ua2_linear_workspace_bytes(a.dtype, a.M, a.K))) return 1;
   const int rt = ua2_gemv_rows_per_tile(a.dtype, a.K);
   if (rt < 1) return 1;                          // the decode kernel cannot take this K at all: nothing to be identical with
   if (!force && a.M <= rt) return 1;             // one row tile: the decode kernel (operand rows live in LDS)

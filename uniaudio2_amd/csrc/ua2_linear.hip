@@ -287,6 +287,12 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     UA2_CHECK(rc <= 0, "ua2_linear: LOCAL_ATTN problem outside the decode kernel's range");
     return rc;
   }
+  if (a.x_packed) {   // operand handed over in fragment order by its producer: only the many-row kernels read it
+    UA2_CHECK(a.prologue == UA2_PRO_CAST && g_force_general != 1 && g_force_general != 2, "ua2_linear: x_packed needs PRO_CAST and the many-row kernels");
+    const int rc = ua2_gemm_try_launch(a, s, 3);
+    UA2_CHECK(rc <= 0, "ua2_linear: x_packed launch not applicable");
+    return rc;
+  }
   if (a.prologue != UA2_PRO_ATTN) {
     UA2_CHECK(a.x != nullptr && a.ldx % 4 == 0, "ua2_linear: x NULL or ldx %% 4 != 0");
   } else {
@@ -298,7 +304,12 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     UA2_CHECK(a.norm_w != nullptr && (a.norm_kind != UA2_NORM_LAYERNORM || a.norm_b != nullptr) && a.norm_kind >= 0 && a.norm_kind <= 2,
               "ua2_linear: norm_w / norm_b / norm_kind invalid");
   if (a.epilogue == UA2_EPI_GELU) UA2_CHECK(a.y != nullptr, "ua2_linear: GELU needs y");
-  if (a.epilogue == UA2_EPI_SWIGLU) UA2_CHECK(a.w1 != nullptr && a.y != nullptr, "ua2_linear: SWIGLU needs w1, y");
+  if (a.epilogue == UA2_EPI_SWIGLU) {
+    UA2_CHECK(a.w1 != nullptr && (a.y != nullptr || a.y_packed != nullptr), "ua2_linear: SWIGLU needs w1 and y or y_packed");
+    UA2_CHECK(!a.y_packed || a.N % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_linear: y_packed needs N %% chunk == 0");
+  } else {
+    UA2_CHECK(!a.y_packed, "ua2_linear: y_packed is a SWIGLU output");
+  }
   if (a.epilogue == UA2_EPI_RESIDUAL) UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
   if (a.epilogue == UA2_EPI_STORE) UA2_CHECK(a.y != nullptr || a.part_max != nullptr, "ua2_linear: STORE needs y or part_max");
   if (a.epilogue == UA2_EPI_QKV_ROPE) {

@@ -172,7 +172,9 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
     if (rvalid && n < a.N) {
       const float gte = v[0];
       const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
-      a.y[(size_t)mr * a.ldy + n] = __fmul_rn(sg, v[1]);
+      const float out = __fmul_rn(sg, v[1]);
+      if (a.y) a.y[(size_t)mr * a.ldy + n] = out;
+      if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, out);
     }
   } else if constexpr (EPI == UA2_EPI_GELU) {
     const int n = tile[0] * 16 + col;

@@ -28,6 +28,7 @@ struct ua2_stage3 {
   int32_t *pidx_t, *pidx_a;
   void* gemm_ws;               // operand scratch of the large-M linear kernel (max_rows x widest K)
   size_t gemm_ws_bytes;
+  void* act_ws;                // packed SwiGLU output handed straight to the down-projection (max_rows x widest intermediate)
   int32_t npart_t, npart_a;
   int32_t grid_pages;
   int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
@@ -48,7 +49,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -70,6 +71,7 @@ Carve carve(const ua2_stage3_desc& d) {
   c.pmax_t = take(Bm * npt); c.pidx_t = take(Bm * npt); c.pmax_a = take(Bm * npa); c.pidx_a = take(Bm * npa);
   c.gemm_ws_floats = ua2_linear_workspace_bytes(d.dtype, (int64_t)R, (int64_t)std::max(std::max(C, Cd), std::max(qmax, actmax))) / sizeof(float);
   c.gemm_ws = take(c.gemm_ws_floats);
+  c.act_ws = take(ua2_linear_workspace_bytes(d.dtype, (int64_t)R, (int64_t)actmax) / sizeof(float));
   c.total = off;
   return c;
 }
@@ -101,10 +103,17 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
 
     static const bool no_fuse = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
     const bool fuse_attn = local && R == 1 && !no_fuse;
+    // more than one row tile: the consumer runs a many-row kernel, so its producer writes the packed operand
+    // directly and the consumer's prep launch disappears (same bits: the same RNE cast either way)
+    static const bool no_handover = getenv("UA2_NO_PACKED_HANDOVER") != nullptr;   // A/B hook
+    const int kc = dt == UA2_BF16 ? 32 : 16;
+    const bool pack_o = !no_handover && R > ua2_gemv_rows_per_tile(dt, qn) && qn % kc == 0;
+    const bool pack_act = !no_handover && R > ua2_gemv_rows_per_tile(dt, g.inter) && g.inter % kc == 0;
     if (!fuse_attn) {
       ua2_attn_args at;
       memset(&at, 0, sizeof(at));
-      at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.y = h->yattn; at.kv = kv;
+      at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.kv = kv;
+      if (pack_o) at.y_packed = h->gemm_ws; else at.y = h->yattn;
       if (int rc = local ? ua2_attn_local_launch(at, s) : ua2_attn_launch(at, s)) return rc;
     }
     fresh_args(h, a);
@@ -112,18 +121,21 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = C; a.K = qn; a.x = fuse_attn ? h->q : h->yattn; a.ldx = qn;
     a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (fuse_attn) { a.row_pos = row_pos; a.row_seq = row_seq; a.kv = kv; }
+    if (pack_o && !fuse_attn) a.x_packed = h->gemm_ws;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_SWIGLU;
     a.M = R; a.N = g.inter; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][1][l]; a.eps = g.eps;
-    a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.y = h->act; a.ldy = g.inter;
+    a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.ldy = g.inter;
+    if (pack_act) a.y_packed = h->act_ws; else a.y = h->act;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_RESIDUAL;
     a.M = R; a.N = C; a.K = g.inter; a.x = h->act; a.ldx = g.inter; a.w0 = h->ptrs[gi][4][l];
     a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
+    if (pack_act) a.x_packed = h->act_ws;
     if (int rc = ua2_linear_launch(a, s)) return rc;
   }
   return 0;
@@ -194,6 +206,7 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->audio_logits = b + c.audio_logits; h->pmax_t = b + c.pmax_t; h->pidx_t = (int32_t*)(b + c.pidx_t);
   h->pmax_a = b + c.pmax_a; h->pidx_a = (int32_t*)(b + c.pidx_a);
   h->gemm_ws = b + c.gemm_ws; h->gemm_ws_bytes = c.gemm_ws_floats * sizeof(float);
+  h->act_ws = b + c.act_ws;
   h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
   h->grid_pages = d->backbone.max_pages;
   *out = h;
