@@ -22,6 +22,8 @@ from weights import seeded_tensor
 
 MIMI = dict(d_model=64, num_heads=2, num_layers=2, dim_feedforward=128, causal=True, context=20, positional_embedding="rope",
             max_period=10000, norm="layer_norm", layer_scale=0.01, gating="none")
+SIN = dict(d_model=64, num_heads=2, num_layers=1, dim_feedforward=128, causal=True, context=None, positional_embedding="sin_rope",
+           max_period=10000, positional_scale=0.5, norm="layer_norm", gating="none")
 DEP = dict(d_model=64, num_heads=2, num_layers=2, dim_feedforward=96, causal=True, context=None, positional_embedding="none",
            norm="rms_norm_f32", gating="silu", weights_per_step=4)
 
@@ -45,7 +47,7 @@ def moshi_state_dict(shapes, seed):
 def main():
     from tools.tokenizer.MimiCodec.model.modules.transformer import StreamingTransformer
     out, meta = {}, {}
-    for name, cfg, T, seed in (("mimi", MIMI, 50, 51), ("dep", DEP, 4, 52)):
+    for name, cfg, T, seed in (("mimi", MIMI, 50, 51), ("dep", DEP, 4, 52), ("sin", SIN, 20, 53)):
         m = StreamingTransformer(**cfg).eval()
         shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         m.load_state_dict(moshi_state_dict(shapes, seed))

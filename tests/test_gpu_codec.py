@@ -130,3 +130,40 @@ def test_mimicodec_encode_decode_vs_reference():
     assert rec.shape == ref.shape
     rms = ((rec - ref) ** 2).mean().sqrt().item()
     assert rms < 1e-4, rms
+
+
+def test_mimicodec_streaming_decode_and_encode_equal_whole_sequence():
+    """Low-latency use: inside `with model.streaming(B):` MimiCodec decodes one code frame at a
+    time (RVQ lookup -> streaming channel-wise up-sampler -> transformer with its own offset -> streaming SEANet) and
+    encodes one down-sampler stride of audio at a time; both equal the whole-sequence results."""
+    import json
+    import os
+    from weights import mimi_state_dict, seeded_tensor
+    from uniaudio2_amd.tools.tokenizer.MimiCodec.model.models.MimiCodec import MimiCodec
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    meta = json.load(open(os.path.join(here, "mimi_toy.json")))
+    g = np.load(os.path.join(here, "mimi_toy.npz"))
+    m = MimiCodec(**meta["config"])
+    m.load_state_dict(mimi_state_dict({k: tuple(s) for k, s in meta["keys"]}, 77))
+    m = m.to("cuda").eval()
+    codes = torch.from_numpy(g["codes"]).cuda()
+    whole = m.decode(codes)
+    outs = []
+    with m.streaming(2):
+        for t in range(codes.shape[-1]):
+            outs.append(m.decode(codes[..., t:t + 1].contiguous()))
+    stream = torch.cat(outs, dim=-1)
+    assert stream.shape[-1] == codes.shape[-1] * 2 * m.hop_length
+    ref = whole[..., :stream.shape[-1]]
+    assert ((stream - ref) ** 2).mean().sqrt().item() < 1e-4 * max(1.0, (ref ** 2).mean().sqrt().item())
+    assert ((stream - torch.from_numpy(g["rec"]).cuda()[..., :stream.shape[-1]]) ** 2).mean().sqrt().item() < 2e-4
+    wav = seeded_tensor((2, 1, 640), 4321, std=0.3).cuda()
+    whole_codes = m.encode(wav)
+    step = 2 * m.hop_length
+    parts = []
+    with m.streaming(2):
+        for t in range(0, wav.shape[-1], step):
+            parts.append(m.encode(wav[..., t:t + step].contiguous()))
+    sc = torch.cat(parts, dim=-1)
+    assert sc.shape == whole_codes.shape
+    assert (sc == whole_codes).float().mean().item() > 0.98

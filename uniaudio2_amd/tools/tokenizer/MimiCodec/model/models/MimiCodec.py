@@ -6,6 +6,8 @@ quantizer) and therefore the same checkpoint keys:
   encode :92-100  wav (B,1,T) -> SEANetEncoder -> ProjectedTransformer -> ConvDownsample1d -> SplitRVQ codes (B,K,T')
   decode :102-109 codes -> SplitRVQ.decode -> ConvTrUpsample1d (channel-wise) -> ProjectedTransformer -> SEANetDecoder
 forward :73-90 (training: random quantisation mask, semantic distillation) is out of scope.
+`with model.streaming(batch):` runs encode / decode chunk by chunk (causal convs keep their tails, the transformers
+their position and cache), equal to the whole-sequence result.
 Every arithmetic op runs in libua2hip.so (ua2_conv1d / ua2_dwconv1d / ua2_linear / ua2_attn / ua2_rvq_*).
 """
 import json
@@ -16,6 +18,7 @@ import torch.nn as nn
 from ..modules import transformer as Stransformer
 from ..modules.resample import ConvDownsample1d, ConvTrUpsample1d
 from ..modules.seanet import SEANetDecoder, SEANetEncoder
+from ..modules.streaming import StreamingModule
 from ..quantization.vq import SplitResidualVectorQuantizer
 
 
@@ -28,7 +31,7 @@ class Semantic_linear_pool(nn.Module):
         self.pl = nn.AvgPool1d(kernel_size=8, stride=4)
 
 
-class MimiCodec(nn.Module):
+class MimiCodec(StreamingModule):
     def __init__(self, sample_rate=24000, n_filters=64, encoder_rates=[4, 5, 6, 8], compress=2, causal=True, latent_dim=512,
                  codebook_size=4096, codebook_dim=32, rvq_layers=8, num_heads=8, num_layers=8, layer_scale=0.01, context=250,
                  dim_feedforward=2048, semantic_feature_dim=1024, target_frame_rate=12.5):

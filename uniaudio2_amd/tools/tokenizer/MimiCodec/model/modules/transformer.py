@@ -33,6 +33,8 @@ from ...... import ops
 from ......_lib import (EPI_GELU, EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, NORM_LAYERNORM, NORM_RMS_MOSHI,
                         PRO_CAST, PRO_NORM, ROPE_INTERLEAVED, ROPE_NONE, UA2_PAGE)
 
+from .streaming import StreamingModule
+
 
 class RMSNorm(nn.Module):
     def __init__(self, dim, eps=1e-5, dtype=None, device=None):
@@ -123,23 +125,39 @@ def rope_tables(max_pos, head_dim, max_period):
     return torch.cos(freqs * ts), torch.sin(freqs * ts)
 
 
-class StreamingTransformer(nn.Module):
+def create_sin_embedding(positions, dim, max_period=10000.0, dtype=torch.float32):
+    """transformer.py:127-152: [cos(p / max_period^(i/(half-1))) , sin(...)], i < dim / 2.  Table arithmetic, kept in torch."""
+    assert dim % 2 == 0
+    half_dim = dim // 2
+    positions = positions.to(dtype)
+    adim = torch.arange(half_dim, device=positions.device, dtype=dtype).view(1, 1, -1)
+    max_period_tensor = torch.full([], max_period, device=positions.device, dtype=dtype)
+    phase = positions / (max_period_tensor ** (adim / (half_dim - 1)))
+    return torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1)
+
+
+class StreamingTransformer(StreamingModule):
     def __init__(self, d_model, num_heads, num_layers, dim_feedforward=2048, causal=False, context=None,
                  positional_embedding="sin", max_period=10_000, positional_scale=1.0, betas=None, device=None, dtype=None,
                  **kwargs):
         super().__init__()
         assert d_model % num_heads == 0
-        if positional_embedding not in ("rope", "none"):
-            raise NotImplementedError("positional_embedding: only 'rope' and 'none' are on the hot path")
+        assert positional_embedding in {"sin", "rope", "sin_rope", "none"}
         self.d_model, self.num_heads, self.context = d_model, num_heads, context
-        self.positional_embedding, self.max_period = positional_embedding, max_period
-        self.rope = RotaryEmbedding(max_period) if positional_embedding == "rope" else None
+        self.positional_embedding, self.max_period, self.positional_scale = positional_embedding, max_period, positional_scale
+        self.rope = RotaryEmbedding(max_period) if positional_embedding in {"rope", "sin_rope"} else None
         self.layers = nn.ModuleList([StreamingTransformerLayer(d_model, num_heads, dim_feedforward, causal=causal, context=context,
                                                                rope=self.rope, device=device, **kwargs) for _ in range(num_layers)])
         self._plan = None
+        self._plan_capacity = self._plan_batch = 0
+        self.streaming_capacity = 2048          # positions one streaming session may span (linear cache; transformer.py's ring is not built)
+
+    def _init_streaming_state(self, batch_size: int):
+        return {"offset": 0}
 
     # ---- device plan -----------------------------------------------------------------------------
     def prepare(self, max_batch=1, max_seq_length=1024, dtype=torch.float32):
+        self._plan_capacity, self._plan_batch = max_seq_length, max_batch
         dev = self.layers[0].self_attn.in_proj_weight.device
         if dev.type != "cuda":
             raise RuntimeError("uniaudio2_amd runs on a ROCm device only (no CPU fallback)")
@@ -216,11 +234,23 @@ class StreamingTransformer(nn.Module):
     def forward(self, x, offset: int = 0):
         """x (B, T, C) at positions offset..offset+T-1 (offset = 0: whole sequence; > 0: incremental decoding
         against the cached keys).  With weights_per_step, position t uses the weights of step t (multi_linear)."""
+        state = self._streaming_state
+        if state is not None:                     # streaming(): positions continue where the previous call stopped
+            assert offset == 0, "pass either an explicit offset or use streaming(), not both"
+            offset = state["offset"]
+            state["offset"] = offset + x.shape[1]
+            if offset + x.shape[1] > self.streaming_capacity:
+                raise RuntimeError(f"streaming past {self.streaming_capacity} positions needs the ring cache (not built)")
+            if self._plan is None or self._plan_capacity < self.streaming_capacity or self._plan_batch < x.shape[0]:
+                self.prepare(max_batch=x.shape[0], max_seq_length=self.streaming_capacity)
         if self._plan is None:
             self.prepare(max_batch=x.shape[0], max_seq_length=max(UA2_PAGE, offset + x.shape[1]))
         B, T, Cc = x.shape
         dev = x.device
         out = x.float().contiguous().clone()
+        if self.positional_embedding in {"sin", "sin_rope"}:        # transformer.py:683-689
+            positions = (offset + torch.arange(T, device=dev)).view(1, -1, 1)
+            out = out + self.positional_scale * create_sin_embedding(positions, Cc, max_period=self.max_period)
         if any(e["wps"] > 1 for e in self._plan["layers"]):
             seq = torch.arange(B, dtype=torch.int32, device=dev)
             for t in range(T):
