@@ -235,7 +235,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torchrun the RCCL path runs even with one rank
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     import uniaudio2_amd  # noqa: F401  (fails loudly without libua2hip.so)
@@ -246,13 +247,13 @@ def main():
 
     def step():
         log = utterance(model, tokens, mask)                    # (FRAMES, 1, 9)
-        if world > 1:
+        if use_dist:
             out = [torch.empty_like(log) for _ in range(world)]
             dist.all_gather(out, log.contiguous())              # the path's only exchange
         return log
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -264,7 +265,7 @@ def main():
         log = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -303,7 +304,7 @@ def main():
         res["batched_decode"] = batched_leg(model, dev)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
