@@ -108,9 +108,9 @@ def roofline_leg(model):
     achieved = per_launch_bytes / (ms * 1e-3) / 1e9
     return {"kernel": "gemv_kernel<1, 1, 2, 4, true> (RMSNorm + fc_1/fc_2 + SwiGLU GEMV, 3072 -> 2x8192, bf16)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # HBM read bytes per launch from a separate PMC pass (profiles/r1_pmc_swiglu.txt: FETCH_SIZE x 1024 x 2,
-            # the gfx950 half-count correction of MI355X_MICROARCH.md §HBM); 1.002x the algorithmic bytes
-            "traffic": 100958000, "launches_per_frame": len(args), "avg_launch_us": round(ms * 1e3, 2),
+            # HBM read bytes per launch from a separate PMC pass (profiles/r1_pmc_swiglu.txt: FETCH_SIZE x 1024 x 2, re-measured on the final kernel,
+            # the gfx950 half-count correction of MI355X_MICROARCH.md §HBM); 1.003x the algorithmic bytes
+            "traffic": 100995000, "launches_per_frame": len(args), "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_bytes_per_launch": int(per_launch_bytes)}
 
 
