@@ -13,6 +13,16 @@ if GOLDEN not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout has no libua2hip.so (built artefacts are git-ignored): build it once (hipcc cross-compiles
+    # gfx950 without a GPU).  Only when the file is MISSING — the GPU box receives the library with the tree and must not
+    # spend its minutes recompiling because of copied timestamps.
+    lib = os.path.join(ROOT, "uniaudio2_amd", "libua2hip.so")
+    if not os.path.exists(lib):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ua2_build", os.path.join(ROOT, "uniaudio2_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_lib(force=True, verbose=False)
 
 
 @pytest.fixture(scope="session")
