@@ -1,5 +1,6 @@
-"""Mirror of the reference's evaluation/asr_task.py `Generator` (greedy `generate_asr`; the n-gram
-variant and the beam search, which is dead code in the reference — SURVEY Appendix A.9 — are out of scope)."""
+"""Mirror of the reference's evaluation/asr_task.py `Generator` (greedy `generate_asr`).  Not mirrored: the beam
+search (:438-, calls a method Model_stage3 lacks — SURVEY Appendix A.9) and the n-gram variant (:329-405: it prefills
+with the training forward `self._model(...)`, :356, which never writes the KV cache, so it decodes without its prompt)."""
 import torch
 
 from ._generator import GeneratorBase
