@@ -11,15 +11,13 @@ packs the weights into MFMA-fragment order, allocates the paged KV pools and pub
 `GptDesc` for the frame executor; `GPT.forward` drives the same kernels op by op (used by the
 parity tests and for stand-alone GPTs).  No torch math on the data path.
 """
-import ctypes as C
-import math
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
 from .. import ops
-from .._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_ATTN, PRO_CAST, PRO_NORM, UA2_PAGE,
+from .._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_SWIGLU, PRO_ATTN, PRO_CAST, PRO_NORM, UA2_PAGE,
                     GptDesc, vp)
 from .config import Config
 

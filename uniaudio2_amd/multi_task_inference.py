@@ -23,7 +23,6 @@ import glob
 import json
 import os
 import random
-import sys
 
 import torch
 import yaml

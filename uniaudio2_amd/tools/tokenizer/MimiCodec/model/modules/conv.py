@@ -11,11 +11,10 @@ Arithmetic: ua2_conv1d / ua2_dwconv1d.
 """
 import math
 
-import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ......_lib import ACT_ELU, ACT_NONE
+from ......_lib import ACT_NONE
 from .streaming import RawStreamingConv1d, RawStreamingConvTranspose1d, StreamingModule
 
 

@@ -12,7 +12,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ...... import ops
 from ......_lib import ACT_ELU, ACT_NONE
 from .conv import StreamingConv1d, StreamingConvTranspose1d
 from .streaming import StreamingModule

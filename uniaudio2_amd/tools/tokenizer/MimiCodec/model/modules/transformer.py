@@ -24,7 +24,6 @@ capacity - 1 once the ring is full); that off-by-one is NOT reproduced — a con
 bug of the ring bookkeeping, not of the model.
 """
 import math
-import typing as tp
 
 import torch
 import torch.nn as nn
