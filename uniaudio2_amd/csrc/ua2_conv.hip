@@ -189,7 +189,8 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
   const int row_blocks = ua2_ceil_div((int64_t)a->Cout * a->out_phases, kBR);
   // largest time tile that still gives >= 512 workgroups (2 per CU); never below 16 steps
   int ntt = 4;
-  while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt) * row_blocks * a->B < 512) ntt >>= 1;
+  static const int min_wg = getenv("UA2_CONV_MIN_WG") ? atoi(getenv("UA2_CONV_MIN_WG")) : 512;   // experiment hook
+  while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt) * row_blocks * a->B < min_wg) ntt >>= 1;
   const int bt = 16 * ntt;
   const int W = (bt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
   const size_t smem = (size_t)kCIG * (W + 1) * sizeof(float) + (size_t)kCIG * a->K * sizeof(int);
