@@ -99,7 +99,7 @@ constexpr int kGroupM = 8;  // row-blocks per L2 patch
 
 template <int DT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
-                                                      const int mblocks, const int nblocks) {
+                                                      const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int WN = 4 / NT;          // column tiles per wave, per matrix
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   int pid = blockIdx.x;
   const int total = gridDim.x;
   if (total % 8 == 0) pid = (pid & 7) * (total >> 3) + (pid >> 3);
-  const int per_group = kGroupM * nblocks;
-  const int group = pid / per_group, first_m = group * kGroupM;
-  const int gsz = min(mblocks - first_m, kGroupM);
+  const int per_group = group_m * nblocks;
+  const int group = pid / per_group, first_m = group * group_m;
+  const int gsz = min(mblocks - first_m, group_m);
   const int pm = first_m + (pid % per_group) % gsz;
   const int pn = (pid % per_group) / gsz;
 
@@ -385,8 +385,9 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int BNT = 2 * (4 / NT);
   const int mblocks = ua2_ceil_div(ua2_ceil_div(a.M, 16), kBMT), nblocks = ua2_ceil_div(ua2_ceil_div(a.N, 16), BNT);
+  static const int group_m = getenv("UA2_GEMM_GROUP_M") ? std::max(1, atoi(getenv("UA2_GEMM_GROUP_M"))) : kGroupM;   // experiment hook
   hipLaunchKernelGGL((gemm_kernel<DT, EPI>), dim3(mblocks * nblocks), dim3(256), 0, s, a,
-                     reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), nw, mblocks, nblocks);
+                     reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), nw, mblocks, nblocks, group_m);
 }
 
 // Which of the two forms is faster — both give the same bits, so this is purely a cost model, fitted on
