@@ -208,3 +208,79 @@ def test_ragged_schedule_runs_every_sequence_exactly_its_frames():
             assert all(done[b] == case[b] for r, b in enumerate(active) if r not in keep)   # the retired are exactly done
             rows = [rows[r] for r in keep]
         assert done == list(case) and rows == []
+
+
+class _ScriptedBatchModel:
+    """CPU stand-in for Model_stage3's batched interface: every sequence replays its own scripted id stream; rows follow
+    the retire_rows permutations exactly as the device state would."""
+
+    def __init__(self, streams):
+        self.streams = streams                      # per sequence: (F_b, 9) int32
+        self._p = torch.nn.Parameter(torch.zeros(1))
+        self._st = None
+        self.rows, self.cursor, self.calls, self.retired = [], {}, [], []
+
+    def parameters(self):
+        return iter([self._p])
+
+    def setup_caches(self, b, max_rows=64, log_frames=512):
+        self._st = {"B": b, "max_rows": max_rows, "log_frames": log_frames}
+
+    def begin_ragged(self, prompts):
+        assert len(prompts) <= self._st["B"]
+        self.prompt_lens = [int(t.shape[0]) for t, _ in prompts]
+        self.rows = list(range(len(prompts)))
+        self.cursor = {b: 0 for b in self.rows}
+
+    def set_sampling(self, topk, temperature, seed=None):
+        self.sampling = (topk, temperature)
+
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
+        assert batch == len(self.rows) and mode == 0
+        self.calls.append((n, batch))
+        out = torch.zeros(n, batch, 9, dtype=torch.int32)
+        for r, b in enumerate(self.rows):
+            s = self.streams[b][self.cursor[b]:self.cursor[b] + n]
+            out[:s.shape[0], r] = s
+            self.cursor[b] += n
+        return out
+
+    def retire_rows(self, keep, batch):
+        assert batch == len(self.rows)
+        self.retired.append([self.rows[r] for r in range(batch) if r not in keep])
+        self.rows = [self.rows[r] for r in keep]
+
+
+def test_batched_tts_retires_sequences_at_their_own_eos():
+    """generate_tts_batch: one ragged prefill, chunked decode of the live rows, per-sequence phase / EOS bookkeeping and
+    retirement; every sequence's (reason, semantic) equals what the single-utterance loop returns for its stream."""
+    from uniaudio2_amd.evaluation.tts_task import Generator
+    g = torch.Generator().manual_seed(11)
+    shapes = [(5, 9), (16, 16), (3, 40), (30, 2), (2, 2)]             # (reason frames, semantic frames) per utterance
+    streams, frames_list = [], []
+    for n_reason, n_sem in shapes:
+        frames = [torch.randint(0, 4096, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_reason)]
+        frames.append(torch.full((1, 8), TA.reason_eos, dtype=torch.int32))
+        frames += [torch.randint(4100, 12292, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_sem)]
+        frames.append(torch.full((1, 8), TA.semantic_eos + TA.audio_reason_card, dtype=torch.int32))
+        frames += [torch.randint(0, 100, (1, 8), generator=g, dtype=torch.int32) for _ in range(48)]
+        log = torch.zeros(len(frames), 9, dtype=torch.int32)
+        log[:, 1:] = torch.cat(frames)
+        streams.append(log); frames_list.append(frames)
+    model = _ScriptedBatchModel(streams)
+    gen = Generator.__new__(Generator)
+    for k, v in vars(TA).items():
+        setattr(gen, k, v)
+    gen.empty_token, gen.is_cfg, gen._model, gen.device = 0, False, model, torch.device("cpu")
+    gen.special_token_dict = gen.get_special_token()
+    texts = [torch.arange(3 + i) for i in range(len(shapes))]         # different prompt lengths
+    out = gen.generate_tts_batch(torch.tensor([128000, 1, 128001]), "tts", texts, topk=1)
+    assert model._st["B"] >= len(shapes) and model.prompt_lens == [3 + 2 + 3 + i for i in range(len(shapes))]
+    for (r, s), frames in zip(out, frames_list):
+        rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+        assert torch.equal(r, rr) and torch.equal(s, rs)
+    # the batch shrank as utterances ended: 5 rows at first, fewer later, never a row computed after its retirement
+    sizes = [b for _, b in model.calls]
+    assert sizes[0] == 5 and sizes == sorted(sizes, reverse=True) and sizes[-1] < 5
+    assert sorted(b for group in model.retired for b in group) == [0, 1, 2, 3, 4]
+    assert model.sampling == (1, 0.9)

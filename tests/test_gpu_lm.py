@@ -311,3 +311,55 @@ def test_multinomial_reference_self_test_distribution():
     assert cnts[6] == 0
     diff = cnts / cnts.sum() - ps / ps.sum()
     assert float(diff.abs().max()) < 1.5e-2, diff
+
+
+def test_batched_generator_streams_equal_single_runs(golden, sd, monkeypatch):
+    """Generator.generate_tts_batch on the device (ragged prefill, chunked frames, retire_rows) feeds every sequence's
+    bookkeeping the same frames as one-by-one generate_tts does (greedy, fp32).  The toy weights never emit the EOS
+    frames, so both loops run to max_audio_frames and fail at the reference's final torch.stack, as the reference
+    would; what is compared is the recorded frame stream of each sequence."""
+    import types
+    from uniaudio2_amd.evaluation import _generator
+    from uniaudio2_amd.evaluation.tts_task import Generator
+    ta = types.SimpleNamespace(text_pad_token=3, semantic_pad_token=0, semantic_eos=69, semantic_bos=68, reason_eos=39,
+                               reason_bos=38, reason_pad_token=0, parallel_number=9, audio_reason_card=RC)
+    recorded = []
+
+    class Recorder(_generator.PhaseSplitter):
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.frames = []
+            recorded.append(self)
+
+        def push(self, audio):
+            self.frames.append(audio.clone())
+            return super().push(audio)
+
+    monkeypatch.setattr(_generator, "PhaseSplitter", Recorder)
+    from helpers import build_toy_module
+    m = build_toy_module()
+    m.load_state_dict(sd)
+    m = m.to("cuda").float()
+    gen = Generator(m, ta, text_tokenizer_path="ids")
+    gen.special_token_dict = {k: 400 + i for i, k in enumerate(gen.special_token_dict)}      # ids inside the toy vocabulary
+    gen.chunk_frames = 5
+    g = torch.Generator().manual_seed(3)
+    prompt = torch.randint(4, 300, (4,), generator=g)
+    texts = [torch.randint(4, 300, (n,), generator=g) for n in (3, 9, 6)]
+
+    def run(fn):
+        recorded.clear()
+        with pytest.raises(RuntimeError, match="non-empty TensorList"):
+            fn()
+        return [torch.cat(r.frames) for r in recorded]
+
+    monkeypatch.setattr(Generator, "_generate_audio_tokens_batch",
+                        lambda self, prompts, **kw: _generator.GeneratorBase._generate_audio_tokens_batch(self, prompts, max_audio_frames=12, **kw))
+    monkeypatch.setattr(Generator, "_generate_audio_tokens",
+                        lambda self, t, mk, *a, **kw: _generator.GeneratorBase._generate_audio_tokens(self, t, mk, *a, max_audio_frames=12, **kw))
+    batch = run(lambda: gen.generate_tts_batch(prompt, "tts", texts, topk=1))
+    assert len(batch) == 3 and all(b.shape == (12, 8) for b in batch)
+    gen._model.setup_caches(1)
+    for i, t in enumerate(texts):
+        single = run(lambda: gen.generate_tts(prompt, "tts", text_token=t, topk=1))
+        assert len(single) == 1 and torch.equal(single[0], batch[i]), i

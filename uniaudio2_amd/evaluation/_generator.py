@@ -215,6 +215,45 @@ class GeneratorBase:
         return de_reason.to(self.device), de_sem.to(self.device)
 
     @torch.inference_mode()
+    def _generate_audio_tokens_batch(self, prompts, topk=1, temperature=1.0, max_audio_frames=500):
+        """Many utterances at once on one GPU (the reference loops over them one by one,
+        multi_task_inference.py:510): prompts = [(tokens (L_b, 9), mask (L_b, 9)), ...] of any lengths.  One ragged prefill,
+        then all sequences decode together in device-side chunks; after each chunk the host runs every sequence's own
+        phase / EOS bookkeeping (the same PhaseSplitter as the single-utterance loop) and retires the finished ones, so
+        the batch shrinks as utterances end.  Greedy results equal the one-by-one results bit for bit (row invariance)."""
+        if self.is_cfg:
+            raise NotImplementedError("batched generation with the classifier-free-guidance pair layout is not built")
+        B = len(prompts)
+        st = getattr(self._model, "_st", None)
+        longest = max(int(t.shape[0]) for t, _ in prompts)
+        need_rows = sum(int(t.shape[0]) - 1 for t, _ in prompts)
+        if st is None or st["B"] < B or st["max_rows"] < min(need_rows, 8192) or st["log_frames"] < max_audio_frames:
+            self._model.setup_caches(B, max_rows=max(64, min(need_rows, 8192)), log_frames=max(512, max_audio_frames))
+        self._model.begin_ragged([(t, m.bool()) for t, m in prompts])
+        self._set_sampling(topk, temperature)
+        splitters = [PhaseSplitter(self.reason_eos, self.semantic_eos, self.audio_reason_card) for _ in range(B)]
+        active, frame = list(range(B)), 0
+        while active and frame < max_audio_frames:
+            n = min(self.chunk_frames, max_audio_frames - frame)
+            log = self._model.generate_frames(n, len(active), 0, reason_eos=self.reason_eos, reason_card=self.audio_reason_card,
+                                              max_pos=longest + max_audio_frames).cpu()       # (n, rows, 9)
+            keep = []
+            for r, b in enumerate(active):
+                for f in range(n):
+                    if not splitters[b].push(log[f, r:r + 1, 1:]):
+                        break
+                if not splitters[b].done:
+                    keep.append(r)
+            self._model.retire_rows(keep, len(active))
+            active = [active[r] for r in keep]
+            frame += n
+        out = []
+        for ph in splitters:
+            de_reason, de_sem = ph.result()
+            out.append((de_reason.to(self.device), de_sem.to(self.device)))
+        return out
+
+    @torch.inference_mode()
     def _generate_text(self, tokens, tokens_mask, topk=1, temperature=1.0, max_frames=500) -> str:
         """The loop of generate_asr / generate_audio_caption / generate_answer (asr_task.py:658-688)."""
         B, L = self._prefill([tokens], [tokens_mask])

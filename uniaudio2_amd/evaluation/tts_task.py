@@ -23,3 +23,11 @@ class Generator(GeneratorBase):
         if self.is_cfg:
             cfg_t, cfg_m = self.prepare_tts_task_for_cfg(task_prompt, text_token)
         return self._generate_audio_tokens(tokens, mask, cfg_t, cfg_m, topk=topk, temperature=temperature)
+
+    @torch.inference_mode()
+    def generate_tts_batch(self, task_prompt, task_name, text_tokens, temperature: float = 0.9, topk: int = 200, cfg_scale=1.0):
+        """Not in the reference: `generate_tts` for a list of texts decoded together on one GPU (continuous batching);
+        returns [(reason (8, T_r), semantic (8, T_s)), ...] in input order, each equal to its own generate_tts result
+        under greedy decoding."""
+        prompts = [self.prepare_tts_task(task_prompt, t) for t in text_tokens]
+        return self._generate_audio_tokens_batch(prompts, topk=topk, temperature=temperature)

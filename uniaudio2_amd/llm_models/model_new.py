@@ -319,18 +319,17 @@ class Model_stage3(nn.Module):
         return len(keep)
 
     @torch.inference_mode()
-    def generate_ragged(self, prompts, n_frames, mode: int = 0, reason_eos: int = -1, reason_card: int = 0):
-        """Batched fixed-length generation with continuous batching: prompts[b] = (tokens (L_b, 9), mask (L_b, 9)),
-        n_frames[b] frames for sequence b (SURVEY.md §8d config 4: deterministic stop).  All sequences decode
-        together; a sequence leaves the batch the frame it finishes.  Returns a list of (n_frames[b], 9) int32
-        id tensors (device), each bit-identical to the sequence's own B = 1 run."""
+    def begin_ragged(self, prompts):
+        """Start of a batched generation: prompts[b] = (tokens (L_b, 9), mask (L_b, 9)) of any lengths.  Resets the caches
+        and the page tables (undoing earlier retirements), prefills every prompt[:-1] in one ragged pass and loads each
+        last prompt frame as the first decode frame of row b.  Returns the (B,) tensor of decode start positions."""
         self._need()
         st = self._st
         dev = st["device"]
         B = len(prompts)
-        assert B <= st["B"] and len(n_frames) == B
+        assert B <= st["B"], f"setup_caches({st['B']}) is too small for {B} sequences"
         self.reset_caches()
-        for g in (self.audio_understanding_expert, self.backbone, self.audio_generation_expert):   # undo earlier retirements
+        for g in (self.audio_understanding_expert, self.backbone, self.audio_generation_expert):
             kv = g.kv_cache
             kv.page_table.copy_(torch.arange(kv.page_table.numel(), dtype=torch.int32, device=dev).view_as(kv.page_table))
         self.forward_prefix_ragged([t[:-1] for t, _ in prompts], [m[:-1] for _, m in prompts])
@@ -338,6 +337,19 @@ class Model_stage3(nn.Module):
         last_m = torch.stack([m[-1] for _, m in prompts]).to(dev)
         pos = torch.tensor([t.shape[0] - 1 for t, _ in prompts], device=dev)
         self.begin_decode(last_t.unsqueeze(1), last_m.unsqueeze(1), pos)
+        return pos
+
+    @torch.inference_mode()
+    def generate_ragged(self, prompts, n_frames, mode: int = 0, reason_eos: int = -1, reason_card: int = 0):
+        """Batched fixed-length generation with continuous batching: prompts[b] = (tokens (L_b, 9), mask (L_b, 9)),
+        n_frames[b] frames for sequence b (SURVEY.md §8d config 4: deterministic stop).  All sequences decode
+        together; a sequence leaves the batch the frame it finishes.  Returns a list of (n_frames[b], 9) int32
+        id tensors (device), each bit-identical to the sequence's own B = 1 run."""
+        B = len(prompts)
+        assert len(n_frames) == B
+        pos = self.begin_ragged(prompts)
+        st = self._st
+        dev = st["device"]
         out = [[] for _ in range(B)]
         max_pos = max(int(p) + int(n) for p, n in zip(pos.tolist(), n_frames)) + 1
         for step, active, keep in ragged_schedule(n_frames):

@@ -9,6 +9,7 @@ MI355X kernels.  Same flags, same `{name}_reason.pt` / `{name}_semantic.pt` (8, 
 
 Differences, all explicit:
   * `--dtype {bf16,fp32}` (default bf16) picks the kernel precision; the reference runs fp32.
+  * `--batch_size N` decodes N utterances of a --text_file together per GPU (continuous batching; TTS).
   * Under `torchrun` (WORLD_SIZE > 1) the texts of --text_file are sharded over the ranks, one utterance
     per GPU at a time, and gathered with one RCCL all-gather (uniaudio2_amd/parallel.py); rank 0 writes.
   * --topk > 1 samples on the device with a counter-based generator seeded by --seed: reproducible, same
@@ -218,7 +219,13 @@ def run_generation_stage1(args):
         return gen_fn(task_prompt=task_prompt, task_name=task, text_token=ids[i], temperature=args.temperature,
                       topk=args.topk, cfg_scale=args.cfg_scale, **extra(i))
 
-    results = parallel.run_sharded(list(range(len(items))), [len(x) for x in ids], one)
+    if args.batch_size > 1 and hasattr(generator, "generate_tts_batch") and _generation_method_name(task) == "generate_tts":
+        def many(idx):
+            return generator.generate_tts_batch(task_prompt=task_prompt, task_name=task, text_tokens=[ids[i] for i in idx],
+                                                temperature=args.temperature, topk=args.topk, cfg_scale=args.cfg_scale)
+        results = parallel.run_sharded_batched(list(range(len(items))), [len(x) for x in ids], many, args.batch_size)
+    else:
+        results = parallel.run_sharded(list(range(len(items))), [len(x) for x in ids], one)
     if int(os.environ.get("RANK", "0")) == 0:
         for i, (name, _) in enumerate(items):
             reason, semantic = results[i]
@@ -288,6 +295,8 @@ def get_parser():
     p.add_argument("--seed", type=int, default=888)
     p.add_argument("--rank", type=int, default=0)
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="kernel precision (extension; the reference runs fp32)")
+    p.add_argument("--batch_size", type=int, default=1,
+                   help="utterances decoded together per GPU (extension; TTS / Yue_TTS with --text_file; 1 = one by one as the reference)")
     return p
 
 

@@ -60,3 +60,17 @@ def run_sharded(items: Sequence, lengths: Sequence[int], generate_fn) -> Dict[in
     rank = dist.get_rank() if world > 1 else 0
     local = {i: generate_fn(items[i]) for i in shard_indices(lengths, world, rank)}
     return gather_results(local, len(items))
+
+
+def run_sharded_batched(items: Sequence, lengths: Sequence[int], generate_batch_fn, batch_size: int):
+    """As run_sharded, but this rank's shard is processed `batch_size` items at a time by
+    generate_batch_fn(list of items) -> list of (reason, semantic) (continuous batching on one GPU)."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = list(shard_indices(lengths, world, rank))
+    local = {}
+    for s0 in range(0, len(mine), max(1, batch_size)):
+        chunk = mine[s0:s0 + max(1, batch_size)]
+        for i, res in zip(chunk, generate_batch_fn([items[i] for i in chunk])):
+            local[i] = res
+    return gather_results(local, len(items))
