@@ -31,3 +31,25 @@ def test_validation_errors_match_reference(argv, msg):
 def test_prompt_key_mapping():
     assert cli._prompt_key_from_task("yue_tts") == "Yue_TTS" and cli._prompt_key_from_task("tts") == "TTS"
     assert cli._prompt_key_from_task("speech_s2t") == "speech_s2t"
+
+
+def test_token_files_follow_the_reference_contract(tmp_path):
+    """multi_task_inference.py:522-523: `{name}_reason.pt` / `{name}_semantic.pt` = torch.save of (8, T) int32 CPU tensors
+    (readers apply .long() / .transpose(0, 1), :304-308); the optional safetensors twin holds the same tensors."""
+    import types
+    import torch
+    from safetensors.torch import load_file
+    from uniaudio2_amd import multi_task_inference as cli
+    args = types.SimpleNamespace(output_dir=str(tmp_path), save_safetensors=True)
+    reason = torch.randint(0, 4096, (8, 7), dtype=torch.int32)
+    semantic = torch.randint(0, 8192, (8, 19), dtype=torch.int32)
+    cli._save_tokens(args, "utt_0", reason, semantic)
+    r = torch.load(tmp_path / "utt_0_reason.pt", map_location="cpu")
+    s = torch.load(tmp_path / "utt_0_semantic.pt", map_location="cpu")
+    assert r.dtype == torch.int32 and r.shape == (8, 7) and torch.equal(r, reason) and torch.equal(s, semantic)
+    assert r.transpose(0, 1).long().shape == (7, 8)
+    st = load_file(str(tmp_path / "utt_0_tokens.safetensors"))
+    assert torch.equal(st["reason"], reason) and torch.equal(st["semantic"], semantic)
+    args.save_safetensors = False
+    cli._save_tokens(args, "utt_1", reason, semantic)
+    assert not (tmp_path / "utt_1_tokens.safetensors").exists() and (tmp_path / "utt_1_reason.pt").exists()

@@ -121,6 +121,18 @@ def _get_generator_class(task):
     return table[task].Generator
 
 
+def _save_tokens(args, name, reason, semantic):
+    """The reference's on-disk contract (multi_task_inference.py:522-523): `{name}_reason.pt` / `{name}_semantic.pt`, each a
+    torch.save of an (8, T) int32 CPU tensor.  `--save_safetensors` adds `{name}_tokens.safetensors` with the same two
+    tensors (keys "reason", "semantic") for consumers that do not unpickle."""
+    reason, semantic = reason.cpu().contiguous(), semantic.cpu().contiguous()
+    torch.save(reason, os.path.join(args.output_dir, f"{name}_reason.pt"))
+    torch.save(semantic, os.path.join(args.output_dir, f"{name}_semantic.pt"))
+    if getattr(args, "save_safetensors", False):
+        from safetensors.torch import save_file
+        save_file({"reason": reason, "semantic": semantic}, os.path.join(args.output_dir, f"{name}_tokens.safetensors"))
+
+
 def _generation_method_name(task):
     t = task.strip().lower()
     if t in ("tts", "yue_tts"):
@@ -229,8 +241,7 @@ def run_generation_stage1(args):
     if int(os.environ.get("RANK", "0")) == 0:
         for i, (name, _) in enumerate(items):
             reason, semantic = results[i]
-            torch.save(reason.cpu(), os.path.join(args.output_dir, f"{name}_reason.pt"))
-            torch.save(semantic.cpu(), os.path.join(args.output_dir, f"{name}_semantic.pt"))
+            _save_tokens(args, name, reason, semantic)
             print(f"[Stage1] {name} -> {name}_reason.pt, {name}_semantic.pt")
     return args.output_dir
 
@@ -263,8 +274,7 @@ def _run_speech_s2s(args, generator, task_prompt):
     if int(os.environ.get("RANK", "0")) == 0:
         for i, (name, _) in enumerate(items):
             reason, semantic = results[i]
-            torch.save(reason.cpu(), os.path.join(args.output_dir, f"{name}_reason.pt"))
-            torch.save(semantic.cpu(), os.path.join(args.output_dir, f"{name}_semantic.pt"))
+            _save_tokens(args, name, reason, semantic)
             print(f"[Stage1] speech_s2s {name} -> {name}_reason.pt, {name}_semantic.pt")
     return args.output_dir
 
@@ -295,6 +305,8 @@ def get_parser():
     p.add_argument("--seed", type=int, default=888)
     p.add_argument("--rank", type=int, default=0)
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="kernel precision (extension; the reference runs fp32)")
+    p.add_argument("--save_safetensors", action="store_true",
+                   help="also write {name}_tokens.safetensors next to the reference's two .pt files (extension)")
     p.add_argument("--batch_size", type=int, default=1,
                    help="utterances decoded together per GPU (extension; TTS / Yue_TTS with --text_file; 1 = one by one as the reference)")
     return p
