@@ -44,6 +44,38 @@ def test_sharded_generation_allgather_world2():
         assert abs(len(ret[0][1]) - len(ret[1][1])) <= 1
 
 
+def _worker_batched(rank, world, port, n, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uniaudio2_amd.parallel import run_sharded_batched
+    lengths = [(i * 5) % 11 + 1 for i in range(n)]
+    calls = []
+
+    def fake_batch(idx):
+        calls.append(list(idx))
+        return [fake_generate(i) for i in idx]
+
+    out = run_sharded_batched(list(range(n)), lengths, fake_batch, batch_size=3)
+    ok = sorted(out) == list(range(n)) and all(len(c) <= 3 for c in calls)
+    for i in range(n):
+        r, s = fake_generate(i)
+        ok = ok and torch.equal(out[i][0], r) and torch.equal(out[i][1], s)
+    ret[rank] = (ok, [i for c in calls for i in c])
+    dist.destroy_process_group()
+
+
+def test_sharded_batched_generation_world2():
+    """--batch_size path: each rank walks its shard three utterances at a time; the gathered result is complete and
+    correctly keyed on every rank."""
+    n, world = 11, 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_batched, args=(world, 29593, n, ret), nprocs=world, join=True)
+        assert all(ret[r][0] for r in range(world))
+        assert sorted(ret[0][1] + ret[1][1]) == list(range(n))
+
+
 def test_shard_indices_longest_first():
     from uniaudio2_amd.parallel import shard_indices
     lengths = [5, 50, 7, 40, 30]
