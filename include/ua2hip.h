@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 1
+#define UA2_VERSION 2
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -35,7 +35,7 @@ enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 enum ua2_prologue {
   UA2_PRO_CAST = 0, /* x as is                                   (lit_model.py:511,595; model_new.py:617,631) */
   UA2_PRO_NORM = 1, /* RMSNorm(x)*w, fp32 math                    (lit_model.py:883-890 before :424 / :591)    */
-  UA2_PRO_ATTN = 2, /* merge of the per-page attention partials   (softmax tail of lit_model.py:529-531)        */
+  /* 2: reserved (round 1's merge of per-page attention partials; ua2_attn now writes the normalised row itself) */
   UA2_PRO_LOCAL_ATTN = 3 /* M == 1 only: the operand row IS the short-context attention of ua2_attn_local, computed
                        in the kernel (x = q [1, n_head*head_size], kv, row_pos, row_seq as for ua2_attn_local;
                        K == n_head*head_size).  Bit-identical to ua2_attn_local followed by UA2_PRO_CAST. */
@@ -106,8 +106,6 @@ typedef struct ua2_linear_args {
   int32_t ldx;
   const float* norm_w;    /* NORM: [K] fp32 */
   float eps;
-  const float* attn_o;    /* ATTN: [M, n_head, max_pages, head_size] fp32 un-normalised partial outputs */
-  const float* attn_ml;   /* ATTN: [M, n_head, max_pages, 2] (max, sum) */
   const void* w0;         /* packed weight */
   const void* w1;         /* SWIGLU: packed fc_2 */
   float* y;               /* STORE/RESIDUAL/SWIGLU: [M, ldy] fp32 (STORE: may be NULL if only partials wanted) */
@@ -117,12 +115,12 @@ typedef struct ua2_linear_args {
   float* part_max;        /* STORE, optional: [M, ceil(N/16)] */
   int32_t* part_idx;
   const int32_t* forbid;  /* optional [M]: columns < forbid[m] are excluded from the partial arg-max */
-  const int32_t* row_pos; /* ATTN, QKV_ROPE: [M] absolute position of each row */
+  const int32_t* row_pos; /* QKV_ROPE, LOCAL_ATTN: [M] absolute position of each row */
   const int32_t* row_seq; /* QKV_ROPE: [M] sequence (page-table row) of each row */
   const float* rope_cos;  /* QKV_ROPE: [max_pos, head_size/2] */
   const float* rope_sin;
   float* q_out;           /* QKV_ROPE: [M, n_head*head_size] fp32, rotated */
-  ua2_kv_geom kv;         /* ATTN (n_head, head_size, max_pages), QKV_ROPE (all) */
+  ua2_kv_geom kv;         /* QKV_ROPE, LOCAL_ATTN */
   const float* norm_b;    /* NORM, LAYERNORM only: [K] bias */
   int32_t norm_kind;      /* enum ua2_norm_kind */
   const float* out_scale; /* RESIDUAL, optional [N]: y = resid + out_scale[n] * xW^T  (LayerScale, transformer.py:97) */
@@ -147,7 +145,7 @@ int ua2_linear(const ua2_linear_args* a, void* stream);
 size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K);
 /* Test hook, returns the previous setting.  0 (default): the launcher picks — row-tiled decode-regime
  * kernel for one row tile, large-M kernels when a workspace is supplied and M spans more than one.
- * 1: the general-M fallback kernel only (different summation order: NOT bit-comparable with the others).
+ * 1: removed (round 1's general-M kernel), treated as 0.
  * 2: never the large-M kernels.  3: a large-M kernel whenever a workspace is supplied, even for M = 1
  * (4: always its skinny form, 5: always its 128-row tiled form).
  * Modes 0, 2, 3, 4 and 5 produce bit-identical results (tests/test_gpu_invariance.py). */
@@ -158,28 +156,22 @@ int ua2_debug_force_general_linear(int on);
  * returns the elapsed milliseconds in *ms_out.  No other work is enqueued in between. */
 int ua2_linear_chain_timed(const ua2_linear_args* args, int32_t n, int32_t iters, void* stream, float* ms_out);
 
-/* Decode/prefill attention over the paged cache: one query row per (row, head); each
- * (row, kv-head, page) workgroup writes un-normalised partials that UA2_PRO_ATTN merges.
- * Replaces repeat_interleave + masked SDPA (lit_model.py:478-481, 529-531): GQA without
+/* Decode/prefill attention over the paged cache: one query row per (row, head); one workgroup per (row, kv-head)
+ * walks positions 0..row_pos (waves own contiguous ranges, online softmax, fixed-order merge in LDS) and writes the
+ * normalised output.  Replaces repeat_interleave + masked SDPA (lit_model.py:478-481, 529-531): GQA without
  * materialising K/V per query head, causal mask = "positions <= row_pos". */
 typedef struct ua2_attn_args {
   int32_t dtype;
   int32_t R;              /* query rows */
   const float* q;         /* [R, n_head*head_size] fp32 */
   const int32_t* row_pos; /* [R] */
-  const int32_t* row_seq; /* [R] */
-  float* attn_o;          /* [R, n_head, max_pages, head_size] */
-  float* attn_ml;         /* [R, n_head, max_pages, 2] */
-  int32_t grid_pages;     /* pages to launch (>= max(row_pos)/UA2_PAGE + 1); <=0 means kv.max_pages */
+  const int32_t* row_seq; /* [R] page-table row of each query row; NULL: row r is sequence r */
   ua2_kv_geom kv;
-  float* y;               /* if non-NULL: single-pass mode — one workgroup per (row, kv-head) walks all pages
-                             (waves own pages, online softmax, merge in LDS) and writes the normalised
-                             output [R, n_head*head_size]; attn_o / attn_ml / grid_pages are unused */
-  int32_t window;         /* single-pass mode: > 0 = attend only to the last `window` positions (Moshi `context`,
+  float* y;               /* [R, n_head*head_size] fp32 normalised output (may be NULL when y_packed is given) */
+  int32_t window;         /* > 0 = attend only to the last `window` positions (Moshi `context`,
                              transformer.py:405-406: delta < context); 0 = all positions <= row_pos */
-  void* y_packed;         /* single-pass mode / ua2_attn_local, optional: the output rounded to `dtype` in the packed
-                             operand layout of the O-projection (ua2_linear_args.x_packed), K = n_head*head_size;
-                             y may then be NULL */
+  void* y_packed;         /* optional: the output rounded to `dtype` in the packed operand layout of the
+                             O-projection (ua2_linear_args.x_packed), K = n_head*head_size */
 } ua2_attn_args;
 
 int ua2_attn(const ua2_attn_args* a, void* stream);
@@ -219,8 +211,10 @@ int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t
 
 /* Top-k sampling tail (model_new.py:146-187 with topk > 1: temperature, forbid_prefix, keep logits >= the
  * k-th largest, exponential-race multinomial draw) + next-step embedding gather.  Philox4x32-10 keyed by
- * (seed, counter[0] = draw index on device, row, stream_id): reproducible under graph replay; it does not
- * reproduce torch's generator stream (parity with the reference is distributional). */
+ * (seed + device seed word, draw index, row, stream_id) where `counter` is a DEVICE int32[3]: [0] = draw index,
+ * [1], [2] = low / high half of a 64-bit word added to `seed` (zeros for a purely by-value seed; the frame
+ * executor keeps its seed there so that one captured graph serves every seed).  Reproducible under graph replay;
+ * it does not reproduce torch's generator stream (parity with the reference is distributional). */
 int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
                     const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
                     int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,
@@ -326,7 +320,7 @@ typedef struct ua2_stage3_desc {
   int32_t* forbid;      /* [max_rows] forbid_prefix per row */
   int32_t* out_tokens;  /* [max_rows, n_cb+1] sampled [text, a0..a7] */
   int32_t* frame_log;   /* [log_frames, max_rows, n_cb+1] */
-  int32_t* counters;    /* [4]: [0] frame index (log slot), [1] sampling draw index */
+  int32_t* counters;    /* [4]: [0] frame index (log slot), [1] sampling draw index, [2..3] sampler seed (lo, hi) */
   int32_t log_frames;
   /* scratch (device, fp32 unless noted) — sizes in ua2_stage3_scratch_floats() */
   float* scratch;
@@ -338,10 +332,10 @@ typedef struct ua2_stage3 ua2_stage3;
 size_t ua2_stage3_scratch_floats(const ua2_stage3_desc* d);
 int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out);
 void ua2_stage3_destroy(ua2_stage3* h);
-/* Number of KV pages the attention grid covers (>= max position / UA2_PAGE + 1). Default: max_pages. */
-int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages);
-/* Sampling mode of the heads: topk == 1 -> greedy (default); topk > 1 -> ua2_sample_topk with this temperature / seed. */
-int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed);
+/* Sampling mode of the heads: topk == 1 -> greedy (default); topk > 1 -> ua2_sample_topk with this temperature / seed.
+ * The seed is written to counters[2..3] on `stream` (stream-ordered with the frames that follow); topk / temperature
+ * select the captured graph, the seed does not. */
+int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed, void* stream);
 /* cfg_scale > 1: frames of exactly two rows (conditional, unconditional) sample from the guided logits (ua2_cfg_mix). */
 int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale);
 

@@ -154,7 +154,6 @@ def test_batch_rows_equal_single_runs_ragged(golden, sd, dtype):
         n = L - 1
         model._load_rows(t[0, :-1].to(dev), mk[0, :-1].to(dev), torch.arange(n, device=dev),
                          torch.full((n,), b, device=dev))
-        model._set_grid_pages(L)
         from uniaudio2_amd import ops
         from uniaudio2_amd._lib import check, lib
         check(lib.ua2_stage3_trunk(model._h, n, ops.stream()), "trunk")
@@ -211,15 +210,15 @@ def test_generators_end_to_end_fp32(golden, sd):
     assert st["tokens"][0].tolist() == [ta.reason_eos] * 8 + [5] and st["mask"][0].tolist() == [1] * 8 + [0]
 
 
-def test_general_m_kernel_path_and_standalone_gpt(golden, sd):
-    """The general-M GEMM (prefill path) forced for every launch reproduces the reference ids too, and a
-    stand-alone GPT.forward (op-by-op: split-per-page attention + merge prologue) matches the oracle GPT."""
+def test_large_m_kernel_path_and_standalone_gpt(golden, sd):
+    """The many-row GEMM (prefill path) forced for every launch reproduces the reference ids too, and a
+    stand-alone GPT.forward (op by op, same kernels as the frame executor) matches the oracle GPT."""
     from oracle.lm_oracle import GPTOracle, shapes_from_configs
     from toy_configs import TOY_LM
     from uniaudio2_amd._lib import lib
     d, _ = golden
     tokens, mask = _case(d, "tts1")
-    old = lib.ua2_debug_force_general_linear(1)
+    old = lib.ua2_debug_force_general_linear(5)      # 128-row tiled GEMM for every launch that supplies a workspace
     try:
         m = build_product_model(sd, torch.float32, batch=1)
         r = product_decode_loop(m, tokens, mask, 8, "audio")
@@ -257,10 +256,10 @@ def test_topk_sampling_kernel_distribution_and_threshold():
     logits = base.unsqueeze(0).repeat(M, 1).contiguous().cuda()
     forbid = torch.full((M,), FB, dtype=torch.int32, device="cuda")
     out = torch.zeros(M, 1, dtype=torch.int32, device="cuda")
-    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(3, dtype=torch.int32, device="cuda")     # [draw index, seed word lo, hi]
 
     def draw(topk, cnt):
-        counter.fill_(cnt)
+        counter[0] = cnt
         check(lib.ua2_sample_topk(1, M, logits.data_ptr(), V, V, topk, C.c_float(T), forbid.data_ptr(), 888, counter.data_ptr(), 2,
                                   out.data_ptr(), 1, 0, None, 0, 0, None, ops.stream()), "ua2_sample_topk")
         return out[:, 0].cpu().long()
@@ -290,6 +289,14 @@ def test_model_topk_sampling_runs_and_is_reproducible(golden, sd):
     assert (a[:, :, 0] < 512).all() and (a[:, :, 1:] < 110).all() and (a >= 0).all()
     # same seed but the draw index keeps counting across utterances (like torch's global generator): streams differ
     assert not torch.equal(a, b)
+    # re-seeding with topk / temperature unchanged must take effect although the captured frame graph is reused
+    # (the seed lives in device memory, counters[2..3]); same seed + same draw index -> same stream
+    runs = []
+    for seed in (888, 889, 888):
+        m.set_sampling(20, 0.9, seed=seed)
+        m._st["counters"][1] = 0
+        runs.append(product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"])
+    assert torch.equal(runs[0], runs[2]) and not torch.equal(runs[0], runs[1])
     m.reset_caches()
 
 
@@ -304,7 +311,7 @@ def test_multinomial_reference_self_test_distribution():
     V, M = ps.numel(), 4000
     logits = torch.log(ps).unsqueeze(0).repeat(M, 1).contiguous().cuda()
     out = torch.zeros(M, 1, dtype=torch.int32, device="cuda")
-    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(3, dtype=torch.int32, device="cuda")     # [draw index, seed word lo, hi]
     check(lib.ua2_sample_topk(1, M, logits.data_ptr(), V, V, V, C.c_float(1.0), None, 1234, counter.data_ptr(), 0,
                               out.data_ptr(), 1, 0, None, 0, 0, None, ops.stream()), "ua2_sample_topk")
     cnts = torch.bincount(out[:, 0].cpu().long(), minlength=V).float()

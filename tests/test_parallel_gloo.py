@@ -81,3 +81,39 @@ def test_shard_indices_longest_first():
     lengths = [5, 50, 7, 40, 30]
     assert shard_indices(lengths, 2, 0) == [1, 4, 0] and shard_indices(lengths, 2, 1) == [3, 2]
     assert shard_indices(lengths, 1, 0) == [1, 3, 4, 2, 0]
+
+
+def _worker_failing(rank, world, port, n, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uniaudio2_amd.parallel import Failed, run_sharded
+
+    def gen(i):
+        if i == 2:
+            raise RuntimeError("no semantic frames were produced")      # what PhaseSplitter.result raises
+        return fake_generate(i)
+
+    out = run_sharded(list(range(n)), [1] * n, gen)
+    ok = sorted(out) == list(range(n)) and isinstance(out[2], Failed)
+    for i in range(n):
+        if i != 2:
+            ok = ok and torch.equal(out[i][0], fake_generate(i)[0])
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_failed_utterance_travels_as_sentinel_world2():
+    """One utterance raising on its rank must not leave the other rank waiting in the all-gather: it is gathered as
+    the sentinel T = -1 and surfaces as parallel.Failed on every rank."""
+    n, world = 5, 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_failing, args=(world, 29595, n, ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world))
+
+
+def test_utterance_seeds_are_distinct_and_sharding_independent():
+    from uniaudio2_amd.parallel import utterance_seed
+    keys = {utterance_seed(888, i) for i in range(512)} | {utterance_seed(889, i) for i in range(512)}
+    assert len(keys) == 1024 and all(0 <= k < 2 ** 64 for k in keys)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libua2hip.so")
 
 UA2_F32, UA2_BF16 = 0, 1
-PRO_CAST, PRO_NORM, PRO_ATTN, PRO_LOCAL_ATTN = 0, 1, 2, 3
+PRO_CAST, PRO_NORM, PRO_LOCAL_ATTN = 0, 1, 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE, EPI_GELU = 0, 1, 2, 3, 4
 NORM_RMS_LIT, NORM_RMS_MOSHI, NORM_LAYERNORM = 0, 1, 2
 ROPE_HALF_SPLIT, ROPE_INTERLEAVED, ROPE_NONE = 0, 1, 2
@@ -33,7 +33,7 @@ class KvGeom(C.Structure):
 
 class LinearArgs(C.Structure):
     _fields_ = [("dtype", i32), ("prologue", i32), ("epilogue", i32), ("M", i32), ("N", i32), ("K", i32),
-                ("x", vp), ("ldx", i32), ("norm_w", vp), ("eps", f32), ("attn_o", vp), ("attn_ml", vp),
+                ("x", vp), ("ldx", i32), ("norm_w", vp), ("eps", f32),
                 ("w0", vp), ("w1", vp), ("y", vp), ("ldy", i32), ("resid", vp), ("ldr", i32),
                 ("part_max", vp), ("part_idx", vp), ("forbid", vp), ("row_pos", vp), ("row_seq", vp),
                 ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom),
@@ -42,8 +42,8 @@ class LinearArgs(C.Structure):
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("attn_o", vp),
-                ("attn_ml", vp), ("grid_pages", i32), ("kv", KvGeom), ("y", vp), ("window", i32), ("y_packed", vp)]
+    _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("kv", KvGeom), ("y", vp),
+                ("window", i32), ("y_packed", vp)]
 
 
 class Conv1dArgs(C.Structure):
@@ -100,8 +100,7 @@ _EXPORTS = {
     "ua2_stage3_create": (C.c_int, [C.POINTER(Stage3Desc), C.POINTER(vp)]),
     "ua2_stage3_destroy": (None, [vp]),
     "ua2_sample_topk": (C.c_int, [C.c_int, i32, vp, i32, i32, i32, f32, vp, C.c_uint64, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp]),
-    "ua2_stage3_set_sampling": (C.c_int, [vp, i32, f32, C.c_uint64]),
-    "ua2_stage3_set_grid_pages": (C.c_int, [vp, i32]),
+    "ua2_stage3_set_sampling": (C.c_int, [vp, i32, f32, C.c_uint64, vp]),
     "ua2_stage3_trunk": (C.c_int, [vp, i32, vp]),
     "ua2_stage3_heads": (C.c_int, [vp, i32, vp]),
     "ua2_stage3_feedback": (C.c_int, [vp, i32, i32, i32, i32, vp]),

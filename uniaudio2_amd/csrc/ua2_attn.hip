@@ -5,12 +5,9 @@
 // reference ("key position <= query position", build_mask_cache :863-866 gathered by
 // input_pos :137) is applied as a length: row r attends to positions 0..row_pos[r].
 //
-// MI355X design: one workgroup per (row, kv-head, page): the K and V
-// pages (64 positions x head_size, contiguous in the pool) are each read exactly once with
-// 16-byte lane loads and shared by the q_per_kv query heads of the group (no repeat_interleave
-// copies); softmax statistics are per page (flash-decoding split), un-normalised partials go to
-// HBM (a few KB) and are merged by the O-projection's prologue (UA2_PRO_ATTN) in page order, so
-// the summation order depends only on the position, never on the batch.
+// MI355X design: one workgroup per (row, kv-head) walks positions 0..row_pos once; the K and V rows
+// are read with 16-byte lane loads and shared by the q_per_kv query heads of the group (no repeat_interleave
+// copies); the summation order depends only on the position, never on the batch.
 #include <algorithm>
 
 #include "ua2_common.h"
@@ -18,156 +15,7 @@
 
 namespace {
 
-constexpr int kAttnThreads = 256;
 constexpr int kMaxG = 4;  // query heads per kv head (Llama-3.2-3B: 3, local decoder: 4)
-
-template <int DT, int HS>
-__global__ __launch_bounds__(kAttnThreads) void attn_kernel(const ua2_attn_args a) {
-  constexpr int EPL = Elem<DT>::EPL;
-  constexpr int LPR = HS / EPL;        // lanes per cache row
-  constexpr int RPW = 64 / LPR;        // rows per wave instruction
-  constexpr int ROWS_PER_WAVE = UA2_PAGE / 4;
-  static_assert(LPR <= 64 && (64 % LPR) == 0, "head size / dtype combination not supported");
-  __shared__ float sc[kMaxG][UA2_PAGE];          // scores, then probabilities
-  __shared__ float ored[4][kMaxG][HS];           // per-wave partial outputs
-
-  const int r = blockIdx.x, kvh = blockIdx.y, pg = blockIdx.z;
-  const int pos = a.row_pos[r];
-  if (pg * UA2_PAGE > pos) return;
-  const int nvalid = min(UA2_PAGE, pos + 1 - pg * UA2_PAGE);
-  const int G = a.kv.n_head / a.kv.n_kv;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = lane % LPR, rin = lane / LPR;
-  const int page = a.kv.page_table[(size_t)(a.row_seq ? a.row_seq[r] : r) * a.kv.max_pages + pg];
-  const size_t pbase = ((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE * HS;
-  const float scale = 1.0f / sqrtf((float)HS);
-
-  // q fragments for the G heads of this group
-  float q[kMaxG][EPL];
-#pragma unroll
-  for (int h = 0; h < kMaxG; ++h) {
-    if (h < G) {
-      const float* qp = a.q + ((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + sub * EPL;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) q[h][e] = qp[e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) q[h][e] = 0.f;
-    }
-  }
-
-  // phase 1: scores
-#pragma unroll
-  for (int it = 0; it < ROWS_PER_WAVE / RPW; ++it) {
-    const int j = wave * ROWS_PER_WAVE + it * RPW + rin;
-    float kf[EPL];
-    if (j < nvalid) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>((const char*)a.kv.k_pool +
-                                                        (pbase + (size_t)j * HS + sub * EPL) * Elem<DT>::BYTES);
-      if constexpr (DT == UA2_BF16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          kf[2 * e] = __uint_as_float(raw[e] << 16);
-          kf[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) kf[e] = __uint_as_float(raw[e]);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) kf[e] = 0.f;
-    }
-#pragma unroll
-    for (int h = 0; h < kMaxG; ++h) {
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) d += q[h][e] * kf[e];
-#pragma unroll
-      for (int o = LPR / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-      if (sub == 0 && h < G) sc[h][j] = (j < nvalid) ? d * scale : -INFINITY;
-    }
-  }
-  __syncthreads();
-
-  // phase 2: per-page softmax statistics, one wave per head (64 positions = 64 lanes)
-  if (wave < G) {
-    const float s = sc[wave][lane];
-    float mx = s;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float p = (lane < nvalid) ? expf(s - mx) : 0.f;
-    float sum = p;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-    sc[wave][lane] = p;
-    if (lane == 0) {
-      float* ml = a.attn_ml + (((size_t)r * a.kv.n_head + (size_t)kvh * G + wave) * a.kv.max_pages + pg) * 2;
-      ml[0] = mx;
-      ml[1] = sum;
-    }
-  }
-  __syncthreads();
-
-  // phase 3: o[h][d] = sum_j p[h][j] * V[j][d]
-  float acc[kMaxG][EPL];
-#pragma unroll
-  for (int h = 0; h < kMaxG; ++h)
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[h][e] = 0.f;
-#pragma unroll
-  for (int it = 0; it < ROWS_PER_WAVE / RPW; ++it) {
-    const int j = wave * ROWS_PER_WAVE + it * RPW + rin;
-    if (j < nvalid) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>((const char*)a.kv.v_pool +
-                                                        (pbase + (size_t)j * HS + sub * EPL) * Elem<DT>::BYTES);
-      float vf[EPL];
-      if constexpr (DT == UA2_BF16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vf[2 * e] = __uint_as_float(raw[e] << 16);
-          vf[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vf[e] = __uint_as_float(raw[e]);
-      }
-#pragma unroll
-      for (int h = 0; h < kMaxG; ++h) {
-        if (h < G) {
-          const float p = sc[h][j];
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) acc[h][e] += p * vf[e];
-        }
-      }
-    }
-  }
-  // reduce over the RPW row groups of the wave (lanes with equal `sub`), then over waves
-#pragma unroll
-  for (int h = 0; h < kMaxG; ++h)
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      float t = acc[h][e];
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o);
-      acc[h][e] = t;
-    }
-  if (rin == 0) {
-#pragma unroll
-    for (int h = 0; h < kMaxG; ++h)
-      if (h < G) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) ored[wave][h][sub * EPL + e] = acc[h][e];
-      }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < G * HS; idx += kAttnThreads) {
-    const int h = idx / HS, d = idx - h * HS;
-    const float t = ((ored[0][h][d] + ored[1][h][d]) + ored[2][h][d]) + ored[3][h][d];
-    a.attn_o[(((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * a.kv.max_pages + pg) * HS + d] = t;
-  }
-}
-
 
 // ---- single-pass variant: one workgroup per (row, kv-head) --------------------------------------
 // After the first profiles (profiles/r1_a, r1_b): at B = 1 attention is pure latency, so
@@ -391,12 +239,8 @@ void launch_fused_hs(const ua2_attn_args& a, hipStream_t s) {
   constexpr int EPL = Elem<DT>::EPL, RPW = 64 / (HS / EPL), NS = kFusedWaves * RPW;
   const int G = a.kv.n_head / a.kv.n_kv;
   const size_t smem = (size_t)(2 * NS * kMaxG + (size_t)NS * G * HS) * sizeof(float);
-  auto kern = attn_fused_kernel<DT, HS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  constexpr auto kern = attn_fused_kernel<DT, HS>;
+  ua2_allow_big_lds<kern>();
   hipLaunchKernelGGL(kern, dim3(a.R, a.kv.n_kv), dim3(kFusedWaves * 64), smem, s, a);
 }
 
@@ -452,39 +296,17 @@ int launch_local(const ua2_attn_args& a, hipStream_t s) {
   return 0;
 }
 
-template <int DT>
-int launch_hs(const ua2_attn_args& a, hipStream_t s) {
-  const int gp = a.grid_pages > 0 ? a.grid_pages : a.kv.max_pages;
-  const dim3 grid(a.R, a.kv.n_kv, gp), block(kAttnThreads);
-  switch (a.kv.head_size) {
-    case 32: hipLaunchKernelGGL((attn_kernel<DT, 32>), grid, block, 0, s, a); break;
-    case 64: hipLaunchKernelGGL((attn_kernel<DT, 64>), grid, block, 0, s, a); break;
-    case 128: hipLaunchKernelGGL((attn_kernel<DT, 128>), grid, block, 0, s, a); break;
-    default:
-      ua2_set_error("ua2_attn: head_size %d not supported (32, 64, 128)", a.kv.head_size);
-      return -1;
-  }
-  UA2_LAUNCH_CHECK();
-  return 0;
-}
-
 }  // namespace
 
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
   UA2_CHECK(a.R > 0, "ua2_attn: R=%d", a.R);
-  UA2_CHECK(a.q && a.row_pos && (a.y || a.y_packed || (a.attn_o && a.attn_ml)) && a.kv.k_pool && a.kv.v_pool &&
-                a.kv.page_table,
+  UA2_CHECK(a.q && a.row_pos && (a.y || a.y_packed) && a.kv.k_pool && a.kv.v_pool && a.kv.page_table,
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
-  UA2_CHECK(a.y || a.y_packed || a.grid_pages <= a.kv.max_pages, "ua2_attn: grid_pages > max_pages");
   UA2_CHECK(!a.y_packed || (a.kv.n_head * a.kv.head_size) % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_attn: y_packed needs n_head*head_size %% chunk == 0");
-  if (a.y || a.y_packed) {
-    if (a.dtype == UA2_BF16) return launch_fused<UA2_BF16>(a, s);
-    if (a.dtype == UA2_F32) return launch_fused<UA2_F32>(a, s);
-  }
-  if (a.dtype == UA2_BF16) return launch_hs<UA2_BF16>(a, s);
-  if (a.dtype == UA2_F32) return launch_hs<UA2_F32>(a, s);
+  if (a.dtype == UA2_BF16) return launch_fused<UA2_BF16>(a, s);
+  if (a.dtype == UA2_F32) return launch_fused<UA2_F32>(a, s);
   ua2_set_error("ua2_attn: bad dtype %d", a.dtype);
   return -1;
 }

@@ -1,6 +1,7 @@
 // Internal helpers shared by the gfx950 kernels of libua2hip.so (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -84,6 +85,20 @@ __device__ __forceinline__ void store_packed_operand(void* base, int m, int k, i
 }
 
 static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised.  The
+// attribute is per device, so it is set once per (kernel instantiation, device ordinal); safe to race (the call is
+// idempotent, the flag only saves the repeat).
+template <auto Kern>
+inline void ua2_allow_big_lds() {
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 // internal launchers used by both the op-level ABI and the frame executor
 int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);

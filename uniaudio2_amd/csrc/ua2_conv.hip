@@ -195,13 +195,9 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
   const int W = (bt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
   const size_t smem = (size_t)kCIG * (W + 1) * sizeof(float) + (size_t)kCIG * a->K * sizeof(int);
   UA2_CHECK(smem <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  ua2_allow_big_lds<conv1d_kernel<4>>();
+  ua2_allow_big_lds<conv1d_kernel<2>>();
+  ua2_allow_big_lds<conv1d_kernel<1>>();
   const dim3 grid(ua2_ceil_div(tq, bt), row_blocks, a->B);
   if (ntt == 4) hipLaunchKernelGGL(conv1d_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, *a);
   else if (ntt == 2) hipLaunchKernelGGL(conv1d_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, *a);

@@ -364,12 +364,8 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const ua2_linear_args a, c
 template <int DT, int EPI>
 void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t s) {
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
-  auto kern = skinny_kernel<DT, EPI, 4>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  constexpr auto kern = skinny_kernel<DT, EPI, 4>;
+  ua2_allow_big_lds<kern>();
   const size_t smem = (size_t)geo.waves * NT * kSkinnyMT * 256 * sizeof(float);
   const dim3 grid(ua2_ceil_div(a.N, 16), ua2_ceil_div(ua2_ceil_div(a.M, 16), kSkinnyMT));
   hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace));

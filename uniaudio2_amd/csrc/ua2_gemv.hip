@@ -333,12 +333,8 @@ Geometry pick_geometry(int nchunks, int blocks, int nt) {
 
 template <int DT, int PRO, int EPI, int CPW, bool MR>
 void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, int red_off, size_t smem, hipStream_t s, int rt) {
-  auto kern = gemv_kernel<DT, PRO, EPI, CPW, MR>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  constexpr auto kern = gemv_kernel<DT, PRO, EPI, CPW, MR>;
+  ua2_allow_big_lds<kern>();
   hipLaunchKernelGGL(kern, grid, dim3(waves * 64), smem, s, a, a_stride, red_off, rt);
 }
 
@@ -405,7 +401,6 @@ ua2_gemv_geometry ua2_pick_gemv_geometry(int dtype, int N, int K, int nt) {
 // Returns 0 if launched, 1 if this problem is outside the decode regime (caller uses the general
 // kernel), negative on error.
 int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s) {
-  if (a.prologue == UA2_PRO_ATTN) return 1;
   if (rows_per_tile(a.dtype, a.K) < 1) return 1;   // a single row does not fit the LDS budget
   if (a.dtype == UA2_BF16) return launch_dt<UA2_BF16>(a, s);
   if (a.dtype == UA2_F32) return launch_dt<UA2_F32>(a, s);

@@ -7,8 +7,8 @@
 // The k-th largest value is found exactly with a 4-pass radix select (8 bits per pass) on the
 // order-preserving integer image of the fp32 logits, one workgroup per row (the row is L2-resident:
 // 513 KB for the text head); softmax normalisation is dropped (it does not move the arg-max).
-// Randomness: counter-based Philox4x32-10 keyed by (seed, draw index from the device frame counter,
-// row, stream) — reproducible under hipGraph replay and independent of launch geometry.  It cannot
+// Randomness: counter-based Philox4x32-10 keyed by (seed + the 64-bit device word counter[1..2], draw index
+// counter[0] from the device frame counter, row, stream) — reproducible under hipGraph replay and independent of launch geometry.  It cannot
 // reproduce torch's generator stream; parity with the reference is distributional (tests).
 #include "ua2_common.h"
 
@@ -82,6 +82,8 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restri
   for (int w = 1; w < (nt >> 6); ++w) mx = fmaxf(mx, red_v[w]);
   __syncthreads();
   const unsigned draw = (unsigned)counter[0];
+  // device-resident part of the key (ua2_stage3_set_sampling writes it): added to the by-value seed
+  seed += (unsigned long long)(unsigned)counter[1] | ((unsigned long long)(unsigned)counter[2] << 32);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   for (int c = fb + tid; c < V; c += nt) {

@@ -30,17 +30,15 @@ struct ua2_stage3 {
   size_t gemm_ws_bytes;
   void* act_ws;                // packed SwiGLU output handed straight to the down-projection (max_rows x widest intermediate)
   int32_t npart_t, npart_a;
-  int32_t grid_pages;
   int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
   float temperature = 1.f;
-  uint64_t seed = 0;
   hipStream_t cap_stream = nullptr;
   // optional (UA2_FORK_LM_HEAD=1): lm_head + text arg-max on a side stream, concurrent with the 8-step
   // local decoder (they only share read-only inputs)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
   float cfg_scale = 1.f;       // > 1: classifier-free guidance over a (conditional, unconditional) row pair
-  std::map<std::tuple<int, int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
+  std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
 };
 
 namespace {
@@ -85,7 +83,7 @@ void fresh_args(const ua2_stage3* h, ua2_linear_args& a) {
 
 // local = the depth decoder: positions < kLocalCtx, short-context attention (fused into the O-projection when R == 1)
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
-            const int32_t* row_seq, int grid_pages, hipStream_t s, bool local = false) {
+            const int32_t* row_seq, hipStream_t s, bool local = false) {
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   for (int l = 0; l < g.n_layer; ++l) {
@@ -208,7 +206,6 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->gemm_ws = b + c.gemm_ws; h->gemm_ws_bytes = c.gemm_ws_floats * sizeof(float);
   h->act_ws = b + c.act_ws;
   h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
-  h->grid_pages = d->backbone.max_pages;
   *out = h;
   return 0;
 }
@@ -223,12 +220,6 @@ extern "C" void ua2_stage3_destroy(ua2_stage3* h) {
   delete h;
 }
 
-extern "C" int ua2_stage3_set_grid_pages(ua2_stage3* h, int32_t pages) {
-  UA2_CHECK(h && pages > 0 && pages <= h->d.backbone.max_pages, "ua2_stage3_set_grid_pages: bad value %d", pages);
-  h->grid_pages = pages;
-  return 0;
-}
-
 // identity: rows are sequences 0..R-1 (decode frames) -> no row_seq indirection in the kernels
 static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_rows, "ua2_stage3_trunk: R=%d out of range", R);
@@ -236,23 +227,29 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   if (identity) d.row_seq = nullptr;
   const int C = d.backbone.n_embd, w = d.n_cb + 1;
   if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, s)) return rc;
-  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
+  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s)) return rc;
   // backbone_input = h_audio*audio_step + text_embeds*text_step   (model_new.py:607)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, s)) return rc;
-  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
+  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s)) return rc;
   // h = ln_f(x); generation_input = h*audio_step                   (model_new.py:609-610)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, s)) return rc;
-  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, h->grid_pages, s)) return rc;
+  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s)) return rc;
   // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, s)) return rc;
   return 0;
 }
 
-extern "C" int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed) {
+__global__ void set_seed_kernel(int32_t* c, uint32_t lo, uint32_t hi) { c[2] = (int32_t)lo; c[3] = (int32_t)hi; }
+
+// The seed lives in device memory (counters[2..3]) and the samplers read it there, so a captured frame graph
+// serves every seed: re-seeding between utterances is one 8-byte store on the caller's stream, never a re-capture.
+extern "C" int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed, void* stream) {
   UA2_CHECK(h != nullptr, "ua2_stage3_set_sampling: NULL handle");
   UA2_CHECK(temperature > 0.f, "temperature must be > 0");
   UA2_CHECK(topk >= 1 && topk <= h->d.va, "topk must be in 1..%d", h->d.va);
-  h->topk = topk; h->temperature = temperature; h->seed = seed;
+  h->topk = topk; h->temperature = temperature;
+  hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d.counters, (uint32_t)seed, (uint32_t)(seed >> 32));
+  UA2_LAUNCH_CHECK();
   return 0;
 }
 
@@ -306,7 +303,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
   } else {   // model_new.py:623 sample_topk(text_logits, topk, temperature)
     for (int rep = 0; rep < (cfg ? 2 : 1); ++rep)   // guidance: the same draw (row key 0) written to both rows
       if (int rc = ua2_sample_topk(d.dtype, cfg ? 1 : R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature,
-                                   nullptr, h->seed, d.counters + 1, 0, d.out_tokens + (size_t)rep * w, w, 0, nullptr, 0, C,
+                                   nullptr, 0, d.counters + 1, 0, d.out_tokens + (size_t)rep * w, w, 0, nullptr, 0, C,
                                    nullptr, side)) return rc;
   }
   if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
@@ -316,7 +313,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
     if (int rc = ua2_linear_launch(a, s)) return rc;
-    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, 1, s, d.n_cb <= 8)) return rc;
+    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
@@ -332,7 +329,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
     } else {   // model_new.py:639 audio_sample_topk(ci_logits, topk, temperature, forbid_prefix)
       for (int rep = 0; rep < (cfg ? 2 : 1); ++rep)
         if (int rc = ua2_sample_topk(d.dtype, cfg ? 1 : R, h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->topk,
-                                     h->temperature, d.forbid, h->seed, d.counters + 1, 1 + i, d.out_tokens + (size_t)rep * w, w,
+                                     h->temperature, d.forbid, 0, d.counters + 1, 1 + i, d.out_tokens + (size_t)rep * w, w,
                                      1 + i, d.audio_emb, i * d.va, C, h->curr_h + (size_t)rep * C, s)) return rc;
     }
     curr = h->curr_h;
@@ -372,7 +369,7 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
   int tbits, cbits;
   memcpy(&tbits, &h->temperature, sizeof(int));
   memcpy(&cbits, &h->cfg_scale, sizeof(int));
-  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->grid_pages, (int)h->topk, tbits, cbits);
+  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->topk, tbits, cbits);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;

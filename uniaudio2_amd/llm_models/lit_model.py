@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_SWIGLU, PRO_ATTN, PRO_CAST, PRO_NORM, UA2_PAGE,
+from .._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_SWIGLU, PRO_CAST, PRO_NORM, UA2_PAGE,
                     GptDesc, vp)
 from .config import Config
 
@@ -204,23 +204,21 @@ class GPT(nn.Module):
         out = ops.rmsnorm_blend(xs, p["ln_f"], cfg.norm_eps)
         return out.view(B, T, Cc)
 
-    def _layers(self, xs, R, row_pos, row_seq, grid_pages=0):
+    def _layers(self, xs, R, row_pos, row_seq):
         cfg, p, kv = self.config, self.plan, self.kv_cache
         dt, dev = p["dtype"], xs.device
         nh, ng, hs, Cc, I = cfg.n_head, cfg.n_query_groups, cfg.head_size, cfg.n_embd, cfg.intermediate_size
         q = torch.empty(R, nh * hs, dtype=torch.float32, device=dev)
         act = torch.empty(R, I, dtype=torch.float32, device=dev)
-        ao = torch.empty(R, nh, kv.max_pages, hs, dtype=torch.float32, device=dev)
-        aml = torch.empty(R, nh, kv.max_pages, 2, dtype=torch.float32, device=dev)
+        ya = torch.empty(R, nh * hs, dtype=torch.float32, device=dev)
         for l in range(cfg.n_layer):
             geom = ops.kv_geom(kv.k[l], kv.v[l], kv.page_table, nh, ng, hs)
             ops.linear(dtype=dt, M=R, N=(nh + 2 * ng) * hs, K=Cc, w0=p["qkv"][l], prologue=PRO_NORM,
                        epilogue=EPI_QKV_ROPE, x=xs, norm_w=p["norm1"][l], eps=cfg.norm_eps, row_pos=row_pos,
                        row_seq=row_seq, rope_cos=p["cos"], rope_sin=p["sin"], q_out=q, kv=geom)
-            ops.attn(dtype=dt, R=R, q=q, row_pos=row_pos, row_seq=row_seq, attn_o=ao, attn_ml=aml, kv=geom,
-                     grid_pages=grid_pages)
-            ops.linear(dtype=dt, M=R, N=Cc, K=nh * hs, w0=p["proj"][l], prologue=PRO_ATTN, epilogue=EPI_RESIDUAL,
-                       attn_o=ao, attn_ml=aml, row_pos=row_pos, y=xs, resid=xs, kv=geom)
+            ops.attn(dtype=dt, R=R, q=q, row_pos=row_pos, row_seq=row_seq, kv=geom, y=ya)
+            ops.linear(dtype=dt, M=R, N=Cc, K=nh * hs, w0=p["proj"][l], prologue=PRO_CAST, epilogue=EPI_RESIDUAL,
+                       x=ya, y=xs, resid=xs)
             ops.linear(dtype=dt, M=R, N=I, K=Cc, w0=p["fc1"][l], w1=p["fc2"][l], prologue=PRO_NORM,
                        epilogue=EPI_SWIGLU, x=xs, norm_w=p["norm2"][l], eps=cfg.norm_eps, y=act)
             ops.linear(dtype=dt, M=R, N=Cc, K=I, w0=p["mlp_proj"][l], prologue=PRO_CAST, epilogue=EPI_RESIDUAL,

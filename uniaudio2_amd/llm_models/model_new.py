@@ -71,6 +71,7 @@ class Model_stage3(nn.Module):
                                            device=device, with_embeddings=False)
         self._h = None
         self._st = None
+        self.sampling_seed = None      # set by callers that key the sampler themselves (CLI: per-utterance keys)
 
     # ---- caches / device plan ----------------------------------------------------------------
     def setup_caches(self, max_batch_size: int, dtype: Optional[torch.dtype] = None, max_seq_length: int = 2048,
@@ -130,9 +131,9 @@ class Model_stage3(nn.Module):
         check(lib.ua2_stage3_create(C.byref(d), C.byref(h)), "ua2_stage3_create")
         st["keep"] = (d, gd, ah)
         self._h, self._st = h, st
-        self._grid_pages = None
         self._sampling = None
         self._cfg = 1.0
+        self._pos_hi = 0
 
     def _destroy(self):
         if self._h is not None:
@@ -156,11 +157,15 @@ class Model_stage3(nn.Module):
         if self._h is None:
             raise TypeError("You need to call `model.setup_caches()`")
 
-    def _set_grid_pages(self, max_pos: int):
-        pages = min(self.backbone.kv_cache.max_pages, max_pos // ops.UA2_PAGE + 1)
-        if pages != self._grid_pages:
-            check(lib.ua2_stage3_set_grid_pages(self._h, pages), "ua2_stage3_set_grid_pages")
-            self._grid_pages = pages
+    def _check_positions(self, max_pos: int):
+        """Every position a launch touches must lie inside the caches planned by setup_caches: the QKV epilogue
+        indexes the RoPE tables and the page table by position, so a position past the end would write K/V into
+        another sequence's pages.  The reference fails loudly in the same situation (`index_copy_` on the
+        2048-slot cache, lit_model.py:831-856); so does this."""
+        limit = self.backbone.plan["max_seq"]
+        if max_pos >= limit or max_pos < 0:
+            raise ValueError(f"position {max_pos} is outside the KV cache / RoPE tables planned for max_seq_length="
+                             f"{limit} (setup_caches); shorten the prompt, generate fewer frames or plan a longer cache")
 
     def _load_rows(self, tokens, tokens_mask, pos, seq):
         """tokens (R, 9) any int dtype, mask (R, 9) bool, pos (R,), seq (R,) -> device state."""
@@ -193,7 +198,8 @@ class Model_stage3(nn.Module):
         # time-major chunks so every chunk only needs KV of earlier chunks
         order = torch.argsort(ps, stable=True)
         tk, mk, ps, sq = tk[order], mk[order], ps[order], sq[order]
-        self._set_grid_pages(int(ps.max().item()))
+        self._check_positions(int(ps.max().item()))
+        self._check_positions(int(ps.min().item()))
         R, mr = B * S, st["max_rows"]
         for s0 in range(0, R, mr):
             n = self._load_rows(tk[s0:s0 + mr], mk[s0:s0 + mr], ps[s0:s0 + mr], sq[s0:s0 + mr])
@@ -220,7 +226,8 @@ class Model_stage3(nn.Module):
         seq = torch.arange(B, device=tokens.device)
         self._load_rows(tokens.reshape(B, W), tokens_mask.reshape(B, W), pos, seq)
         st["forbid"][:B].fill_(int(forbid_prefix))
-        self._set_grid_pages(int(input_pos_maxp1) if input_pos_maxp1 is not None else int(pos.max().item()) + 1)
+        self._check_positions(int(pos.max().item()))
+        self._check_positions(int(pos.min().item()))
         check(lib.ua2_stage3_frame(self._h, B, -1, 0, 0, 1, ops.stream()), "ua2_stage3_frame")
         return st["out_tokens"][:B].clone()
 
@@ -235,10 +242,10 @@ class Model_stage3(nn.Module):
         if topk <= 0 or topk > va:
             raise ValueError(f"topk must be in 1..{va}")
         if seed is None:
-            seed = torch.initial_seed()
+            seed = self.sampling_seed if self.sampling_seed is not None else torch.initial_seed()
         key = (int(topk), float(temperature), int(seed) & (2 ** 64 - 1))
         if getattr(self, "_sampling", None) != key:
-            check(lib.ua2_stage3_set_sampling(self._h, key[0], key[1], key[2]), "ua2_stage3_set_sampling")
+            check(lib.ua2_stage3_set_sampling(self._h, key[0], key[1], key[2], ops.stream()), "ua2_stage3_set_sampling")
             self._sampling = key
 
     def set_cfg(self, cfg_scale: float = 1.0):
@@ -265,9 +272,14 @@ class Model_stage3(nn.Module):
         start = int(st["counters"][0].item())
         if start + n_frames > st["log_frames"]:
             raise ValueError("frame log too small: raise log_frames in setup_caches")
-        if max_pos is None:
-            max_pos = int(st["row_pos"][:batch].max().item()) + n_frames
-        self._set_grid_pages(max_pos)
+        # the last frame of this call reads / writes position (current max row_pos) + n_frames - 1.  The host-side bound
+        # `_pos_hi` avoids a device sync; it can only over-estimate (after retirements), so the exact value is fetched
+        # before refusing.  `max_pos` is accepted for compatibility with round-1 callers and ignored.
+        limit = self.backbone.plan["max_seq"]
+        if self._pos_hi + n_frames - 1 >= limit:
+            self._pos_hi = int(st["row_pos"][:batch].max().item())
+            self._check_positions(self._pos_hi + n_frames - 1)
+        self._pos_hi += n_frames
         s = ops.stream()
         for _ in range(n_frames):
             check(lib.ua2_stage3_frame(self._h, batch, mode, reason_eos, reason_card, int(use_graph), s),
@@ -291,7 +303,7 @@ class Model_stage3(nn.Module):
         sq = torch.cat([torch.full((t.shape[0],), b, device=dev) for b, t in enumerate(tokens_list)])
         order = torch.argsort(ps, stable=True)
         tk, mk, ps, sq = tk[order], mk[order], ps[order], sq[order]
-        self._set_grid_pages(int(ps.max().item()))
+        self._check_positions(int(ps.max().item()))
         R, mr = tk.shape[0], st["max_rows"]
         for s0 in range(0, R, mr):
             n = self._load_rows(tk[s0:s0 + mr], mk[s0:s0 + mr], ps[s0:s0 + mr], sq[s0:s0 + mr])
@@ -368,6 +380,10 @@ class Model_stage3(nn.Module):
         pos = input_pos.reshape(-1)
         if pos.numel() == 1:
             pos = pos.expand(B)
+        lo, hi = int(pos.min().item()), int(pos.max().item())
+        self._check_positions(lo)
+        self._check_positions(hi)
+        self._pos_hi = hi
         self._load_rows(tokens.reshape(B, W), tokens_mask.reshape(B, W), pos, torch.arange(B, device=tokens.device))
         self._st["forbid"][:B].fill_(int(forbid_prefix))
 

@@ -93,6 +93,7 @@ def _load_config_and_llm(args):
     with open(args.llm_train_config, "r", encoding="utf-8") as f:
         train_args = argparse.Namespace(**yaml.safe_load(f))
     torch.manual_seed(args.seed)
+    random.seed(args.seed)            # every rank draws the same task prompt from --prompt_json (random.choice below)
     if not torch.cuda.is_available():
         raise RuntimeError("uniaudio2_amd needs a ROCm GPU (no CPU fallback)")
     rank = int(os.environ.get("LOCAL_RANK", getattr(args, "rank", 0)))
@@ -183,11 +184,20 @@ def run_understanding(args):
             reason = torch.load(rp, map_location="cpu").transpose(0, 1).long()          # (T, 8), :304-308
             semantic = torch.load(sp, map_location="cpu").transpose(0, 1).long()
             if task == "audio_understanding":
-                question = (args.question or "").strip() or "What is described in this audio?"
+                question = (args.question or "").strip()
+                if not question and args.question_file and os.path.isfile(args.question_file):      # :345-347
+                    with open(args.question_file, "r", encoding="utf-8") as f:
+                        question = f.read().strip()
+                question = question or "What is described in this audio?"
                 d = {"text_seq_question": torch.tensor(generator._text_tokenizer.tokenize(question), dtype=torch.long),
                      "reason_seq": reason.transpose(0, 1), "semantic_seq": semantic.transpose(0, 1)}
                 text_out = generator.generate_answer(task_prompt, task_name=task, d=d, keys=list(d), types=["text", "audio", "audio"],
                                                      temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
+            elif task == "speech_s2t":                                                             # :363-379: samples with --topk
+                d = {"reason_seq": reason.transpose(0, 1), "semantic_seq": semantic.transpose(0, 1)}
+                text_out = generator.generate_answer(task_prompt, task_name="speech_s2t", d=d, keys=["reason_seq", "semantic_seq"],
+                                                     types=["audio", "audio"], temperature=args.temperature, topk=args.topk,
+                                                     cfg_scale=args.cfg_scale)
             else:
                 text_out = generator.generate_asr(task_prompt, task_name=task, reason_token=reason, semantic_token=semantic,
                                                   temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
@@ -228,22 +238,40 @@ def run_generation_stage1(args):
     extra = (lambda i: {"caption": ids[i]}) if _generation_method_name(task) == "generate_instruct_tts" else (lambda i: {})   # :520-521
 
     def one(i):
+        # the sampler's key folds in the global utterance index: ranks (and utterances) draw from independent
+        # streams, and an utterance's samples do not depend on how the work was sharded
+        model.sampling_seed = parallel.utterance_seed(args.seed, i)
         return gen_fn(task_prompt=task_prompt, task_name=task, text_token=ids[i], temperature=args.temperature,
                       topk=args.topk, cfg_scale=args.cfg_scale, **extra(i))
 
     if args.batch_size > 1 and hasattr(generator, "generate_tts_batch") and _generation_method_name(task) == "generate_tts":
         def many(idx):
+            model.sampling_seed = parallel.utterance_seed(args.seed, idx[0])
             return generator.generate_tts_batch(task_prompt=task_prompt, task_name=task, text_tokens=[ids[i] for i in idx],
                                                 temperature=args.temperature, topk=args.topk, cfg_scale=args.cfg_scale)
         results = parallel.run_sharded_batched(list(range(len(items))), [len(x) for x in ids], many, args.batch_size)
     else:
         results = parallel.run_sharded(list(range(len(items))), [len(x) for x in ids], one)
+    _write_results(args, items, results, "[Stage1]")
+    return args.output_dir
+
+
+def _write_results(args, items, results, tag):
+    """Rank 0 writes the gathered token tensors; an utterance whose generation failed on its rank (parallel.Failed:
+    e.g. the model never produced the semantic phase) is reported after everything else was saved."""
+    from . import parallel
+    failed = []
     if int(os.environ.get("RANK", "0")) == 0:
         for i, (name, _) in enumerate(items):
+            if isinstance(results[i], parallel.Failed):
+                failed.append(name)
+                print(f"[Fail] {name}: {results[i].message}")
+                continue
             reason, semantic = results[i]
             _save_tokens(args, name, reason, semantic)
-            print(f"[Stage1] {name} -> {name}_reason.pt, {name}_semantic.pt")
-    return args.output_dir
+            print(f"{tag} {name} -> {name}_reason.pt, {name}_semantic.pt")
+    if failed:
+        raise RuntimeError(f"{len(failed)} of {len(items)} utterances failed: {', '.join(failed)}")
 
 
 def _run_speech_s2s(args, generator, task_prompt):
@@ -267,15 +295,12 @@ def _run_speech_s2s(args, generator, task_prompt):
         items.append((name, {"reason_seq_1": reason, "semantic_seq_1": semantic, "reason_seq_2": reason, "semantic_seq_2": semantic}))
 
     def one(i):
+        generator._model.sampling_seed = parallel.utterance_seed(args.seed, i)
         return generator.generate_audio(task_prompt=task_prompt, task_name="speech_s2s", d=items[i][1], keys=S2S_KEYS[:-2],
                                         types=S2S_TYPES[:-2], temperature=args.temperature, topk=args.topk, cfg_scale=args.cfg_scale)
 
     results = parallel.run_sharded(list(range(len(items))), [int(d["semantic_seq_1"].shape[-1]) for _, d in items], one)
-    if int(os.environ.get("RANK", "0")) == 0:
-        for i, (name, _) in enumerate(items):
-            reason, semantic = results[i]
-            _save_tokens(args, name, reason, semantic)
-            print(f"[Stage1] speech_s2s {name} -> {name}_reason.pt, {name}_semantic.pt")
+    _write_results(args, items, results, "[Stage1] speech_s2s")
     return args.output_dir
 
 

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_ATTN, PRO_CAST, PRO_NORM, UA2_BF16,
+from ._lib import (EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_CAST, PRO_NORM, UA2_BF16,
                    UA2_F32, UA2_PAGE, AttnArgs, KvGeom, LinearArgs, check, lib)
 
 _CODES = {torch.float32: UA2_F32, torch.bfloat16: UA2_BF16}
@@ -57,7 +57,7 @@ def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
 
 
 def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None, ldx=None, norm_w=None, eps=1e-5,
-           attn_o=None, attn_ml=None, w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
+           w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
            forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True,
            norm_b=None, norm_kind=0, out_scale=None, rope_mode=0, workspace=None):
     a = LinearArgs()
@@ -65,7 +65,6 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
     a.M, a.N, a.K = M, N, K
     a.x, a.ldx = ptr(x), (ldx if ldx is not None else (x.shape[-1] if x is not None else 0))
     a.norm_w, a.eps = ptr(norm_w), eps
-    a.attn_o, a.attn_ml = ptr(attn_o), ptr(attn_ml)
     a.w0, a.w1 = ptr(w0), ptr(w1)
     a.y, a.ldy = ptr(y), (ldy if ldy is not None else (y.shape[-1] if y is not None else 0))
     a.resid, a.ldr = ptr(resid), (ldr if ldr is not None else (resid.shape[-1] if resid is not None else 0))
@@ -96,13 +95,13 @@ def linear_chain_timed(args_list, iters):
     return ms.value / (len(args_list) * iters)
 
 
-def attn(*, dtype, R, q, row_pos, row_seq, kv, attn_o=None, attn_ml=None, grid_pages=0, y=None, window=0):
+def attn(*, dtype, R, q, row_pos, row_seq, kv, y, window=0):
     a = AttnArgs()
     a.y = ptr(y)
     a.window = window
     a.dtype, a.R = dtype_code(dtype), R
     a.q, a.row_pos, a.row_seq = ptr(q), ptr(row_pos), ptr(row_seq)
-    a.attn_o, a.attn_ml, a.grid_pages, a.kv = ptr(attn_o), ptr(attn_ml), grid_pages, kv
+    a.kv = kv
     check(lib.ua2_attn(C.byref(a), stream()), "ua2_attn")
 
 

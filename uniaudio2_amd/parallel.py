@@ -15,6 +15,26 @@ import torch.distributed as dist
 MAX_FRAMES = 500          # evaluation/tts_task.py:222
 
 
+class Failed:
+    """Result slot of an utterance whose generation raised on its rank.  It travels through the all-gather as the
+    sentinel T_r = T_s = -1 (a rank that raised BEFORE the collective would leave the others waiting in it forever)."""
+
+    def __init__(self, message: str = "generation failed on its rank"):
+        self.message = message
+
+    def __repr__(self):
+        return f"Failed({self.message!r})"
+
+
+def utterance_seed(seed: int, index: int) -> int:
+    """Sampler key of utterance `index` (global, i.e. independent of the sharding): distinct, well-mixed 64-bit keys
+    (splitmix64 finaliser) so that ranks never walk the same Philox stream."""
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(index) + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
 def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:
     """Longest-first round-robin: utterance order[i] goes to rank i % world (balances decode time)."""
     order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
@@ -25,7 +45,11 @@ def pack_local(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_local_ma
     """results: global index -> (reason (8,T_r), semantic (8,T_s)) int32.  Fixed-shape buffers for the all-gather."""
     tok = torch.zeros(n_local_max, 2, n_cb, MAX_FRAMES, dtype=torch.int32, device=device)
     meta = torch.full((n_local_max, 3), -1, dtype=torch.int32, device=device)      # (global index, T_r, T_s)
-    for slot, (gi, (r, s)) in enumerate(sorted(results.items())):
+    for slot, (gi, res) in enumerate(sorted(results.items(), key=lambda kv: kv[0])):
+        if isinstance(res, Failed):
+            meta[slot] = torch.tensor([gi, -1, -1], dtype=torch.int32)
+            continue
+        r, s = res
         tok[slot, 0, :, :r.shape[1]] = r.to(device=device, dtype=torch.int32)
         tok[slot, 1, :, :s.shape[1]] = s.to(device=device, dtype=torch.int32)
         meta[slot] = torch.tensor([gi, r.shape[1], s.shape[1]], dtype=torch.int32)
@@ -50,7 +74,7 @@ def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_tota
         for slot in range(n_local_max):
             gi, tr, ts = (int(v) for v in m[slot])
             if gi >= 0:
-                out[gi] = (t[slot, 0, :, :tr].clone(), t[slot, 1, :, :ts].clone())
+                out[gi] = Failed() if tr < 0 else (t[slot, 0, :, :tr].clone(), t[slot, 1, :, :ts].clone())
     return out
 
 
@@ -58,7 +82,12 @@ def run_sharded(items: Sequence, lengths: Sequence[int], generate_fn) -> Dict[in
     """generate_fn(item) -> (reason, semantic); runs this rank's shard, then gathers everything everywhere."""
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    local = {i: generate_fn(items[i]) for i in shard_indices(lengths, world, rank)}
+    local = {}
+    for i in shard_indices(lengths, world, rank):
+        try:
+            local[i] = generate_fn(items[i])
+        except (RuntimeError, ValueError) as e:          # e.g. PhaseSplitter.result: no frames of a phase were produced
+            local[i] = Failed(f"{type(e).__name__}: {e}")
     return gather_results(local, len(items))
 
 
@@ -71,6 +100,10 @@ def run_sharded_batched(items: Sequence, lengths: Sequence[int], generate_batch_
     local = {}
     for s0 in range(0, len(mine), max(1, batch_size)):
         chunk = mine[s0:s0 + max(1, batch_size)]
-        for i, res in zip(chunk, generate_batch_fn([items[i] for i in chunk])):
-            local[i] = res
+        try:
+            for i, res in zip(chunk, generate_batch_fn([items[i] for i in chunk])):
+                local[i] = res
+        except (RuntimeError, ValueError) as e:
+            for i in chunk:
+                local.setdefault(i, Failed(f"{type(e).__name__}: {e}"))
     return gather_results(local, len(items))
