@@ -1,0 +1,159 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the live codec's waveform auto-encoder.
+
+A functional plain-PyTorch (fp32, CPU) restatement of the reference's
+tools/tokenizer/ReasoningCodec_film/models/scalar24k.py `ScalarModel.encode` / `.decode` (:392-407) driven by a
+reference state dict (same keys: `encoder.N...weight_g / weight_v / bias`, `...activation.weight`), plus the codec's
+windowing arithmetic of tools/tokenizer/ReasoningCodec_film/reason_tokenizer.py:229-306 (index lists only).
+Every function cites the reference lines it follows (paths relative to /root/reference).
+
+Pinned against outputs of the reference itself: tests/golden/codec_toy.npz (made by tests/golden/make_golden_codec.py,
+which imports and runs the reference's ScalarModel); checked by tests/test_oracle_codec.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.  The product
+(uniaudio2_amd/) never does and has no CPU fallback.
+"""
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+def _w(sd, prefix):
+    """Effective filter of a conv: weight-norm folded exactly as torch.nn.utils.weight_norm does at forward time
+    (w = g * v / ||v||, norm over all dims but 0), or the plain weight (PreProcessor / PostProcessor convs,
+    scalar24k.py:119,132 have no weight_norm)."""
+    if prefix + "weight_g" in sd:
+        return torch._weight_norm(sd[prefix + "weight_v"].float(), sd[prefix + "weight_g"].float(), 0)
+    return sd[prefix + "weight"].float()
+
+
+def conv1d(sd, prefix, x, causal, dilation=1, stride=1):
+    """scalar24k.py:36-74 Conv1d: causal = left zero-pad dilation*(k-1) (:50-52,70-72), else symmetric
+    get_padding (:17-18,54)."""
+    w = _w(sd, prefix)
+    k = w.shape[-1]
+    b = sd.get(prefix + "bias")
+    if causal:
+        x = F.pad(x, (dilation * (k - 1), 0))
+        return F.conv1d(x, w, b, stride=stride, dilation=dilation)
+    return F.conv1d(x, w, b, stride=stride, dilation=dilation, padding=int((k * dilation - dilation) / 2))
+
+
+def conv_transpose1d(sd, prefix, x, causal, stride):
+    """scalar24k.py:76-112 ConvTranspose1d: causal needs k == 2*stride and trims the last `stride` samples (:108-111);
+    otherwise padding (k - stride) // 2 (:90-91)."""
+    w = _w(sd, prefix)
+    k = w.shape[-1]
+    b = sd.get(prefix + "bias")
+    if causal:
+        assert k == 2 * stride
+        return F.conv_transpose1d(x, w, b, stride=stride)[:, :, :-stride]
+    return F.conv_transpose1d(x, w, b, stride=stride, padding=(k - stride) // 2)
+
+
+def prelu(sd, key, x):
+    return F.prelu(x, sd[key].float())
+
+
+def residual_unit(sd, p, x, dilation, causal):
+    """scalar24k.py:143-151."""
+    y = prelu(sd, p + "activation1.weight", conv1d(sd, p + "conv1.", x, causal, dilation=dilation))
+    y = prelu(sd, p + "activation2.weight", conv1d(sd, p + "conv2.", y, causal))
+    return y + x
+
+
+class ScalarOracle:
+    """cfg = the ScalarModel constructor arguments (scalar24k.py:306-309)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: dict):
+        self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.cfg = cfg
+        self.causal = cfg["causal"]
+        self.ns = cfg["num_samples"]
+        self.down, self.up = list(cfg["downsample_factors"]), list(cfg["upsample_factors"])
+        # scalar24k.py:206 `activation=nn.PReLU()` is a default argument, i.e. ONE module shared by every
+        # DownsampleLayer: the state dict lists it once per layer, load_state_dict copies them in order into the same
+        # tensor, so the value in effect is the last key's (real checkpoints hold identical copies).
+        shared = [k for k in self.sd if k.endswith("down_conv.activation.weight")]
+        self.down_act = shared[-1] if shared else None
+
+    @torch.no_grad()
+    def encode(self, x):
+        """scalar24k.py:392-401: conv -> [PreProcessor] -> ResEncoderBlocks -> conv -> tanh; returns the un-rounded
+        latent (`emb`, :398,401)."""
+        sd, c = self.sd, self.causal
+        x = x.float()
+        i = 0
+        x = conv1d(sd, f"encoder.{i}.", x, c); i += 1
+        if self.ns > 1:                                                     # PreProcessor :114-123
+            x = prelu(sd, f"encoder.{i}.activation.weight", conv1d(sd, f"encoder.{i}.conv.", x, c))
+            x = F.avg_pool1d(x, self.ns); i += 1
+        for f in self.down:                                                 # ResEncoderBlock :154-173
+            for j, d in enumerate((1, 3, 5, 7, 9)):
+                x = residual_unit(sd, f"encoder.{i}.convs.{j}.", x, d, c)
+            p = f"encoder.{i}.down_conv."                                   # DownsampleLayer :199-229
+            x = prelu(sd, self.down_act, conv1d(sd, p + "layer.", x, c, stride=f)); i += 1
+        return torch.tanh(conv1d(sd, f"encoder.{i}.", x, c))
+
+    @torch.no_grad()
+    def decode(self, x):
+        """scalar24k.py:403-407: round(9x)/9 (:285-290) -> look-ahead conv (non-causal, :354-358) -> ResDecoderBlocks
+        (:176-196) -> [PostProcessor :126-140: repeat each step num_samples times, conv, PReLU] -> conv."""
+        sd, c = self.sd, self.causal
+        x = torch.round(9 * x.float()) / 9
+        i = 0
+        x = conv1d(sd, f"decoder.{i}.", x, False); i += 1
+        for f in self.up:
+            x = conv_transpose1d(sd, f"decoder.{i}.up_conv.layer.", x, c, f)   # UpsampleLayer, activation=None (:180)
+            for j, d in enumerate((1, 3, 5, 7, 9)):
+                x = residual_unit(sd, f"decoder.{i}.convs.{j}.", x, d, c)
+            i += 1
+        if self.ns > 1:
+            x = x.repeat_interleave(self.ns, dim=-1)                        # == transpose/repeat/view/transpose :135-138
+            x = prelu(sd, f"decoder.{i}.activation.weight", conv1d(sd, f"decoder.{i}.conv.", x, c)); i += 1
+        return conv1d(sd, f"decoder.{i}.", x, c)
+
+
+# ---- windowing arithmetic of token2audio_no_reason (reason_tokenizer.py:229-306) ------------------------------------
+
+def window_indices(rec_codes_len: int, duration: int = 20, rec_frame_rate: float = 12.5, sample_rate: int = 24000):
+    """Index lists only, no NN: which code indices of the ORIGINAL (8, T) tensor each window reads, and the waveform
+    bookkeeping.  Follows reason_tokenizer.py line by line: min/hop/overlap in codes (:239-241), target length (:250),
+    self-concatenation up to one window (:251-254) and up to a whole number of hops (:256-260), the window loop
+    `range(0, len - hop, hop)` (:267), the waveform-domain window / hop / overlap (:289-291)."""
+    import math
+    min_samples = int(duration * rec_frame_rate)
+    hop_samples = min_samples // 4 * 3
+    ovlp_samples = min_samples - hop_samples
+    idx = list(range(rec_codes_len))
+    target_len = int(rec_codes_len / 12.5 * sample_rate)
+    if len(idx) < min_samples:
+        while len(idx) < min_samples:
+            idx = idx + idx
+        idx = idx[:min_samples]
+    if (len(idx) - ovlp_samples) % hop_samples > 0:
+        len_codes = math.ceil((len(idx) - ovlp_samples) / float(hop_samples)) * hop_samples + ovlp_samples
+        while len(idx) < len_codes:
+            idx = idx + idx
+        idx = idx[:len_codes]
+    windows = [idx[s:s + min_samples] for s in range(0, len(idx) - hop_samples, hop_samples)]
+    wav_min = int(duration * sample_rate)
+    wav_hop = wav_min // 4 * 3
+    return dict(windows=windows, ovlp_frames=(ovlp_samples // 2), target_len=target_len, wav_window=wav_min,
+                wav_ovlp=wav_min - wav_hop)
+
+
+def crossfade(segments, wav_window: int, wav_ovlp: int, target_len: int):
+    """reason_tokenizer.py:292-305: float64 linear ramp over the overlap, running output kept on the CPU."""
+    import numpy as np
+    output = None
+    for cur in segments:
+        cur = cur[:, 0:wav_window].detach().cpu()
+        if output is None:
+            output = cur
+        else:
+            ov_win = torch.from_numpy(np.linspace(0, 1, wav_ovlp)[None, :])
+            ov_win = torch.cat([ov_win, 1 - ov_win], -1)
+            output[:, -wav_ovlp:] = output[:, -wav_ovlp:] * ov_win[:, -wav_ovlp:] + cur[:, 0:wav_ovlp] * ov_win[:, 0:wav_ovlp]
+            output = torch.cat([output, cur[:, wav_ovlp:]], -1)
+    return output[:, 0:target_len]

@@ -117,8 +117,14 @@ def test_mimicodec_encode_decode_vs_reference():
     codes = m.quantizer.encode(lat)
     ref_codes = torch.from_numpy(g["codes"]).cuda()
     assert codes.shape == ref_codes.shape and codes.dtype == torch.int64
-    agree = (codes == ref_codes).float().mean().item()
-    assert agree > 0.98, agree            # cdist-vs-fma near-ties may flip (and then change the levels after them)
+    # Integer work: equality with the reference's codes.  The 1x1 input projection runs on the exact-fp32 MFMA path and
+    # the search on an fma chain where the reference uses conv1d + cdist, so an fp32 near-tie can flip a level (and
+    # with it the levels after it of that frame); such frames are ENUMERATED in the golden's json
+    # ("near_tie_frames": [[b, t], ...], measured once on the GPU) — everything else must be identical, and the
+    # enumerated frames must be exactly the ones that differ.
+    diff = (codes != ref_codes).any(1).nonzero().tolist()
+    print("mimi codes: frames differing from the reference:", diff)
+    assert diff == meta.get("near_tie_frames", []), diff
     assert torch.equal(m.encode(wav)[:, 0], m.quantizer.rvq_first.encode(z)[:, 0])
     # decode side on the reference's codes
     zq = m.quantizer.decode(ref_codes)
@@ -166,4 +172,49 @@ def test_mimicodec_streaming_decode_and_encode_equal_whole_sequence():
             parts.append(m.encode(wav[..., t:t + step].contiguous()))
     sc = torch.cat(parts, dim=-1)
     assert sc.shape == whole_codes.shape
-    assert (sc == whole_codes).float().mean().item() > 0.98
+    assert torch.equal(sc, whole_codes)          # same kernels, row / chunk invariant arithmetic: identical codes
+
+
+BENCH_SCALAR_CFG = dict(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
+                        downsample_kernel_sizes=[4, 8, 8, 10, 6], upsample_factors=[3, 5, 4, 4, 2],
+                        upsample_kernel_sizes=[6, 10, 8, 8, 4], latent_hidden_dim=136, default_kernel_size=7,
+                        delay_kernel_size=5, init_channel=32, res_kernel_size=7)
+
+
+def _bench_scalar_model():
+    """The ScalarModel bench.py times (placeholder widths, hop 960, latent 136) with fan-in scaled seeded weights, and
+    the CPU oracle on the same state dict."""
+    from oracle.codec_oracle import ScalarOracle
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
+    m = ScalarModel(**BENCH_SCALAR_CFG)
+    sd = codec_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 77)
+    m.load_state_dict(sd)
+    return m.cuda().prepare(), ScalarOracle(sd, BENCH_SCALAR_CFG)
+
+
+def test_scalar_decode_full_20s_window_vs_cpu_oracle():
+    """One full stage-2 window at the bench's size: ScalarModel.decode of a (1, 136, 500) latent -> 480 000 samples
+    against the CPU oracle (pinned on the reference's outputs, tests/test_oracle_codec.py): <= 1e-4 RMS (north_star).
+    Covers every time-tile shape of ua2_conv1d (the 12.5 / 50 Hz layers run the 16- and 32-step tiles, the 24 kHz
+    layers the 64-step one) and launches with T up to 480 000, which the toy goldens (T <= 2 085) never reach."""
+    m, o = _bench_scalar_model()
+    lat = torch.tanh(seeded_tensor((1, 136, 500), 99, std=1.0))
+    got = m.decode(lat.cuda()).cpu().numpy()
+    ref = o.decode(lat).numpy()
+    assert got.shape == ref.shape == (1, 1, 480000)
+    scale = max(1.0, float(np.sqrt(np.mean(ref ** 2))))
+    print("20-s window decode: rms err %.3e (ref rms %.3e, max |ref| %.3e)" % (_rms(got, ref), np.sqrt(np.mean(ref ** 2)), np.abs(ref).max()))
+    assert _rms(got, ref) < 1e-4 * scale
+    assert float(np.abs(got - ref).max()) < 2e-3 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_scalar_encode_10s_clip_vs_cpu_oracle():
+    """Config 3's codec-encode half at full length: ScalarModel.encode of a 10-s clip (240 000 samples, uniform(-0.5, 0.5)
+    as SURVEY.md §8d) -> latent (1, 136, 250) against the CPU oracle, <= 1e-5 RMS."""
+    m, o = _bench_scalar_model()
+    g = torch.Generator().manual_seed(7)
+    wav = torch.rand(1, 1, 240000, generator=g) - 0.5
+    got = m.encode(wav.cuda()).cpu().numpy()
+    ref = o.encode(wav).numpy()
+    assert got.shape == ref.shape == (1, 136, 250)
+    assert _rms(got, ref) < 1e-5, _rms(got, ref)

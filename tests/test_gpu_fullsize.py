@@ -1,8 +1,10 @@
 """Full-size checks (BASELINE.json configs[1] shapes: Llama-3.2-3B backbone + experts + 4-layer local decoder,
 V_a = 12296, random-init).  The CPU oracle takes ~5 s per frame at this size, so parity here is
 (a) UA2_F32 contract: greedy ids of a free-running prefill + 3 frames identical to the fp32 oracle on the same weights;
-(b) UA2_BF16 contract: frame-0 logits against the oracle's bf16 restatement, with the tolerance calibrated in the
-    test itself against the distance between the oracle's bf16 and fp32 modes;
+(b) UA2_BF16 contract (the bench dtype): frame-0 logits against the oracle's bf16 restatement, with the tolerance
+    calibrated in the test itself against the distance between the oracle's bf16 and fp32 modes; and 8 teacher-forced
+    frames against the bf16 oracle with every greedy id asserted wherever the oracle's margin exceeds the measured
+    logit error of that very row;
 (c) size-independent properties: run-to-run determinism, batch invariance (two identical prompts in one batch ==
     the single run, bit for bit), position bookkeeping."""
 import numpy as np
@@ -11,6 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 FRAMES_F32 = 3
+FRAMES_BF16 = 8
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +33,7 @@ def oracle_runs(full_model):
     shapes = dict(backbone=GPTShape(28, 3072, 24, 8, 8192), understanding=GPTShape(3, 3072, 24, 8, 8192),
                   generation=GPTShape(2, 3072, 24, 8, 8192), decoder=GPTShape(4, 2048, 32, 8, 8192))
     runs = {}
-    for mode, frames in (("bf16", 1), ("fp32", FRAMES_F32)):
+    for mode, frames in (("bf16", FRAMES_BF16), ("fp32", FRAMES_F32)):
         o = Stage3Oracle(sd, shapes, bench.SEM_CARD, bench.REASON_CARD, 8, mode=mode, max_seq=64)
         o.setup_caches(1)
         runs[mode] = run_decode_loop(o, tokens, mask, frames, "audio", collect_logits=True)
@@ -79,9 +82,69 @@ def test_fullsize_bf16_frame0_and_properties(full_model, oracle_runs):
               % (name, _rms(d), np.abs(d).max(), _rms(q), np.abs(q).max()))
         assert _rms(d) < 0.75 * _rms(q), name
         assert _rms(d) < 4e-2 and np.abs(d).max() < 0.3, name
-    top2 = np.sort(o_text)[-2:]
-    if top2[1] - top2[0] > 0.3:
-        assert int(s[0, 0]) == int(ob["samples"][0][0, 0])
+
+
+def _forced_margin(o_row, g_row, forbid=0):
+    """(oracle arg-max, oracle top-2 margin, bound): with e = max |gpu - oracle| over the whole row, only columns whose
+    oracle logit is within 2e of the oracle's best can win on the GPU; with e_c = the largest error among THOSE columns,
+    the GPU arg-max must equal the oracle's whenever margin > 2 e_c.  Everything here is measured on this row."""
+    o, g = o_row.astype(np.float64).copy(), g_row.astype(np.float64).copy()
+    if forbid > 0:
+        o[:forbid] = -np.inf
+        g[:forbid] = -np.inf
+    best = int(np.argmax(o))
+    err = np.abs(np.where(np.isfinite(o), g - o, 0.0))
+    cand = o >= o[best] - 2.0 * err.max()
+    second = np.partition(o, -2)[-2]
+    return best, float(o[best] - second), 2.0 * float(err[cand].max()), float(err.max())
+
+
+def test_fullsize_bf16_teacher_forced_ids_vs_bf16_oracle(full_model, oracle_runs):
+    """north_star: "identical reason/semantic token ids under greedy decode", for the dtype the bench times, at
+    bench.build_model size.  Free-running bf16 ids legitimately diverge from ANY other bf16 evaluation once a margin
+    falls below the rounding noise (the reference's own bf16 run diverges from its fp32 run at frame
+    10), so the protocol is the one of tests/test_gpu_lm.py::test_bf16_teacher_forced_vs_oracle_bf16_contract: each
+    frame the kernels get the ORACLE's previous frame as input; all 9 logit rows must stay within the absolute caps,
+    and each of the 9 ids must equal the oracle's wherever the oracle's top-2 margin exceeds what the measured error
+    of that row can flip (_forced_margin).  Inside a frame the depth decoder continues from the GPU's own sample, so
+    a frame's comparison ends at the first id that differs (allowed only below the margin).  Fails if fewer than half
+    of the 72 ids were asserted."""
+    m, bench = full_model
+    dev = torch.device("cuda")
+    tokens, mask, runs = oracle_runs
+    o = runs["bf16"]
+    tokens, mask = tokens.to(dev), mask.to(dev)
+    L = tokens.size(1)
+    m.setup_caches(2, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=64)
+    m.reset_caches()
+    m.forward_prefix(tokens[:, :-1], tokens_mask=mask, input_pos=torch.arange(L - 1, device=dev).unsqueeze(0))
+    ct, cm = tokens[:, -1:], mask[:, -1:]
+    asserted = agree = total = 0
+    worst = 0.0
+    for f in range(FRAMES_BF16):
+        s = m.generate_frame(ct, cm, input_pos=torch.tensor([L - 1 + f], device=dev), input_pos_maxp1=L + f).cpu()
+        rows = [(m.buffer("text_logits", 1).cpu().numpy()[0], o["text_logits"][f][0].numpy())]
+        al = m.buffer("audio_logits", 1).cpu().numpy()[0]
+        rows += [(al[i], o["audio_logits"][f][0, i].numpy()) for i in range(8)]
+        total += 9
+        for c, (g_row, o_row) in enumerate(rows):
+            best, margin, bound, emax = _forced_margin(o_row, g_row)
+            worst = max(worst, emax)
+            assert emax < 0.3 and _rms(g_row - o_row) < 4e-2, (f, c, emax)
+            assert best == int(o["samples"][f][0, c]), "oracle arg-max bookkeeping"
+            same = int(s[0, c]) == best
+            if margin > bound:
+                assert same, f"frame {f} id {c}: gpu {int(s[0, c])} != oracle {best}, margin {margin:.3e} > bound {bound:.3e}"
+                asserted += 1
+            agree += int(same)
+            if not same and c >= 1:
+                break                      # later depth-decoder steps of this frame were conditioned on another token
+        so = o["samples"][f].to(dev)       # teacher forcing: next input = the oracle's frame
+        audio, text_tok = so[:, 1:].long(), so[:, 0:1].long()
+        ct = torch.cat([audio, text_tok], dim=-1).unsqueeze(1)
+        cm = torch.cat([torch.ones_like(audio).bool(), torch.zeros(1, 1, device=dev).bool()], dim=1).unsqueeze(1)
+    print(f"full-size bf16 teacher-forced: asserted {asserted}/{total} ids, equal {agree}/{total}, worst |dlogit| {worst:.3e}")
+    assert asserted >= total // 2, f"only {asserted}/{total} ids had a margin above the measured error"
 
 
 def test_fullsize_fp32_greedy_ids_match_oracle(full_model, oracle_runs):

@@ -16,17 +16,12 @@ def test_rvq_oracle_matches_reference_codes(golden_dir, name):
     flat = x.permute(0, 2, 1).reshape(-1, c["D"]).numpy()  # rows = (b, t)
     codes, q, margin = rvq_oracle.rvq_encode(flat, emb.numpy(), want_margin=True)
     ref = np.ascontiguousarray(d[f"{name}_codes"].reshape(c["L"], -1).T)         # (N, L)
-    # identical wherever the distance gap to the runner-up is above fp32 noise; the reference's
-    # cdist-based distances cannot be reproduced bit for bit (different expansion), so allow a
-    # mismatch only on a level whose margin is < 1e-4 relative, and nothing after it for that row
-    bad = 0
-    for n in range(codes.shape[0]):
-        for l in range(c["L"]):
-            if codes[n, l] != ref[n, l]:
-                assert margin[n, l] < 1e-4 * max(1.0, float(np.abs(flat[n]).max())), (n, l, margin[n, l])
-                bad += 1
-                break
-    assert bad <= 1, f"{bad} rows diverged from the reference"
+    # Integer work: the codes must EQUAL the reference's, all of them (no slack the data does not need).
+    # The reference measures distances through cdist, the oracle through an fma chain; the smallest top-2 distance gap
+    # in these goldens (`margin`, recorded below) is 3.6e-4, four orders above fp32 noise, so there are no near-tie
+    # rows to enumerate: near_tie_rows == [].
+    np.testing.assert_array_equal(codes, ref)
+    assert float(margin.min()) > 1e-4, "golden inputs must stay clear of fp32 near-ties; regenerate with another seed"
     if c["dup"]:
         assert not np.isin(codes, [7, 100]).any(), "duplicate codewords must resolve to the lower index"
         assert not np.isin(ref, [7, 100]).any()
