@@ -48,7 +48,17 @@ enum ua2_epilogue {
   UA2_EPI_SWIGLU = 2,   /* y = silu(xW1^T) * (xW2^T)                 (lit_model.py:592-594)                    */
   UA2_EPI_QKV_ROPE = 3, /* split q|k|v, RoPE on q,k (rope_mode), append k,v to the paged cache
                            (lit_model.py:431, 458-461, 778-807, 831-856; Moshi: transformer.py:386-396, rope.py:12-68) */
-  UA2_EPI_GELU = 4      /* y = gelu(xW^T), exact erf form (Moshi FFN, transformer.py:559 F.gelu)                  */
+  UA2_EPI_GELU = 4      /* y = gelu(xW^T + b): exact erf form (Moshi FFN, transformer.py:559 F.gelu) or, with
+                           act_kind = UA2_GELU_TANH, the tanh approximation (DiT FeedForward "gelu-approximate",
+                           ReasoningCodec_film/models/model_config.json:4)                                        */
+};
+
+/* ua2_linear_args.act_kind: variant of the activation inside UA2_EPI_GELU / UA2_EPI_SWIGLU */
+enum ua2_act_kind {
+  UA2_ACT_DEFAULT = 0,          /* GELU: erf form; SWIGLU: silu(xW0^T) * (xW1^T)                                    */
+  UA2_GELU_TANH = 1,            /* GELU: tanh approximation                                                         */
+  UA2_GATE_SIGMOID_SECOND = 2   /* SWIGLU: (xW0^T + b0) * sigmoid(xW1^T + b1)  — the GLU of ReasoningCodec_film/
+                                   modules/transformer.py:208-243 under power_normalized (proj output chunked x | gate) */
 };
 
 /* flavours of UA2_PRO_NORM */
@@ -131,12 +141,17 @@ typedef struct ua2_linear_args {
                              16-row tile. */
   size_t workspace_bytes;
   /* Producer / consumer hand-over of the many-row operand, skipping the consumer's prep launch:
-     y_packed (UA2_EPI_SWIGLU; N % chunk == 0): the result, rounded to `dtype`, also (or, with y == NULL, only) in the
+     y_packed (UA2_EPI_SWIGLU, UA2_EPI_GELU; N % chunk == 0): the result, rounded to `dtype`, also (or, with y == NULL, only) in the
        packed operand layout [ceil(M/16)][N/KC][64 lanes][16 B] of a following K = N launch;
      x_packed (UA2_PRO_CAST, M spanning more than one row tile): the operand already in that layout (K = this launch's K).
      Same bits as the unpacked route: the packed value is the same RNE cast the prep launch applies. */
   void* y_packed;
   const void* x_packed;
+  const float* bias;      /* optional [N]: nn.Linear bias added to xW^T before the epilogue's activation / residual /
+                             split (NULL for every Linear of the LM).  With UA2_EPI_QKV_ROPE only for weights packed
+                             WITHOUT rope_head_size (rope_mode INTERLEAVED / NONE), where column n is source row n */
+  const float* bias1;     /* SWIGLU: bias of w1 */
+  int32_t act_kind;       /* enum ua2_act_kind */
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
@@ -274,6 +289,36 @@ int ua2_avgpool1d(const float* x, float* y, int64_t rows, int32_t Tin, int32_t k
 int ua2_dwconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t C, int32_t Tin,
                  int32_t Tout, int32_t K, int32_t stride, int32_t dilation, int32_t pad_left, int32_t transposed,
                  void* stream);
+
+/* ---- codec: glue of the neural stages (flow-matching DiT, AudioThinking encoder) ------------------------------- */
+
+enum ua2_ew_act { UA2_EW_IDENTITY = 0, UA2_EW_SILU = 1, UA2_EW_SIGMOID = 2, UA2_EW_TANH = 3 };
+
+/* out[i] = alpha * a[i % na] * (b ? b[i % nb] : 1) + (c ? c[i % nc] : 0) + beta, i < n (modulo = broadcast of a shorter
+ * operand over rows).  The broadcast multiply-adds of the DiT and the Euler solver: adaLN modulation vectors
+ * (models/attention.py:308-311), gated residuals (:345-349, 401-405), ProjectLayer's k^-0.5 (transformer_1d_flow.py:31),
+ * guidance and the Euler step (AudioDiffusion1D.py:104,116-123).  out may alias a, b or c. */
+int ua2_ew_fma(float* out, int64_t n, const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc,
+               float alpha, float beta, void* stream);
+/* out[i] = act(x[i]) (SiLU of adaLN-single, transformer_1d_flow.py:113; nn.SiLU of TimestepEmbedding). */
+int ua2_ew_act(float* out, const float* x, int64_t n, int32_t act, void* stream);
+/* out[r, :] = in[idx[r], :], zeros where idx[r] < 0; C % 4 == 0.  Nearest-neighbour interpolation along time
+ * (AudioDiffusion1D.py:450,512,590) and the cls-token interleave / extraction (:458-486) with host-built index lists. */
+int ua2_gather_rows(float* out, const float* in, const int32_t* idx, int64_t R, int32_t C, void* stream);
+/* time_film (AudioDiffusion1D.py:428-438): params [R, 2C] = (delta_gamma | beta); out = (1 + gamma_scale * tanh(dg)) * x
+ * + beta; rows of a batch element with batch_mask[b] != 0 (the reference's `torch.rand(B,1,1) < 0.2` draw, passed in so
+ * that runs are reproducible) pass x through unchanged.  R = B * rows_per_batch. */
+int ua2_time_film(float* out, const float* params, const float* x, const uint8_t* batch_mask, int64_t R,
+                  int32_t rows_per_batch, int32_t C, float gamma_scale, void* stream);
+/* F.layer_norm over the last axis of [R, C]; w, b optional (NULL = elementwise_affine=False, transformer_1d_flow.py:252). */
+int ua2_layernorm_rows(float* out, const float* x, const float* w, const float* b, int64_t R, int32_t C, float eps, void* stream);
+/* q/k LayerNorm over the head dim + partial rotary embedding + K/V append to the paged cache for the x-transformers
+ * style attention of the AudioThinking encoder (modules/transformer.py:447-485, 146-170).  qkv [R, 3*n_head*hs] =
+ * (q | k | v); q_out [R, n_head*hs] fp32; cos_t / sin_t [max_pos, rot_dim/2]; norm weights NULL = no q/k norm;
+ * rot_dim 0 = no rotary.  Multi-head only (kv->n_kv == kv->n_head). */
+int ua2_qknorm_rope_kv(int dtype, const float* qkv, int64_t R, const int32_t* row_pos, const int32_t* row_seq,
+                       const float* q_norm_w, const float* q_norm_b, const float* k_norm_w, const float* k_norm_b, float eps,
+                       const float* cos_t, const float* sin_t, int32_t rot_dim, float* q_out, const ua2_kv_geom* kv, void* stream);
 
 /* ---- whole-frame executor -------------------------------------------------------------- */
 

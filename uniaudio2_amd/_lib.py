@@ -21,6 +21,7 @@ PRO_CAST, PRO_NORM, PRO_LOCAL_ATTN = 0, 1, 3
 EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE, EPI_GELU = 0, 1, 2, 3, 4
 NORM_RMS_LIT, NORM_RMS_MOSHI, NORM_LAYERNORM = 0, 1, 2
 ROPE_HALF_SPLIT, ROPE_INTERLEAVED, ROPE_NONE = 0, 1, 2
+ACT_KIND_DEFAULT, GELU_TANH, GATE_SIGMOID_SECOND = 0, 1, 2
 UA2_PAGE = 64
 
 vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
@@ -38,7 +39,8 @@ class LinearArgs(C.Structure):
                 ("part_max", vp), ("part_idx", vp), ("forbid", vp), ("row_pos", vp), ("row_seq", vp),
                 ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom),
                 ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32),
-                ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp)]
+                ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp),
+                ("bias", vp), ("bias1", vp), ("act_kind", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -54,6 +56,7 @@ class Conv1dArgs(C.Structure):
 
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_TANH, ACT_ROUND9 = 0, 1, 2, 3, 4
+EW_IDENTITY, EW_SILU, EW_SIGMOID, EW_TANH = 0, 1, 2, 3
 
 
 class GptDesc(C.Structure):
@@ -96,6 +99,12 @@ _EXPORTS = {
     "ua2_avgpool1d": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
     "ua2_rvq_decode": (C.c_int, [vp, vp, i64, i32, i32, i32, vp, vp]),
+    "ua2_ew_fma": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp]),
+    "ua2_ew_act": (C.c_int, [vp, vp, i64, i32, vp]),
+    "ua2_gather_rows": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+    "ua2_time_film": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ua2_layernorm_rows": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, vp]),
+    "ua2_qknorm_rope_kv": (C.c_int, [C.c_int, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, vp, C.POINTER(KvGeom), vp]),
     "ua2_stage3_scratch_floats": (C.c_size_t, [C.POINTER(Stage3Desc)]),
     "ua2_stage3_create": (C.c_int, [C.POINTER(Stage3Desc), C.POINTER(vp)]),
     "ua2_stage3_destroy": (None, [vp]),

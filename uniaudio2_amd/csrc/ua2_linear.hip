@@ -72,12 +72,18 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
   if (a.prologue == UA2_PRO_NORM)
     UA2_CHECK(a.norm_w != nullptr && (a.norm_kind != UA2_NORM_LAYERNORM || a.norm_b != nullptr) && a.norm_kind >= 0 && a.norm_kind <= 2,
               "ua2_linear: norm_w / norm_b / norm_kind invalid");
-  if (a.epilogue == UA2_EPI_GELU) UA2_CHECK(a.y != nullptr, "ua2_linear: GELU needs y");
+  if (a.epilogue == UA2_EPI_GELU) {
+    UA2_CHECK(a.y != nullptr || a.y_packed != nullptr, "ua2_linear: GELU needs y or y_packed");
+    UA2_CHECK(!a.y_packed || a.N % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_linear: y_packed needs N %% chunk == 0");
+  }
+  UA2_CHECK(!a.bias || a.epilogue != UA2_EPI_QKV_ROPE || a.rope_mode != UA2_ROPE_HALF_SPLIT,
+            "ua2_linear: bias with the half-split QKV layout is not supported (columns are permuted at pack time)");
+  UA2_CHECK(a.act_kind >= 0 && a.act_kind <= 2, "ua2_linear: bad act_kind %d", a.act_kind);
   if (a.epilogue == UA2_EPI_SWIGLU) {
     UA2_CHECK(a.w1 != nullptr && (a.y != nullptr || a.y_packed != nullptr), "ua2_linear: SWIGLU needs w1 and y or y_packed");
     UA2_CHECK(!a.y_packed || a.N % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_linear: y_packed needs N %% chunk == 0");
-  } else {
-    UA2_CHECK(!a.y_packed, "ua2_linear: y_packed is a SWIGLU output");
+  } else if (a.epilogue != UA2_EPI_GELU) {
+    UA2_CHECK(!a.y_packed, "ua2_linear: y_packed is a SWIGLU / GELU output");
   }
   if (a.epilogue == UA2_EPI_RESIDUAL) UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
   if (a.epilogue == UA2_EPI_STORE) UA2_CHECK(a.y != nullptr || a.part_max != nullptr, "ua2_linear: STORE needs y or part_max");

@@ -94,6 +94,7 @@ __device__ __forceinline__ float norm_apply(const ua2_linear_args& a, float x, f
 // instead of as dependent loads after the reduction.
 struct EpiPre {
   float resid = 0.f, cs = 0.f, sn = 0.f;
+  float bias = 0.f, bias1 = 0.f;
   int pos = 0, page = 0, forbid = 0;
 };
 
@@ -119,6 +120,13 @@ __device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, in
 // only needed by the epilogue)
 template <int DT, int EPI>
 __device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
+  if (a.bias) {                                    // nn.Linear bias: per output column, any epilogue
+    const int n = tile0 * 16 + col;
+    if (n < a.N) {
+      p.bias = a.bias[n];
+      if constexpr (EPI == UA2_EPI_SWIGLU) p.bias1 = a.bias1 ? a.bias1[n] : 0.f;
+    }
+  }
   if constexpr (EPI == UA2_EPI_QKV_ROPE) {
     const int mr = m0 + row;
     if (mr >= a.M) return;
@@ -141,10 +149,17 @@ __device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int 
 
 // NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.
 template <int DT, int EPI, int NT>
-__device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&v)[NT], const int (&tile)[NT],
+__device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&vin)[NT], const int (&tile)[NT],
                                                 int row, int col, const EpiPre& p, int m0, int rows) {
   const int mr = m0 + row;
   const bool rvalid = row < rows;
+  float v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) v[t] = vin[t];
+  if (a.bias) {                                    // absent (every Linear of the LM): the sums pass through untouched
+    v[0] = __fadd_rn(v[0], p.bias);
+    if constexpr (NT == 2) v[1] = __fadd_rn(v[1], p.bias1);
+  }
 
   if constexpr (EPI == UA2_EPI_STORE) {
     const int n = tile[0] * 16 + col;
@@ -170,15 +185,31 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {
-      const float gte = v[0];
-      const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
-      const float out = __fmul_rn(sg, v[1]);
+      float out;
+      if (a.act_kind == UA2_GATE_SIGMOID_SECOND) {   // x-transformers GLU: x * sigmoid(gate), x = first half (w0), gate = second (w1)
+        out = __fmul_rn(v[0], 1.0f / (1.0f + expf(-v[1])));
+      } else {
+        const float gte = v[0];
+        const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
+        out = __fmul_rn(sg, v[1]);
+      }
       if (a.y) a.y[(size_t)mr * a.ldy + n] = out;
       if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, out);
     }
   } else if constexpr (EPI == UA2_EPI_GELU) {
     const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = __fmul_rn(__fmul_rn(0.5f, v[0]), __fadd_rn(1.0f, erff(__fmul_rn(v[0], 0.70710678118654752440f))));
+    if (rvalid && n < a.N) {
+      float out;
+      if (a.act_kind == UA2_GELU_TANH) {   // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+        const float x = v[0];
+        const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+        out = 0.5f * x * (1.0f + tanhf(inner));
+      } else {
+        out = __fmul_rn(__fmul_rn(0.5f, v[0]), __fadd_rn(1.0f, erff(__fmul_rn(v[0], 0.70710678118654752440f))));
+      }
+      if (a.y) a.y[(size_t)mr * a.ldy + n] = out;
+      if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, out);
+    }
   } else {  // UA2_EPI_QKV_ROPE — weight rows were permuted at pack time (ua2_pack_linear rope_head_size):
     // tile r of a head holds dims [8r, 8r+8) in columns 0-7 and their rotation partners
     // [hs/2+8r, hs/2+8r+8) in columns 8-15, so the half-split rotation closes inside one tile.

@@ -59,7 +59,8 @@ def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
 def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None, ldx=None, norm_w=None, eps=1e-5,
            w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
            forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True,
-           norm_b=None, norm_kind=0, out_scale=None, rope_mode=0, workspace=None):
+           norm_b=None, norm_kind=0, out_scale=None, rope_mode=0, workspace=None, bias=None, bias1=None, act_kind=0,
+           y_packed=None, x_packed=None):
     a = LinearArgs()
     a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
     a.M, a.N, a.K = M, N, K
@@ -72,6 +73,8 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
     a.row_pos, a.row_seq = ptr(row_pos), ptr(row_seq)
     a.rope_cos, a.rope_sin, a.q_out = ptr(rope_cos), ptr(rope_sin), ptr(q_out)
     a.norm_b, a.norm_kind, a.out_scale, a.rope_mode = ptr(norm_b), norm_kind, ptr(out_scale), rope_mode
+    a.bias, a.bias1, a.act_kind = ptr(bias), ptr(bias1), act_kind
+    a.y_packed, a.x_packed = ptr(y_packed), ptr(x_packed)
     if workspace is not None:
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     if kv is not None:
@@ -220,3 +223,53 @@ def avgpool1d(x, k):
     y = torch.empty(B, Cc, T // k, dtype=torch.float32, device=x.device)
     check(lib.ua2_avgpool1d(ptr(x), ptr(y), B * Cc, T, k, stream()), "ua2_avgpool1d")
     return y
+
+
+# ---- codec neural stages: glue ops -----------------------------------------------------------------
+
+def ew_fma(a, b=None, c=None, alpha=1.0, beta=0.0, out=None, n=None):
+    """out[i] = alpha * a[i % na] * b[i % nb] + c[i % nc] + beta over n = max numel (ua2_ew_fma)."""
+    ts = [t for t in (a, b, c) if t is not None]
+    n = n or max(t.numel() for t in ts)
+    if out is None:
+        big = max(ts, key=lambda t: t.numel())
+        out = torch.empty(big.shape, dtype=torch.float32, device=a.device)
+    nz = lambda t: t.numel() if t is not None else 0
+    check(lib.ua2_ew_fma(ptr(out), n, ptr(a), a.numel(), ptr(b), nz(b), ptr(c), nz(c), float(alpha), float(beta), stream()), "ua2_ew_fma")
+    return out
+
+
+def ew_act(x, act):
+    out = torch.empty_like(x)
+    check(lib.ua2_ew_act(ptr(out), ptr(x), x.numel(), act, stream()), "ua2_ew_act")
+    return out
+
+
+def gather_rows(x, idx):
+    """x [N, C] fp32, idx [R] int32 (negative = zero row) -> [R, C]."""
+    R, Cc = idx.numel(), x.shape[-1]
+    out = torch.empty(R, Cc, dtype=torch.float32, device=x.device)
+    check(lib.ua2_gather_rows(ptr(out), ptr(x), ptr(idx), R, Cc, stream()), "ua2_gather_rows")
+    return out
+
+
+def time_film(params, x, batch_mask, rows_per_batch, gamma_scale):
+    R, Cc = x.shape
+    out = torch.empty_like(x)
+    check(lib.ua2_time_film(ptr(out), ptr(params), ptr(x), ptr(batch_mask), R, rows_per_batch, Cc, float(gamma_scale), stream()),
+          "ua2_time_film")
+    return out
+
+
+def layernorm_rows(x, w=None, b=None, eps=1e-5):
+    R, Cc = x.shape
+    out = torch.empty_like(x)
+    check(lib.ua2_layernorm_rows(ptr(out), ptr(x), ptr(w), ptr(b), R, Cc, float(eps), stream()), "ua2_layernorm_rows")
+    return out
+
+
+def qknorm_rope_kv(dtype, qkv, row_pos, row_seq, kv, q_out, qw=None, qb=None, kw=None, kb=None, eps=1e-5, cos=None, sin=None,
+                   rot_dim=0):
+    check(lib.ua2_qknorm_rope_kv(dtype_code(dtype), ptr(qkv), qkv.shape[0], ptr(row_pos), ptr(row_seq), ptr(qw), ptr(qb), ptr(kw),
+                                 ptr(kb), float(eps), ptr(cos), ptr(sin), rot_dim, ptr(q_out), C.byref(kv), stream()),
+          "ua2_qknorm_rope_kv")
