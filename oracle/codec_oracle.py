@@ -157,3 +157,32 @@ def crossfade(segments, wav_window: int, wav_ovlp: int, target_len: int):
             output[:, -wav_ovlp:] = output[:, -wav_ovlp:] * ov_win[:, -wav_ovlp:] + cur[:, 0:wav_ovlp] * ov_win[:, 0:wav_ovlp]
             output = torch.cat([output, cur[:, wav_ovlp:]], -1)
     return output[:, 0:target_len]
+
+
+# ---- torchaudio.functional.resample (reason_tokenizer.py:383-385) — PARITY UNPINNED: torchaudio is not installed ---------
+
+def resample(waveform, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Restatement of torchaudio's published sinc_interp_hann algorithm (`_get_sinc_resample_kernel` +
+    `_apply_sinc_resample_kernel`) with its defaults, as the reference calls it: float64 index grid, clamp to the filter
+    width, Hann window cos^2, sinc, scale; then a strided conv1d of the (width, width + orig) padded signal.
+    waveform (C, L) fp32 -> (C, ceil(new * L / orig))."""
+    import math
+    if int(orig_freq) == int(new_freq):
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
+    t = torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx
+    t = t * base
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels = (kernels * window * (base / o)).to(torch.float32)
+    C, L = waveform.shape
+    x = F.pad(waveform.float(), (width, width + o))
+    y = F.conv1d(x[:, None], kernels, stride=o)                 # (C, n, frames)
+    y = y.transpose(1, 2).reshape(C, -1)
+    return y[..., :math.ceil(n * L / o)]

@@ -1,0 +1,255 @@
+"""GPU parity of the codec's neural stages (§8a a15, a18) and the BASELINE config-1 plumbing.
+
+Oracles: oracle/codec_model_oracle.py + oracle/codec_oracle.py, both pinned on outputs of the reference's own code
+(tests/test_oracle_codec_model.py, tests/test_oracle_codec.py); the goldens themselves (tests/golden/codec_model_toy.npz)
+are compared directly where they apply.  Unpinned pieces (diffusers DiT, vector_quantize_pytorch RVQ, torchaudio
+resampler) are compared with the oracle's restatement of the published algorithms."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from codec_model_stub import CFG, StubEstimator, fetch_inputs, infer_inputs, module_state_dict, think_inputs
+from weights import seeded_tensor
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gold():
+    return np.load(os.path.join(HERE, "codec_model_toy.npz")), json.load(open(os.path.join(HERE, "codec_model_toy.json")))
+
+
+def _toy_model(meta, dit=False, vq_seed=None):
+    """AudioDiffusion1D mirror at the goldens' toy sizes with the goldens' weights (audio_thinking.* seed 301, layers 302)."""
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.AudioDiffusion1D import AudioDiffusion1D
+    import dit_toy
+    c = CFG
+    m = AudioDiffusion1D(whisper_fea_dim=c["Cw"], wavlm_fea_dim=c["Cl"], codec_dim=c["D"], encoder_depth=c["depth"],
+                         unet_model_config_path=dict(num_attention_heads=dit_toy.CFG["heads"], attention_head_dim=dit_toy.CFG["head_dim"],
+                                                     in_channels=dit_toy.CFG["in_channels"], out_channels=dit_toy.CFG["out_channels"],
+                                                     num_layers=dit_toy.CFG["layers"]) if dit else None)
+    m.sq_codec_latent = c["latent"]
+    sd = m.state_dict()
+    new = {"audio_thinking." + k: v for k, v in module_state_dict({k: tuple(s) for k, s in meta["think_keys"]}, 301).items()}
+    new.update(module_state_dict({k: tuple(s) for k, s in meta["fetch_keys"]}, 302))
+    if dit:
+        new.update({"cfm_wrapper.estimator." + k: v for k, v in dit_toy.state_dict(5).items()})
+    rest = {k: tuple(v.shape) for k, v in sd.items() if k not in new}
+    new.update(module_state_dict(rest, vq_seed or 304))                  # RVQ codebooks / projections, zero_cond_embedding1
+    for k in rest:
+        if k.endswith("_codebook.embed"):
+            lvl = int(k.split("layers.")[1].split(".")[0])
+            new[k] = seeded_tensor(rest[k], hash(k) % 100000, std=0.7 ** lvl)
+    m.load_state_dict(new)
+    return m.cuda().prepare(), new
+
+
+def _close(got, ref, tol, name=""):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = float(np.abs(got - ref).max())
+    assert err < tol * max(1.0, float(np.abs(ref).max())), (name, err)
+
+
+def test_thinking_encoder_vs_reference_golden():
+    """AudioThinking encoder (strided conv, merge projection, cls interleave, 2 transformer blocks with q/k LayerNorm, partial
+    rotary, sigmoid-GLU, LayerScale, cls extraction) on the exact-fp32 kernels vs the reference's own output."""
+    d, meta = _gold()
+    m, _ = _toy_model(meta)
+    w, mu = think_inputs()
+    q = m.encode_reasoning_query(w.cuda(), mu.cuda()).cpu().numpy()
+    _close(q, d["think_query"], 1e-4, "think_query")
+
+
+def test_fetch_codes_pipeline_vs_reference_golden_and_oracle():
+    """fetch_codes_from_features with the golden's FiLM masks: every tensor that enters an RVQ equals the reference's
+    (1e-4); then, with real RVQs, codes against the oracle's ResidualVQ restatement on the same features: identical wherever
+    the oracle's nearest / runner-up distance gap is above fp32 noise (the projections run on different fp32 summation
+    orders), and those must be nearly all frames."""
+    from oracle import rvq_oracle
+    from oracle.codec_model_oracle import ResidualVQOracle, sub
+    d, meta = _gold()
+    m, sd = _toy_model(meta)
+    f = fetch_inputs()
+    masks = torch.from_numpy(d["fetch_film_masks"])
+    r = m.fetch_codes_from_features(f["whisper"].cuda(), f["wavlm"].cuda(), f["bestrq_acoustic"].cuda(), f["bestrq_semantic"].cuda(),
+                                    film_masks=masks, return_intermediates=True)
+    for name, key in (("reason_query", "fetch_reason_query"), ("pre_vq_phone", "fetch_pre_vq_phone"), ("pre_vq_semantic", "fetch_pre_vq_semantic"),
+                      ("pre_vq_acoustic", "fetch_pre_vq_acoustic")):
+        _close(r[name].cpu().numpy(), d[key], 1e-4, name)
+    assert r["merge_codes"].shape == (CFG["B"], 15, 8) and r["merge_codes"].dtype == torch.int64
+    assert r["reason_codes"].shape == (CFG["B"], 6, 8)
+    checked = total = 0
+    for key, feat, cols in (("vq_pronunciation_semantic.", d["fetch_pre_vq_phone"], slice(0, 1)), ("vq_structure_semantic.", d["fetch_pre_vq_semantic"], slice(1, 2)),
+                            ("vq_acoustic.", d["fetch_pre_vq_acoustic"], slice(2, 8))):
+        o = ResidualVQOracle(sub(sd, key))
+        x = torch.from_numpy(feat)
+        _, o_codes, h = o(x)
+        _, _, margin = rvq_oracle.rvq_encode(np.ascontiguousarray(h.numpy()), o.emb.numpy(), want_margin=True)
+        got = getattr(m, key[:-1])(x.cuda())[1].cpu()
+        safe = torch.from_numpy((margin > 1e-4).all(1)).view(o_codes.shape[:2])
+        assert torch.equal(got[safe], o_codes[safe]), key
+        checked += int(safe.sum()); total += safe.numel()
+    assert checked >= 0.95 * total, (checked, total)
+
+
+@pytest.mark.parametrize("tag", ["infer_first", "infer_other"])
+def test_inference_codes_and_euler_vs_reference_golden(tag):
+    """inference_codes + BASECFM.solve_euler on the device (look-up sum, cond_feature_emb GEMM, x2 nearest gather, masks,
+    zero_cond rows, in-context blend, guidance, Euler update) with the stand-in estimator of the golden vs the reference's own
+    output."""
+    d, meta = _gold()
+    m, _ = _toy_model(meta, dit=True)
+    i = infer_inputs()
+    cfe = module_state_dict({k: tuple(s) for k, s in meta["cfe_keys"]}, 303)
+    with torch.no_grad():
+        m.cond_feature_emb.weight.copy_(cfe["weight"]); m.cond_feature_emb.bias.copy_(cfe["bias"])
+        m.zero_cond_embedding1.copy_(i["zero_cond"])
+    m.prepare()
+
+    class Table:
+        def __init__(self, t):
+            self.t = t.cuda()
+
+        def get_output_from_indices(self, idx):
+            return sum(self.t[l][idx[..., l]] for l in range(idx.shape[-1]))
+
+    m.vq_pronunciation_semantic, m.vq_structure_semantic, m.vq_acoustic = Table(i["tab_phone"]), Table(i["tab_sem"]), Table(i["tab_ac"])
+    est = StubEstimator("cuda")
+    true_lat, n_inc = (i["first_latent"], 0) if tag == "infer_first" else (i["true_latent"], i["incontext"])
+    lat = m.inference_codes([i["codes"].cuda()], None, true_lat.cuda(), i["latent_length"], n_inc, additional_feats=[], guidance_scale=1.5,
+                            num_steps=CFG["steps"], scenario="other_seg", noise=i["noise"].cuda(),
+                            estimator=lambda x, t: est(x, timestep=torch.full((2,), t, device="cuda")).sample)
+    _close(lat.cpu().numpy(), d[tag], 2e-4, tag)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+def test_dit_forward_vs_oracle(dtype, tol):
+    """Transformer1DModel mirror vs the oracle's restatement (both PARITY UNPINNED vs diffusers — the package is absent):
+    adaLN-single modulation, fused q|k|v with bias, dense attention, gated residuals, tanh-GELU feed-forward, 3-tap
+    ProjectLayers, sinusoidal position table, final modulation."""
+    from oracle.codec_model_oracle import dit_forward
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.transformer_1d_flow import Transformer1DModel
+    import dit_toy
+    c = dit_toy.CFG
+    m = Transformer1DModel(num_attention_heads=c["heads"], attention_head_dim=c["head_dim"], in_channels=c["in_channels"],
+                           out_channels=c["out_channels"], num_layers=c["layers"])
+    sd = dit_toy.state_dict(5)
+    m.load_state_dict(sd)
+    m = m.cuda().prepare(dtype)
+    x = seeded_tensor((2, 37, c["in_channels"]), 9, std=1.0)
+    ref = dit_forward(sd, x, torch.tensor([0.35, 0.35]), c["heads"], c["head_dim"]).numpy()
+    got = m(x.cuda(), 0.35).cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.sqrt(np.mean((got - ref) ** 2)) / max(1e-6, np.sqrt(np.mean(ref ** 2)))
+    print(f"DiT {dtype}: relative rms error {err:.3e}")
+    assert err < tol, err
+
+
+def test_stage_all_decode_runs_at_real_dit_size():
+    """`--stage all`'s second half at the released DiT's shape (models/model_config.json: 32 layers x 1536, 24 heads x 64,
+    in 1040, out 136): one 20-s window, 2 Euler steps, guided (batch 2) -> latent (1, 500, 136) -> ScalarModel.decode ->
+    480 000 samples, finite.  Times the stage (information)."""
+    import time
+    from test_gpu_codec import BENCH_SCALAR_CFG
+    from make_golden_codec import codec_state_dict
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.AudioDiffusion1D import AudioDiffusion1D
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer import ReasoningTokenizer
+    torch.manual_seed(0)
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.transformer_1d_flow import RELEASED_CONFIG
+    model = AudioDiffusion1D(unet_model_config_path=dict(RELEASED_CONFIG), encoder_depth=1, device="cuda")
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if p_.dim() > 1:
+                p_.normal_(0, 0.02)
+        for n_, b_ in model.named_buffers():
+            if n_.endswith("_codebook.embed"):
+                b_.normal_(0, 0.5)
+    model = model.cuda().prepare()
+    sq = ScalarModel(**BENCH_SCALAR_CFG)
+    sq.load_state_dict(codec_state_dict({k: tuple(v.shape) for k, v in sq.state_dict().items()}, 77))
+    sq = sq.cuda().prepare()
+    tok = ReasoningTokenizer(sq_codec=sq, model=model, device="cuda")
+    codes = torch.randint(0, 8192, (8, 250))
+    wav = tok.detokenize_no_reason(codes, steps=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wav = tok.detokenize_no_reason(codes, steps=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert wav.shape == (1, 480000) and wav.device.type == "cpu" and torch.isfinite(wav).all()
+    print(f"stage-2 of one 20-s window, 2 Euler steps: {dt * 1e3:.1f} ms -> {dt * 1e3 / 2:.1f} ms per guided step + decode")
+
+
+def test_config1_codec_plumbing_p225(tmp_path):
+    """BASELINE.json config 1: samples/p225_002.wav (fixture: its 86 848 samples at 22 050 Hz) -> load ->
+    resample to 24 kHz (94 529 samples) -> ScalarModel.encode -> latent (1, 136, 98); synthetic features (1, 50, 768) seed 0
+    -> RVQ 1 + 1 + 6 levels of 8192 x 32 (seed 1) -> codes (8, 50) -> `*_semantic.pt` round trip -> look-up ->
+    stand-in latent -> ScalarModel.decode.  GPU vs the CPU oracles: resampler 1e-5, latent 1e-5 rms, codes equal (near-tie
+    frames enumerated: none allowed above the fp32-noise margin), wav 1e-4 rms."""
+    from scipy.io import wavfile
+    from oracle import rvq_oracle
+    from oracle.codec_model_oracle import ResidualVQOracle
+    from oracle.codec_oracle import resample as resample_oracle
+    from test_gpu_codec import _bench_scalar_model
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.residual_vq import ResidualVQ
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film import reason_tokenizer as rt
+    fx = np.load(os.path.join(HERE, "p225_002.npz"))
+    path = str(tmp_path / "p225_002.wav")
+    wavfile.write(path, int(fx["sample_rate"]), fx["samples"])
+    audio, sr = rt.load_wav(path)
+    assert sr == 22050 and audio.shape == (1, 86848) and np.array_equal(audio.numpy()[0], fx["samples"])
+    got24 = rt.resample(audio.cuda(), sr, 24000).cpu()
+    ref24 = resample_oracle(audio, sr, 24000)
+    assert got24.shape == ref24.shape == (1, 94529)
+    assert float((got24 - ref24).abs().max()) < 1e-5
+    sq, so = _bench_scalar_model()
+    lat = sq.encode(ref24.view(1, 1, -1).cuda()).cpu()
+    lat_ref = so.encode(ref24.view(1, 1, -1))
+    assert lat.shape == lat_ref.shape == (1, 136, 98)
+    assert float(((lat - lat_ref) ** 2).mean().sqrt()) < 1e-5
+    # synthetic features -> the three RVQs (phone 1, semantic 1, acoustic 6 levels; AudioDiffusion1D.py:256-264)
+    feats = torch.randn(1, 50, 768, generator=torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(1)
+    codes, near_ties, vqs = [], [], []
+    for nq in (1, 1, 6):
+        vq = ResidualVQ(dim=768, codebook_size=8192, num_quantizers=nq, codebook_dim=32)
+        sd = {k: (torch.randn(v.shape, generator=g) * (768 ** -0.5 if "project_in.weight" in k else 0.3 if "bias" not in k else 0.01)) for k, v in vq.state_dict().items()}
+        for l in range(nq):
+            sd[f"layers.{l}._codebook.embed"] = torch.randn(1, 8192, 32, generator=g) * 0.6 ** l
+        vq.load_state_dict(sd)
+        vq = vq.cuda()
+        vqs.append(vq)
+        o = ResidualVQOracle(sd)
+        _, o_codes, h = o(feats)
+        _, _, margin = rvq_oracle.rvq_encode(np.ascontiguousarray(h.numpy()), o.emb.numpy(), want_margin=True)
+        got = vq(feats.cuda())[1].cpu()
+        bad = (got != o_codes).any(-1).view(-1).nonzero().view(-1).tolist()
+        for t in bad:                                                  # a differing frame must be an fp32 near-tie of the oracle
+            assert float(margin[t].min()) < 1e-4, (nq, t, margin[t])
+        near_ties += bad
+        codes.append(o_codes[0].transpose(0, 1))                        # (nq, 50)
+    print("config 1: RVQ frames differing from the oracle (near-ties):", near_ties)
+    assert near_ties == []
+    rec = torch.cat(codes, 0)                                           # (8, 50) int64: phone | semantic | acoustic x 6
+    assert rec.shape == (8, 50)
+    torch.save(rec.cpu(), str(tmp_path / "p225_002_semantic.pt"))       # the encode side writes int64
+    back = torch.load(str(tmp_path / "p225_002_semantic.pt"), map_location="cpu")
+    assert back.dtype == torch.int64 and torch.equal(back, rec)
+    # look-up sum -> stand-in latent (fixed projection 768 -> 136, x2 nearest, tanh) -> decode
+    tok = rt.ReasoningTokenizer(sq_codec=sq, vq_phone=vqs[0], vq_semantic=vqs[1], vq_acoustic=vqs[2], device="cuda")
+    cond = tok.codes_to_condition(back.unsqueeze(0).cuda()).cpu()
+    os_ = [ResidualVQOracle({k: v.cpu() for k, v in vq.state_dict().items()}) for vq in vqs]
+    cond_ref = sum(o.get_output_from_indices(c.transpose(1, 2)) for o, c in zip(os_, (back[None, 0:1], back[None, 1:2], back[None, 2:])))
+    assert float((cond - cond_ref).abs().max()) < 1e-5 * max(1.0, float(cond_ref.abs().max()))
+    P = seeded_tensor((768, 136), 5, std=768 ** -0.5)
+    latent = torch.tanh(cond_ref @ P).repeat_interleave(2, dim=1).transpose(1, 2).contiguous()      # (1, 136, 100)
+    wav = sq.decode(latent.cuda()).cpu()
+    wav_ref = so.decode(latent)
+    assert wav.shape == wav_ref.shape == (1, 1, 96000)
+    rms = float(((wav - wav_ref) ** 2).mean().sqrt())
+    assert rms < 1e-4 * max(1.0, float((wav_ref ** 2).mean().sqrt())), rms

@@ -384,6 +384,9 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
   } else if (a.prologue == UA2_PRO_CAST) {
     if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_RESIDUAL>(a, s);
     if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_STORE>(a, s);
+    if (a.epilogue == UA2_EPI_SWIGLU) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_SWIGLU>(a, s);     // codec GLU (no norm in front)
+    if (a.epilogue == UA2_EPI_GELU) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_GELU>(a, s);
+    if (a.epilogue == UA2_EPI_QKV_ROPE) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_QKV_ROPE>(a, s);
   } else if (a.prologue == UA2_PRO_LOCAL_ATTN) {
     if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_LOCAL_ATTN, UA2_EPI_RESIDUAL>(a, s);
   }

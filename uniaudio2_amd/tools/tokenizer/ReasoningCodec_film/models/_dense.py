@@ -1,0 +1,78 @@
+"""Host-side helpers shared by the codec's neural stages (AudioThinking encoder, flow-matching DiT): a packed Linear
+(`nn.Linear` call sites -> one ua2_linear launch with the surrounding norm / bias / activation / gated residual fused),
+a dense (non-causal) attention over the paged K/V layout, and torch's own nearest-neighbour index rule.  No torch math on
+the data path; torch owns memory and builds index lists."""
+import torch
+import torch.nn.functional as F
+
+from ..... import ops
+from ....._lib import (EPI_GELU, EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, NORM_LAYERNORM, PRO_CAST, PRO_NORM, ROPE_NONE,
+                       UA2_PAGE)
+
+
+def folded_weight(lin):
+    """Effective fp32 weight of an nn.Linear, weight-norm (parametrizations) folded: w = g * v / ||v||_row."""
+    if hasattr(lin, "parametrizations") and "weight" in lin.parametrizations:
+        p = lin.parametrizations.weight
+        return torch._weight_norm(p.original1.detach().float(), p.original0.detach().float(), 0)
+    return lin.weight.detach().float()
+
+
+class PackedLinear:
+    """weight [N, K] (+ bias [N]) packed once for `dtype`; call = one ua2_linear launch."""
+
+    def __init__(self, weight, bias, dtype, scale=None):
+        w = weight.detach().float()
+        b = bias.detach().float() if bias is not None else None
+        if scale is not None:
+            w, b = w * scale, (b * scale if b is not None else None)
+        self.N, self.K = w.shape
+        self.dtype = dtype
+        self.w = ops.pack_linear(w.contiguous(), dtype)
+        self.b = b.contiguous() if b is not None else None
+
+    def __call__(self, x, *, epilogue=EPI_STORE, norm=None, resid=None, out_scale=None, act_kind=0, w1=None, y=None, M=None, **kw):
+        """x [M, K] fp32 contiguous rows.  norm = (w, b, eps) -> LayerNorm prologue (F.layer_norm then * w + b)."""
+        M = M or x.shape[0]
+        if y is None and epilogue != EPI_QKV_ROPE:                   # QKV: the results go to q_out and the K/V pools
+            y = torch.empty(M, self.N, dtype=torch.float32, device=x.device)
+        ws = ops.linear_workspace(self.dtype, M, self.K, x.device) if M > 16 else None
+        extra = {}
+        if norm is not None:
+            extra = dict(prologue=PRO_NORM, norm_w=norm[0], norm_b=norm[1], eps=norm[2], norm_kind=NORM_LAYERNORM)
+        if w1 is not None:
+            extra.update(w1=w1.w, bias1=w1.b)
+        ops.linear(dtype=self.dtype, M=M, N=self.N, K=self.K, w0=self.w, epilogue=epilogue, x=x, ldx=self.K, y=y, ldy=(self.N if y is not None else 0), resid=resid,
+                   ldr=(self.N if resid is not None else None), out_scale=out_scale, bias=self.b, act_kind=act_kind, workspace=ws, **extra, **kw)
+        return y if y is not None else kw.get("q_out")
+
+
+class DenseKV:
+    """Paged K/V pools for B sequences of up to T positions, one layer at a time (re-used by every layer: a layer's K/V
+    are dead once its attention has run)."""
+
+    def __init__(self, B, T, n_head, head_size, dtype, device):
+        self.max_pages = (T + UA2_PAGE - 1) // UA2_PAGE
+        shape = (B * self.max_pages, n_head, UA2_PAGE, head_size)
+        self.k = torch.zeros(shape, dtype=dtype, device=device)
+        self.v = torch.zeros(shape, dtype=dtype, device=device)
+        self.table = torch.arange(B * self.max_pages, dtype=torch.int32, device=device).view(B, self.max_pages)
+        self.geom = ops.kv_geom(self.k, self.v, self.table, n_head, n_head, head_size)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.row_pos = torch.arange(T, **i32).repeat(B)                       # row r = (b, t): position t ...
+        self.row_seq = torch.arange(B, **i32).repeat_interleave(T)            # ... of sequence b
+        self.all_pos = torch.full((B * T,), T - 1, **i32)                     # non-causal: every row sees positions 0..T-1
+        self.dtype, self.B, self.T = dtype, B, T
+
+    def attend(self, q):
+        """q [B*T, n_head*hs] fp32 -> softmax(q K^T / sqrt(hs)) V, every row over all T positions of its sequence."""
+        y = torch.empty_like(q)
+        ops.attn(dtype=self.dtype, R=q.shape[0], q=q, row_pos=self.all_pos, row_seq=self.row_seq, kv=self.geom, y=y)
+        return y
+
+
+def nearest_indices(T_in, scale_factor, device):
+    """Source index of every output step of F.interpolate(mode='nearest', scale_factor=s) along time — obtained from
+    torch's own rule by interpolating an index ramp (AudioDiffusion1D.py:450,512,590)."""
+    ramp = torch.arange(T_in, dtype=torch.float32).view(1, 1, T_in)
+    return F.interpolate(ramp, scale_factor=scale_factor, mode="nearest").view(-1).to(torch.int32).to(device)

@@ -1,0 +1,223 @@
+"""Flow-matching DiT of the codec's decoder, host side.
+
+Mirror of the reference's tools/tokenizer/ReasoningCodec_film/models/transformer_1d_flow.py `Transformer1DModel`
+(:162-386) in the configuration models/model_config.json pins (norm_type 'ada_norm_single', 'gelu-approximate',
+attention_bias, no cross attention) over models/attention.py `BasicTransformerBlock` (:97-420).  The reference builds these
+from diffusers (Attention, FeedForward, TimestepEmbedding, SinusoidalPositionalEmbedding: not vendored, not installed ->
+restated from the call sites, PARITY UNPINNED, see oracle/codec_model_oracle.py); parameter names follow diffusers'
+modules so a reference checkpoint's `cfm_wrapper.estimator.*` keys load: `proj_in.ffn_1/ffn_2`, `transformer_blocks.N.
+{scale_shift_table, attn1.to_q/to_k/to_v/to_out.0, ff.net.0.proj, ff.net.2}`, `scale_shift_table`, `proj_out.*`,
+`adaln_single.{emb.timestep_embedder.linear_1/2, linear}`.
+
+Per layer on the device (6 GEMM launches + 1 attention + 3 tiny vector ops; the reference: ~25 PyTorch ops):
+  adaLN vectors (table + t_emb, 1 + scale)              ua2_ew_fma                         attention.py:308-310
+  LayerNorm * (1 + scale) + shift -> q|k|v + bias       ua2_linear NORM(LayerNorm) / QKV   :311-319, attn1
+  dense softmax attention over the T frames             ua2_attn (rows see all positions)  attn1 (non-causal SDPA)
+  to_out + bias, * gate, + residual                     ua2_linear CAST / RESIDUAL(scale)  :345-349
+  LayerNorm * (1 + scale) + shift -> ff.net.0 + GELU    ua2_linear NORM / GELU(tanh)       :388-390, ff
+  ff.net.2 + bias, * gate, + residual                   ua2_linear CAST / RESIDUAL(scale)  :401-405
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..... import ops
+from ....._lib import EPI_GELU, EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EW_SILU, GELU_TANH, ROPE_NONE
+from ._dense import DenseKV, PackedLinear
+
+
+class ProjectLayer(nn.Module):
+    """transformer_1d_flow.py:19-33: Conv1d(k, padding k//2) over time, * k^-0.5, Linear."""
+
+    def __init__(self, hidden_size, filter_size, kernel_size=1):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.ffn_1 = nn.Conv1d(hidden_size, filter_size, kernel_size, padding=kernel_size // 2)
+        self.ffn_2 = nn.Linear(filter_size, filter_size)
+
+    def prepare(self, dtype):
+        k = self.kernel_size
+        w = self.ffn_1.weight.detach().float()                      # [Cout, Cin, k]
+        s = k ** -0.5                                               # folded into the conv taps and bias (:31)
+        self._taps = [PackedLinear(w[:, :, j].contiguous(), self.ffn_1.bias if j == 0 else None, dtype, scale=s) for j in range(k)]
+        self._lin = PackedLinear(self.ffn_2.weight, self.ffn_2.bias, dtype)
+
+    def run(self, x, B, T):
+        """x [B*T, Cin] fp32 rows -> [B*T, Cout].  The k-tap conv is k accumulated GEMMs over row-shifted views of a
+        zero-padded copy (tap j reads frames t + j - k//2)."""
+        k, Cin = self.kernel_size, x.shape[1]
+        pad = k // 2
+        xp = torch.zeros(B, T + 2 * pad, Cin, dtype=torch.float32, device=x.device)
+        xp[:, pad:pad + T] = x.view(B, T, Cin)
+        y = torch.empty(B * T, self._taps[0].N, dtype=torch.float32, device=x.device)
+        for b in range(B):
+            yb = y[b * T:(b + 1) * T]
+            for j, tap in enumerate(self._taps):
+                src = xp[b, j:j + T]
+                if j == 0:
+                    tap(src, y=yb, M=T)
+                else:
+                    tap(src, epilogue=EPI_RESIDUAL, resid=yb, y=yb, M=T)
+        return self._lin(y)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, bias=True):
+        super().__init__()
+        self.to_q, self.to_k, self.to_v = (nn.Linear(dim, dim, bias=bias) for _ in range(3))
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim, bias=True), nn.Identity()])
+
+
+class _GELUProj(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([_GELUProj(dim, dim * mult), nn.Identity(), nn.Linear(dim * mult, dim)])
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, num_attention_heads, attention_head_dim, attention_bias=True, norm_eps=1e-6):
+        super().__init__()
+        self.dim, self.heads, self.head_dim, self.eps = dim, num_attention_heads, attention_head_dim, norm_eps
+        self.attn1 = _Attention(dim, bias=attention_bias)
+        self.ff = _FeedForward(dim)
+        self.scale_shift_table = nn.Parameter(torch.randn(6, dim) / dim ** 0.5)
+
+    def prepare(self, dtype):
+        a = self.attn1
+        cat = lambda ts: torch.cat([t.detach().float() for t in ts], 0)
+        bias = cat([a.to_q.bias, a.to_k.bias, a.to_v.bias]) if a.to_q.bias is not None else None
+        self._p = dict(qkv=PackedLinear(cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]), bias, dtype),
+                       out=PackedLinear(a.to_out[0].weight, a.to_out[0].bias, dtype),
+                       ff1=PackedLinear(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias, dtype),
+                       ff2=PackedLinear(self.ff.net[2].weight, self.ff.net[2].bias, dtype),
+                       table=self.scale_shift_table.detach().float().contiguous().view(-1), dtype=dtype)
+
+    def run(self, h, ts, kv: DenseKV):
+        """h [B*T, D] fp32 rows (in place); ts [6*D] = adaln_single.linear(silu(t_emb)) of this step (one timestep for the
+        whole batch, as solve_euler passes it)."""
+        p, D = self._p, self.dim
+        mod = ops.ew_fma(p["table"], c=ts)                                   # table + timestep  -> (6, D)
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = (mod[i * D:(i + 1) * D] for i in range(6))
+        w_a, w_m = ops.ew_fma(sc_a, beta=1.0), ops.ew_fma(sc_m, beta=1.0)    # 1 + scale
+        q = torch.empty(h.shape[0], D, dtype=torch.float32, device=h.device)
+        p["qkv"](h, epilogue=EPI_QKV_ROPE, norm=(w_a, sh_a, self.eps), rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq,
+                 q_out=q, kv=kv.geom)
+        o = kv.attend(q)
+        p["out"](o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
+        f = p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH)
+        p["ff2"](f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h)
+        return h
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, dim):
+        super().__init__()
+        self.linear_1, self.linear_2 = nn.Linear(in_channels, dim), nn.Linear(dim, dim)
+
+
+class _CombinedFlowEmbeddings(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.flow_t_size = 512
+        self.timestep_embedder = _TimestepEmbedding(self.flow_t_size, dim)
+
+
+class AdaLayerNormSingleFlow(nn.Module):
+    """transformer_1d_flow.py:87-115."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.emb = _CombinedFlowEmbeddings(dim)
+        self.linear = nn.Linear(dim, 6 * dim, bias=True)
+
+    def prepare(self, dtype):
+        te = self.emb.timestep_embedder
+        self._p = dict(l1=PackedLinear(te.linear_1.weight, te.linear_1.bias, dtype), l2=PackedLinear(te.linear_2.weight, te.linear_2.bias, dtype),
+                       lin=PackedLinear(self.linear.weight, self.linear.bias, dtype))
+
+    def run(self, t: float, device):
+        """t: the step's time in [0, 1] (host scalar: the Euler schedule is host-side) -> (ts [6D], embedded [D])."""
+        half = self.emb.flow_t_size // 2                                      # :57-72, a 512-entry table of cos | sin: host-side
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        args = torch.tensor([t], dtype=torch.float32)[:, None] * freqs[None] * 1000
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(device)
+        p = self._p
+        e = p["l2"](ops.ew_act(p["l1"](emb), EW_SILU))
+        return p["lin"](ops.ew_act(e, EW_SILU)).view(-1), e.view(-1)
+
+
+# The hyper-parameters the released codec pins in models/model_config.json (what `from_config` needs of them).
+RELEASED_CONFIG = dict(num_attention_heads=24, attention_head_dim=64, in_channels=1040, out_channels=136, num_layers=32,
+                       attention_bias=True, norm_eps=1e-6, norm_type="ada_norm_single", activation_fn="gelu-approximate",
+                       cross_attention_dim=None)
+
+
+class Transformer1DModel(nn.Module):
+    def __init__(self, num_attention_heads=24, attention_head_dim=64, in_channels=1040, out_channels=136, num_layers=32,
+                 attention_bias=True, norm_eps=1e-6, num_positional_embeddings=3000, **unused_config):
+        super().__init__()
+        D = num_attention_heads * attention_head_dim
+        self.inner_dim, self.heads, self.head_dim = D, num_attention_heads, attention_head_dim
+        self.in_channels, self.out_channels, self.max_pos = in_channels, out_channels, num_positional_embeddings
+        self.proj_in = ProjectLayer(in_channels, D, kernel_size=3)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(D, num_attention_heads, attention_head_dim, attention_bias, norm_eps)
+                                                 for _ in range(num_layers)])
+        self.scale_shift_table = nn.Parameter(torch.randn(2, D) / D ** 0.5)
+        self.proj_out = ProjectLayer(D, out_channels, kernel_size=3)
+        self.adaln_single = AdaLayerNormSingleFlow(D)
+        self._ready = False
+
+    @classmethod
+    def from_config(cls, path_or_dict):
+        import json
+        cfg = path_or_dict if isinstance(path_or_dict, dict) else json.load(open(path_or_dict))
+        if (cfg.get("norm_type", "ada_norm_single") != "ada_norm_single" or cfg.get("activation_fn", "gelu-approximate") != "gelu-approximate"
+                or cfg.get("cross_attention_dim") is not None):
+            raise NotImplementedError("only the released codec's DiT configuration (models/model_config.json) is built")
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+    def prepare(self, dtype=torch.bfloat16):
+        dev = self.scale_shift_table.device
+        if dev.type != "cuda":
+            raise RuntimeError("uniaudio2_amd runs on a ROCm device only (no CPU fallback); move the model to cuda")
+        self.proj_in.prepare(dtype); self.proj_out.prepare(dtype); self.adaln_single.prepare(dtype)
+        for b in self.transformer_blocks:
+            b.prepare(dtype)
+        D = self.inner_dim
+        pos = torch.arange(self.max_pos).unsqueeze(1).float()                 # diffusers SinusoidalPositionalEmbedding (:232)
+        div = torch.exp(torch.arange(0, D, 2).float() * (-math.log(10000.0) / D))
+        pe = torch.zeros(self.max_pos, D)
+        pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
+        self._pe = pe.to(dev).contiguous()
+        self._table = self.scale_shift_table.detach().float().contiguous().view(-1)
+        self._dtype, self._ready, self._kv = dtype, True, None
+        return self
+
+    @torch.inference_mode()
+    def forward(self, hidden_states, timestep: float):
+        """hidden_states (B, T, in_channels) fp32, one timestep for the whole batch -> (B, T, out_channels) fp32
+        (transformer_1d_flow.py:279-386 `.sample`)."""
+        if not self._ready:
+            self.prepare()
+        B, T, Cin = hidden_states.shape
+        D = self.inner_dim
+        x = hidden_states.reshape(B * T, Cin).float().contiguous()
+        h = self.proj_in.run(x, B, T)
+        h = ops.ew_fma(h, c=self._pe[:T])                                     # + pos_embed (:338); the modulo broadcast repeats it per batch element
+        ts, emb = self.adaln_single.run(float(timestep), h.device)
+        if self._kv is None or self._kv.B != B or self._kv.T != T:
+            self._kv = DenseKV(B, T, self.heads, self.head_dim, self._dtype, h.device)
+        for blk in self.transformer_blocks:
+            blk.run(h, ts, self._kv)
+        mod = ops.ew_fma(self._table, c=emb)                                  # (2, D): scale_shift_table + embedded_timestep  :378
+        shift, scale = mod[:D], mod[D:]
+        hn = ops.layernorm_rows(h, None, None, 1e-6)                          # norm_out :379
+        hm = ops.ew_fma(hn, b=ops.ew_fma(scale, beta=1.0), c=shift)           # * (1 + scale) + shift  :381
+        return self.proj_out.run(hm, B, T).view(B, T, self.out_channels)

@@ -1,20 +1,26 @@
-"""ReasoningCodec tokenizer, host side: the tensor contract, the windowing and the in-scope part of decode.
+"""ReasoningCodec tokenizer, host side: audio <-> the (8, T) token tensors of the `*_reason.pt` / `*_semantic.pt` contract.
 
 Mirror of the reference's tools/tokenizer/ReasoningCodec_film/reason_tokenizer.py `ReasoningTokenizer`
-for what is on the hot path:
+(SURVEY.md §8a rows a15, a17-a19, §8f #1, #3):
   * `detokenize_no_reason(rec_codec (8,T), ...) -> wave (1, N) float32 CPU` (:399-404) through
     `token2audio_no_reason` (:229-306): tile / pad the codes to 20-s windows (250 codes, hop 186,
-    overlap 64), per window: RVQ lookup of the three code groups (AudioDiffusion1D.py:570-583, in
-    scope) -> latent generator (flow-matching DiT + Euler ODE: OUT OF SCOPE this round, SURVEY §8f #1,
-    injected through `latent_fn`) -> `SQCodec.decode` (ScalarModel, in scope) -> linear cross-fade of
-    the 25 % overlap in float64 on the host, crop to T / 12.5 * 24000 samples.
-  * `tokenize(tensor)` passes tensors through (:387-388); tokenising a wav path needs the frozen
-    Whisper / WavLM / BEST-RQ encoders (out of scope) and raises.
+    overlap 64); per window `model.inference_codes` (RVQ look-ups -> cond_feature_emb -> x2 nearest ->
+    flow-matching DiT + guided Euler ODE, the previous window's last 32 latent frames as in-context
+    frames) -> `SQCodec.decode` (ScalarModel) -> linear cross-fade of the 25 % overlap in float64 on the
+    host, crop to T / 12.5 * 24000 samples.
+  * `tokenize(wav path) -> (reason (8, T_r), rec (8, T_s))` (:377-387): load, down-mix, resample to 24 kHz
+    (torchaudio's windowed-sinc algorithm restated as one MFMA GEMM, `resample`), then `audio2token`
+    (:86-129): tile the clip to 30-s segments (+240 samples), `model.fetch_codes_batch` per batch of 6
+    segments, crop to int(dur * 12.5) + 1 / int(dur * 5) + 1 tokens.  The frozen SSL encoders inside
+    fetch_codes_batch are an injected callable (models/AudioDiffusion1D.py); `tokenize(tensor)` passes
+    tensors through (:387-388).
 """
 import math
 
 import numpy as np
 import torch
+
+from .... import ops
 
 
 def window_plan(rec_codes_len, duration=20, rec_frame_rate=12.5, sample_rate=24000, sq_codec_hz=25):
@@ -58,34 +64,153 @@ def crossfade_concat(segments, wav_window, wav_ovlp, target_len):
     return output[:, 0:target_len]
 
 
+def resample_kernel(orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """Filter bank of `torchaudio.functional.resample` (sinc_interp_hann, the defaults reason_tokenizer.py:383-385 uses):
+    [new/gcd, 2*width + orig/gcd] fp32 + width.  torchaudio is not installed here (parity with the package UNPINNED,
+    SURVEY.md §8d config 1); this follows its published algorithm: float64 index grid, clamp to the filter width,
+    Hann window cos^2, sinc, scale by base_freq / orig."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
+    t = torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base / o
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels = kernels * window * scale
+    return kernels.to(torch.float32).view(n, -1), width, o, n
+
+
+def resample(wav, orig_freq, new_freq):
+    """wav (C, L) fp32 on the device -> (C, ceil(new * L / orig)).  The polyphase FIR is one exact-fp32 GEMM: frames of
+    2*width + orig samples every `orig` samples (a strided view of the padded signal) x the [new, taps] filter bank."""
+    if int(orig_freq) == int(new_freq):
+        return wav
+    kern, width, o, n = resample_kernel(orig_freq, new_freq)
+    C_, L = wav.shape
+    taps = kern.shape[1]
+    kp = (taps + 3) // 4 * 4                                          # ua2_linear wants K % 4 == 0: zero taps
+    w = torch.zeros(n, kp)
+    w[:, :taps] = kern
+    wp = ops.pack_linear(w.to(wav.device), torch.float32)
+    outs = []
+    for c in range(C_):
+        x = torch.nn.functional.pad(wav[c].float(), (width, width + o))
+        frames = x.unfold(0, taps, o)                                  # [n_frames, taps] strided view (data movement only)
+        fr = torch.zeros(frames.shape[0], kp, dtype=torch.float32, device=wav.device)
+        fr[:, :taps] = frames
+        y = torch.empty(fr.shape[0], n, dtype=torch.float32, device=wav.device)
+        ws = ops.linear_workspace(torch.float32, fr.shape[0], kp, wav.device)
+        ops.linear(dtype=torch.float32, M=fr.shape[0], N=n, K=kp, w0=wp, x=fr, y=y, workspace=ws)
+        outs.append(y.reshape(-1)[:math.ceil(n * L / o)])
+    return torch.stack(outs)
+
+
+def load_wav(path):
+    """(channels, samples) fp32 in [-1, 1] + sample rate, as torchaudio.load normalises (int PCM / 2^(bits-1))."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path)
+    x = np.asarray(data)
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(2 ** (8 * x.dtype.itemsize - 1))
+    elif x.dtype.kind == "u":
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    x = x.astype(np.float32)
+    if x.ndim == 1:
+        x = x[None]
+    else:
+        x = x.T
+    return torch.from_numpy(np.ascontiguousarray(x)), int(sr)
+
+
+def segment_plan(orig_length, sample_rate=24000, min_duration=30, rec_frame_rate=12.5, reason_frame_rate=5):
+    """Index arithmetic of audio2token (:98-109, 125-128) — pure function: how often the clip is self-concatenated, how many
+    (min_samples + 240)-sample segments are cut, how many tokens are kept."""
+    min_samples = int(min_duration * sample_rate)
+    output_len = int(orig_length / float(sample_rate) * rec_frame_rate) + 1
+    output_len_reason = int(orig_length / float(sample_rate) * reason_frame_rate) + 1
+    n = orig_length
+    while n < min_samples + 240:
+        n *= 2
+    int_max_len = n // min_samples + 1
+    n *= 2
+    seg = min_samples + 240
+    total = int(int_max_len * seg)
+    if n < total:
+        raise ValueError("audio2token: the doubled clip is shorter than the segment grid (the reference's reshape fails here too)")
+    return dict(segment=seg, n_segments=int_max_len, total=total, output_len=output_len, output_len_reason=output_len_reason)
+
+
 class ReasoningTokenizer:
-    """`sq_codec`: a prepared ScalarModel; `vq_*`: ResidualVQ mirrors of the three code groups
-    [phone (1 level), semantic (1), acoustic (6)] (AudioDiffusion1D.py:256-264); `latent_fn(cond, steps)`:
-    (B, 500, 768) conditioning -> (B, 500, 136) SQ-Codec latent — the DiT stage this build does not contain."""
+    """`model`: a prepared models.AudioDiffusion1D.AudioDiffusion1D (RVQs, AudioThinking encoder, DiT); `sq_codec`: a
+    prepared ScalarModel.  For runs without a DiT, `latent_fn(cond (B, 500, 768), steps) -> (B, 500, 136)` may stand in for
+    the flow-matching stage, with `vq_*` given directly (round-1 interface, kept for the sub-graph tests)."""
 
     def __init__(self, sq_codec=None, vq_phone=None, vq_semantic=None, vq_acoustic=None, latent_fn=None, device="cuda",
-                 train_config=None, model_path=None, music_ssl_folder=None):
+                 train_config=None, model_path=None, music_ssl_folder=None, model=None, feature_extractor=None):
         self.device = torch.device(device)
         self.sample_rate = 24000
         self.rec_frame_rate, self.reason_frame_rate, self.sq_codec_hz = 12.5, 5, 25        # :31-33
-        self.SQCodec, self.latent_fn = sq_codec, latent_fn
+        self.SQCodec, self.latent_fn, self.model = sq_codec, latent_fn, model
+        self.feature_extractor = feature_extractor          # Whisper log-mel front end (:67-72), out of scope: injected or None
         self.vq = (vq_phone, vq_semantic, vq_acoustic)
+        if model is not None:
+            self.vq = (model.vq_pronunciation_semantic, model.vq_structure_semantic, model.vq_acoustic)
         if train_config is not None or model_path is not None:
-            raise NotImplementedError("loading the released codec checkpoint needs the un-vendored DiT / SSL stack "
-                                      "(diffusers, fairseq, whisper): out of scope this round, SURVEY.md §8f")
+            raise NotImplementedError("loading the released codec checkpoint needs its yaml / SSL model folders, which are not in the "
+                                      "repository (SURVEY.md §0.5); build AudioDiffusion1D + ScalarModel, load_state_dict, and pass them in")
 
     @property
     def is_discrete(self):
         return True
 
+    # ---- audio -> tokens ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def audio2token(self, orig_samples, sr, return_reasoning_text=False, task_name="speech_reasoning", min_duration=30, batch_size=6):
+        """:86-129.  orig_samples (1, N) at 24 kHz -> (reason (1, 8, T_r), rec (1, 8, T_s)) int64."""
+        if self.model is None:
+            raise NotImplementedError("audio2token needs the codec model (AudioDiffusion1D) — pass model=")
+        audios = orig_samples.to(self.device)
+        audios = audios.squeeze(0) if audios.ndim == 3 else audios
+        plan = segment_plan(audios.shape[-1], self.sample_rate, min_duration, self.rec_frame_rate, self.reason_frame_rate)
+        while audios.shape[-1] < plan["segment"]:
+            audios = torch.cat([audios, audios], -1)
+        audios = torch.cat([audios, audios], -1)[:, :plan["total"]]
+        audio_input = audios.reshape(1, -1, plan["segment"]).permute(1, 0, 2).reshape(-1, 1, plan["segment"])
+        reason_list, rec_list = [], []
+        for i in range(0, audio_input.shape[0], batch_size):
+            chunk = audio_input[i:i + batch_size]
+            mels = self.feature_extractor(chunk[:, 0, :]) if self.feature_extractor is not None else None
+            reasoning_codes, rec_codes, _ = self.model.fetch_codes_batch(chunk, mels, additional_feats=[], return_reasoning_text=return_reasoning_text)
+            reason_list.append(torch.cat(reasoning_codes, 1))
+            rec_list.append(torch.cat(rec_codes, 1))
+        reason = torch.cat(reason_list, 0).reshape(-1, 8).unsqueeze(0)
+        rec = torch.cat(rec_list, 0).reshape(-1, 8).unsqueeze(0)
+        return reason[:, :plan["output_len_reason"], :].transpose(1, 2), rec[:, :plan["output_len"], :].transpose(1, 2)
+
     def tokenize(self, wav, return_reasoning_text=False, task_name="asr", min_duration=30):
+        """:377-390: wav path -> (reason (8, T_r), rec (8, T_s)); tensors pass through."""
         if isinstance(wav, torch.Tensor):
             return wav                                              # :387-388
-        raise NotImplementedError("tokenising audio needs the frozen Whisper / WavLM / BEST-RQ encoders "
-                                  "(out of scope, SURVEY.md §2.1 row 15); pass --reason_pt/--semantic_pt instead")
+        if isinstance(wav, str):
+            audio, fs = load_wav(wav)
+            if audio.shape[0] == 2:
+                audio = audio.mean(0, keepdim=True)
+            audio = audio.to(self.device)
+            if fs != self.sample_rate:
+                audio = resample(audio, fs, self.sample_rate)
+            reason, rec = self.audio2token(audio, self.sample_rate, return_reasoning_text, task_name=task_name)
+            return reason.squeeze(0), rec.squeeze(0)
+        raise NotImplementedError
 
+    # ---- tokens -> audio ---------------------------------------------------------------------------------------------
     def codes_to_condition(self, codes):
-        """codes (B, 8, T) -> (B, T, 768): sum of the three RVQ lookups (AudioDiffusion1D.py:570-583)."""
+        """codes (B, 8, T) -> (B, T, 768): sum of the three RVQ look-ups (AudioDiffusion1D.py:570-583) — the conditioning BEFORE
+        cond_feature_emb and the x2 up-sampling (those live in AudioDiffusion1D.codes_to_condition); what `latent_fn` stand-ins
+        of the sub-graph tests receive."""
         groups = (codes[:, 0:1], codes[:, 1:2], codes[:, 2:])
         out = None
         for vq, c in zip(self.vq, groups):
@@ -96,18 +221,30 @@ class ReasoningTokenizer:
     @torch.no_grad()
     def token2audio_no_reason(self, rec_codec, return_reasoning_text=False, duration=20, guidance_scale=1.5, num_steps=20,
                               disable_progress=False):
-        if self.latent_fn is None:
-            raise NotImplementedError("the flow-matching DiT that turns code conditioning into SQ-Codec latents is out of "
-                                      "scope this round (SURVEY.md §8f #1); supply latent_fn for synthetic runs")
+        if self.latent_fn is None and (self.model is None or not hasattr(self.model, "cfm_wrapper")):
+            raise NotImplementedError("decoding needs the codec model with its flow-matching DiT (AudioDiffusion1D(unet_model_config_path=...)) "
+                                      "or a latent_fn stand-in")
         rec_codec = rec_codec.to(self.device)
+        B = rec_codec.shape[0]
         plan = window_plan(rec_codec.shape[-1], duration, self.rec_frame_rate, self.sample_rate, self.sq_codec_hz)
         rec_codec = tile_codes(rec_codec, plan["tiled_len"])
-        segments = []
-        for s0 in plan["starts"]:
-            cond = self.codes_to_condition(rec_codec[:, :, s0:s0 + plan["min_codes"]])
-            latent = self.latent_fn(cond, num_steps).float()                       # (B, latent_length, 136)
-            wav = self.SQCodec.decode(latent.transpose(1, 2).contiguous()).squeeze(0)   # (1, N) per :295
-            segments.append(wav)
+        L = plan["latent_length"]
+        latents = []
+        for i, s0 in enumerate(plan["starts"]):
+            window = rec_codec[:, :, s0:s0 + plan["min_codes"]]
+            if self.latent_fn is not None:
+                lat = self.latent_fn(self.codes_to_condition(window), num_steps).float()
+            elif i == 0:                                             # :271-276: random "true" latent, no in-context frames
+                first = torch.randn(B, L, self.model.sq_codec_latent, device=self.device)
+                lat = self.model.inference_codes([window], None, first, L, 0, additional_feats=[], guidance_scale=1.5, num_steps=num_steps,
+                                                 scenario="other_seg")
+            else:                                                    # :277-284: the previous window's tail as in-context frames
+                true = latents[-1][:, -plan["ovlp_frames"]:, :]
+                pad = torch.randn(B, L - true.shape[1], true.shape[-1], device=self.device)
+                lat = self.model.inference_codes([window], None, torch.cat([true, pad], 1), L, true.shape[1], additional_feats=[],
+                                                 guidance_scale=1.5, num_steps=num_steps, scenario="other_seg")
+            latents.append(lat.float())
+        segments = [self.SQCodec.decode(lat.transpose(1, 2).contiguous()).squeeze(0) for lat in latents]      # (1, N) per :295
         return crossfade_concat(segments, plan["wav_window"], plan["wav_ovlp"], plan["target_len"])
 
     def detokenize_no_reason(self, rec_codec, return_reasoning_text=False, min_duration=30, steps=50, guidance_scale=1.5,
