@@ -261,7 +261,12 @@ enum ua2_act { UA2_ACT_NONE = 0, UA2_ACT_PRELU = 1, UA2_ACT_ELU = 2, UA2_ACT_TAN
  * filters stacked (rows phase*Cout + co, taps of a phase in descending order: ua2 host helper
  * pack_convtr_weight), K = taps per phase, pad_left = K - 1, stride = dilation = 1; result written to
  * y[co][t*P + phase - out_trim_left], Tout = final (trimmed) length.
- * w: ua2_pack_linear(fp32) of the [rows, Cin_pad*K] matrix, Cin padded with zeros to a multiple of 16. */
+ * w: ua2_pack_linear(fp32) of the [rows, Cin_pad*K] matrix, Cin padded with zeros to a multiple of 16.
+ * precision = 1 ("bf16 x 3"): every fp32 operand is split into two bf16 halves and the product taken as
+ * Wh Xh + Wh Xl + Wl Xh on the bf16 MFMA with fp32 accumulation (~2^-16 relative per product instead of exact; 5x the
+ * matrix rate).  w / w_lo then hold the hi / lo halves, each ua2_pack_linear(bf16) of the [rows, G*K*32] matrix whose
+ * reduction index is (channel group of 32, tap, channel in group), Cin zero-padded to a multiple of 32 (host helper
+ * ops.pack_conv_weight_x3). */
 typedef struct ua2_conv1d_args {
   int32_t B, Cin, Cout, Tin, Tout;
   int32_t K, stride, dilation, pad_left;
@@ -275,6 +280,8 @@ typedef struct ua2_conv1d_args {
   int32_t post_alpha_n;            /* 1 or Cout */
   const float* residual;           /* [B, Cout, Tout] or NULL, added after post_act (scalar24k.py:151) */
   float* y;                        /* [B, Cout, Tout] */
+  const void* w_lo;                /* precision 1: packed bf16 low halves of the filter */
+  int32_t precision;               /* 0 = exact fp32 (f32-input MFMA), 1 = bf16 x 3 */
 } ua2_conv1d_args;
 
 int ua2_conv1d(const ua2_conv1d_args* a, void* stream);

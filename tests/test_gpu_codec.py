@@ -17,12 +17,15 @@ def _rms(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-def test_scalar_model_encode_decode_vs_reference(golden_dir):
+@pytest.mark.parametrize("fast_decode", [True, False])
+def test_scalar_model_encode_decode_vs_reference(golden_dir, fast_decode):
+    """fast_decode: the decoder's convolutions on the bf16 x 3 form of ua2_conv1d (the default, what the bench times) or on
+    the exact-fp32 form; both must meet the north_star bound (1e-4 RMS) against the REFERENCE's own waveform."""
     from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
     d = np.load(os.path.join(golden_dir, "codec_toy.npz"))
     m = ScalarModel(**SCALAR_CFG)
     m.load_state_dict(codec_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 21))
-    m = m.cuda().prepare()
+    m = m.cuda().prepare(fast_decode=fast_decode)
     wav = seeded_tensor((2, 1, 16 * 130 + 5), 31, std=0.3).cuda()
     lat = m.encode(wav)
     assert lat.shape == d["scalar_latent"].shape
@@ -30,6 +33,7 @@ def test_scalar_model_encode_decode_vs_reference(golden_dir):
     # decode the REFERENCE's latent (the round(9x)/9 snap makes decode discontinuous in its input)
     rec = m.decode(torch.from_numpy(d["scalar_latent"]).cuda())
     assert rec.shape == d["scalar_wav"].shape
+    print("ScalarModel.decode vs reference, fast=%s: rms %.3e (ref rms %.3e)" % (fast_decode, _rms(rec.cpu().numpy(), d["scalar_wav"]), np.sqrt(np.mean(d["scalar_wav"] ** 2))))
     assert _rms(rec.cpu().numpy(), d["scalar_wav"]) < 1e-4 * max(1.0, float(np.abs(d["scalar_wav"]).max()))
 
 
@@ -181,7 +185,7 @@ BENCH_SCALAR_CFG = dict(num_bands=1, sample_rate=24000, causal=True, num_samples
                         delay_kernel_size=5, init_channel=32, res_kernel_size=7)
 
 
-def _bench_scalar_model():
+def _bench_scalar_model(fast_decode=True):
     """The ScalarModel bench.py times (placeholder widths, hop 960, latent 136) with fan-in scaled seeded weights, and
     the CPU oracle on the same state dict."""
     from oracle.codec_oracle import ScalarOracle
@@ -189,21 +193,22 @@ def _bench_scalar_model():
     m = ScalarModel(**BENCH_SCALAR_CFG)
     sd = codec_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 77)
     m.load_state_dict(sd)
-    return m.cuda().prepare(), ScalarOracle(sd, BENCH_SCALAR_CFG)
+    return m.cuda().prepare(fast_decode=fast_decode), ScalarOracle(sd, BENCH_SCALAR_CFG)
 
 
-def test_scalar_decode_full_20s_window_vs_cpu_oracle():
+@pytest.mark.parametrize("fast_decode", [True, False])
+def test_scalar_decode_full_20s_window_vs_cpu_oracle(fast_decode):
     """One full stage-2 window at the bench's size: ScalarModel.decode of a (1, 136, 500) latent -> 480 000 samples
     against the CPU oracle (pinned on the reference's outputs, tests/test_oracle_codec.py): <= 1e-4 RMS (north_star).
     Covers every time-tile shape of ua2_conv1d (the 12.5 / 50 Hz layers run the 16- and 32-step tiles, the 24 kHz
     layers the 64-step one) and launches with T up to 480 000, which the toy goldens (T <= 2 085) never reach."""
-    m, o = _bench_scalar_model()
+    m, o = _bench_scalar_model(fast_decode)
     lat = torch.tanh(seeded_tensor((1, 136, 500), 99, std=1.0))
     got = m.decode(lat.cuda()).cpu().numpy()
     ref = o.decode(lat).numpy()
     assert got.shape == ref.shape == (1, 1, 480000)
     scale = max(1.0, float(np.sqrt(np.mean(ref ** 2))))
-    print("20-s window decode: rms err %.3e (ref rms %.3e, max |ref| %.3e)" % (_rms(got, ref), np.sqrt(np.mean(ref ** 2)), np.abs(ref).max()))
+    print("20-s window decode (fast=%s): rms err %.3e (ref rms %.3e, max |ref| %.3e)" % (fast_decode, _rms(got, ref), np.sqrt(np.mean(ref ** 2)), np.abs(ref).max()))
     assert _rms(got, ref) < 1e-4 * scale
     assert float(np.abs(got - ref).max()) < 2e-3 * max(1.0, float(np.abs(ref).max()))
 

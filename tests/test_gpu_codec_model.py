@@ -75,13 +75,20 @@ def test_fetch_codes_pipeline_vs_reference_golden_and_oracle():
     m, sd = _toy_model(meta)
     f = fetch_inputs()
     masks = torch.from_numpy(d["fetch_film_masks"])
+    real_vq = m.audio_thinking.reasoning_vq
+    # the golden was produced with identity quantisers (vector_quantize_pytorch is absent where the reference ran), so the
+    # FiLM conditioning of the three branches comes from the UN-quantised query tokens: mirror that for the comparison
+    m.audio_thinking.reasoning_vq = lambda x: (x, torch.zeros(x.shape[0], x.shape[1], 8, dtype=torch.long, device=x.device), None)
     r = m.fetch_codes_from_features(f["whisper"].cuda(), f["wavlm"].cuda(), f["bestrq_acoustic"].cuda(), f["bestrq_semantic"].cuda(),
                                     film_masks=masks, return_intermediates=True)
     for name, key in (("reason_query", "fetch_reason_query"), ("pre_vq_phone", "fetch_pre_vq_phone"), ("pre_vq_semantic", "fetch_pre_vq_semantic"),
                       ("pre_vq_acoustic", "fetch_pre_vq_acoustic")):
         _close(r[name].cpu().numpy(), d[key], 1e-4, name)
     assert r["merge_codes"].shape == (CFG["B"], 15, 8) and r["merge_codes"].dtype == torch.int64
-    assert r["reason_codes"].shape == (CFG["B"], 6, 8)
+    m.audio_thinking.reasoning_vq = real_vq
+    rc, mc, mf = m.fetch_codes_from_features(f["whisper"].cuda(), f["wavlm"].cuda(), f["bestrq_acoustic"].cuda(), f["bestrq_semantic"].cuda(), film_masks=masks)
+    assert rc[0].shape == (CFG["B"], 6, 8) and mc[0].shape == (CFG["B"], 15, 8) and mf[0].shape == (CFG["B"], 15, CFG["D"])
+    assert int(mc[0].max()) < 8192 and int(rc[0].max()) < 4096 and int(mc[0].min()) >= 0
     checked = total = 0
     for key, feat, cols in (("vq_pronunciation_semantic.", d["fetch_pre_vq_phone"], slice(0, 1)), ("vq_structure_semantic.", d["fetch_pre_vq_semantic"], slice(1, 2)),
                             ("vq_acoustic.", d["fetch_pre_vq_acoustic"], slice(2, 8))):

@@ -21,8 +21,11 @@ CONV_CASES = [
 ]
 
 
+# fast = the bf16 x 3 form of the kernel (16-bit split operands on the bf16 MFMA, fp32 accumulate): ~2^-16 relative per
+# product instead of exact fp32; tolerance 1e-4 of the output scale (measured 1e-5), the exact form keeps 2e-5
+@pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("Cin,Cout,K,stride,dil,causal,T", CONV_CASES)
-def test_conv1d_matches_torch(Cin, Cout, K, stride, dil, causal, T):
+def test_conv1d_matches_torch(Cin, Cout, K, stride, dil, causal, T, fast):
     from uniaudio2_amd import ops
     from uniaudio2_amd._lib import ACT_PRELU
     g = torch.Generator().manual_seed(Cin * 7 + K)
@@ -41,15 +44,16 @@ def test_conv1d_matches_torch(Cin, Cout, K, stride, dil, causal, T):
     ref = F.prelu(F.conv1d(xp, w, b, stride=stride, dilation=dil), alpha)
     res = torch.randn(ref.shape, generator=g)
     ref = ref + res
-    wp, _ = ops.pack_conv_weight(w.cuda())
+    wp, wlo = ops.pack_conv_weight_x3(w.cuda()) if fast else (ops.pack_conv_weight(w.cuda())[0], None)
     y = ops.conv1d(x.cuda(), wp, K, Cout, stride=stride, dilation=dil, pad_left=pad_l, Tout=ref.shape[-1], bias=b.cuda(),
-                   post_act=ACT_PRELU, post_alpha=alpha.cuda(), residual=res.cuda())
-    _close(y, ref)
+                   post_act=ACT_PRELU, post_alpha=alpha.cuda(), residual=res.cuda(), w_lo=wlo)
+    _close(y, ref, tol=1e-4 if fast else 2e-5)
 
 
 @pytest.mark.parametrize("Cin,Cout,stride,K,causal,T", [(64, 32, 2, 4, True, 333), (128, 64, 5, 10, True, 64), (32, 32, 3, 6, True, 200),
                                                         (64, 64, 4, 8, False, 100), (512, 256, 8, 16, True, 25), (16, 16, 2, 2, False, 50)])
-def test_conv_transpose1d_matches_torch(Cin, Cout, stride, K, causal, T):
+@pytest.mark.parametrize("fast", [False, True])
+def test_conv_transpose1d_matches_torch(Cin, Cout, stride, K, causal, T, fast):
     from uniaudio2_amd import ops
     g = torch.Generator().manual_seed(Cin + stride)
     x = torch.randn(2, Cin, T, generator=g)
@@ -61,9 +65,10 @@ def test_conv_transpose1d_matches_torch(Cin, Cout, stride, K, causal, T):
     else:                                        # padding = (k - s) // 2
         trim = (K - stride) // 2
         ref = F.conv_transpose1d(x, w, b, stride=stride, padding=trim)
-    wp, M = ops.pack_convtr_weight(w.cuda(), stride)
-    y = ops.conv1d(x.cuda(), wp, M, Cout, pad_left=M - 1, Tout=ref.shape[-1], bias=b.cuda(), out_phases=stride, out_trim_left=trim)
-    _close(y, ref)
+    rows, M = ops.convtr_phase_rows(w.cuda(), stride)
+    wp, wlo = ops.pack_conv_weight_x3(rows) if fast else (ops.pack_convtr_weight(w.cuda(), stride)[0], None)
+    y = ops.conv1d(x.cuda(), wp, M, Cout, pad_left=M - 1, Tout=ref.shape[-1], bias=b.cuda(), out_phases=stride, out_trim_left=trim, w_lo=wlo)
+    _close(y, ref, tol=1e-4 if fast else 2e-5)
 
 
 def test_conv1d_pre_activation_repeat_and_pool():
@@ -83,6 +88,13 @@ def test_conv1d_pre_activation_repeat_and_pool():
     # decode entry: round(9x)/9 on the input (scalar24k.py:404)
     ref = F.conv1d(F.pad(torch.round(9 * x) / 9, (1, 1)), w)
     _close(ops.conv1d(x.cuda(), wp, 3, 64, pad_left=1, Tout=150, pre_act=ACT_ROUND9), ref)
+    # the same three through the bf16 x 3 form
+    wh, wl = ops.pack_conv_weight_x3(w.cuda())
+    _close(ops.conv1d(x.cuda(), wh, 3, 64, pad_left=1, Tout=150, pre_act=ACT_ROUND9, w_lo=wl), ref, tol=1e-4)
+    ref = torch.tanh(F.conv1d(F.pad(xr, (2, 0)), w))
+    _close(ops.conv1d(x.cuda(), wh, 3, 64, pad_left=2, Tout=300, in_repeat=2, post_act=ACT_TANH, w_lo=wl), ref, tol=1e-4)
+    ref = F.conv1d(F.pad(F.elu(x), (4, 0)), w, dilation=2)
+    _close(ops.conv1d(x.cuda(), wh, 3, 64, dilation=2, pad_left=4, Tout=150, pre_act=ACT_ELU, w_lo=wl), ref, tol=1e-4)
     _close(ops.avgpool1d(x.cuda(), 2), F.avg_pool1d(x, 2), tol=1e-6)
 
 

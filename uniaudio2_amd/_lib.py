@@ -52,7 +52,7 @@ class Conv1dArgs(C.Structure):
     _fields_ = [("B", i32), ("Cin", i32), ("Cout", i32), ("Tin", i32), ("Tout", i32), ("K", i32), ("stride", i32),
                 ("dilation", i32), ("pad_left", i32), ("in_repeat", i32), ("out_phases", i32), ("out_trim_left", i32),
                 ("pre_act", i32), ("post_act", i32), ("x", vp), ("w", vp), ("bias", vp), ("pre_alpha", vp),
-                ("post_alpha", vp), ("post_alpha_n", i32), ("residual", vp), ("y", vp)]
+                ("post_alpha", vp), ("post_alpha_n", i32), ("residual", vp), ("y", vp), ("w_lo", vp), ("precision", i32)]
 
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_TANH, ACT_ROUND9 = 0, 1, 2, 3, 4

@@ -122,6 +122,122 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
   }
 }
 
+// ---- bf16 x 3 form ("precision = 1") --------------------------------------------------------------------
+// The exact-fp32 kernel above is bound by the f32 matrix pipe (1/16 of the bf16 rate), 4x slower than the bytes it
+// moves.  Here every fp32 operand is split into two bf16 halves (hi = RNE(x), lo = RNE(x - hi): 16 significant
+// bits together) and the product is taken as  Wh Xh + Wh Xl + Wl Xh  on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation: 3 MFMAs at 16x the rate = 5.3x the f32 pipe; the dropped Wl Xl term and the split's own rounding are
+// ~2^-16 relative per product (measured end to end against the goldens: DESIGN.md §5).  The exact kernel stays the
+// reference for that measurement and serves the encode side (its latents feed integer decisions).
+//
+// Layout.  K index of the implicit GEMM = (channel group of 32, tap j, channel within the group): one MFMA K-chunk
+// is ONE tap over 32 input channels.  The input window of a channel group is staged in LDS time-major:
+// plane[w][32 channels] of bf16 (hi plane, lo plane; 80-byte rows: 64 B of channels + 16 B pad so that neither the
+// transposing writes nor the 16-byte reads collide on banks), so the B operand of a (tap, time tile) is one
+// ds_read_b128 per lane per plane: lane (g = lane >> 4, t = lane & 15) reads channels 8g..8g+7 at window position
+// (t0 + t) * stride + j * dilation.  No per-element address tables, no integer division in the staging loop.
+// Weights come pre-split and pre-tiled ([rows/16][chunks][64 lanes][16 B], hi and lo buffers) straight from L2, one
+// chunk ahead of the MFMAs.  A wave owns 16 output rows x NTT time tiles; the four waves of a workgroup cover
+// `rt` row tiles x (4 / rt) time sub-blocks, so layers with 32 or 16 output rows still use every wave.
+constexpr int kCG3 = 32;       // channels per staging group
+constexpr int kRowB = 80;      // LDS bytes per window position per plane
+
+template <int NTT>
+__global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a, const int rt) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  const int K = a.K, s = a.stride, d = a.dilation;
+  const int tsub = 4 / rt;
+  constexpr int kBT = 16 * NTT;                        // time steps per wave
+  const int wgt = kBT * tsub;                          // time steps per workgroup
+  const int W = (wgt - 1) * s + (K - 1) * d + 1;       // staged window positions
+  char* xh = smc;
+  char* xl = smc + (size_t)W * kRowB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tl = lane & 15, g = lane >> 4;
+  const int wr = wave % rt, wt = wave / rt;
+  const int t0 = blockIdx.x * wgt;
+  const int tw0 = wt * kBT;
+  const int r0 = (blockIdx.y * rt + wr) * 16;
+  const int b = blockIdx.z;
+  const int rows = a.Cout * a.out_phases;
+  const int ngroups = (a.Cin + kCG3 - 1) / kCG3;
+  const int nchunks = ngroups * K;
+  const int tin_eff = a.Tin * a.in_repeat;
+  const bool wave_active = r0 < rows;
+  const u32x4* wph = reinterpret_cast<const u32x4*>(a.w) + (size_t)(r0 / 16) * nchunks * 64 + lane;
+  const u32x4* wpl = reinterpret_cast<const u32x4*>(a.w_lo) + (size_t)(r0 / 16) * nchunks * 64 + lane;
+  const float pre_alpha = (a.pre_act == UA2_ACT_PRELU && a.pre_alpha) ? a.pre_alpha[0] : 0.f;
+  const int in_start = t0 * s - a.pad_left;
+
+  f32x4 acc[NTT];
+#pragma unroll
+  for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging walk of this thread: (channel pair p, window position wi), advanced by 256 elements per step without a division
+  const int p_step = 256 / W, w_step = 256 - p_step * W;
+  const int p_first = tid / W, w_first = tid - p_first * W;
+  // first weight chunk
+  u32x4 wh = u32x4{0u, 0u, 0u, 0u}, wl = wh;
+  if (wave_active) { wh = wph[0]; wl = wpl[0]; }
+
+  for (int cg = 0; cg < ngroups; ++cg) {
+    __syncthreads();
+    for (int p = p_first, wi = w_first; p < kCG3 / 2; ) {
+      const int ci = cg * kCG3 + 2 * p, ti = in_start + wi;
+      float v0 = 0.f, v1 = 0.f;
+      if (ti >= 0 && ti < tin_eff) {
+        const int tsrc = (a.in_repeat == 1) ? ti : (a.in_repeat == 2 ? (ti >> 1) : ti / a.in_repeat);
+        const size_t off = ((size_t)b * a.Cin + ci) * a.Tin + tsrc;
+        if (ci < a.Cin) v0 = apply_act(a.x[off], a.pre_act, pre_alpha);
+        if (ci + 1 < a.Cin) v1 = apply_act(a.x[off + a.Tin], a.pre_act, pre_alpha);
+      }
+      const unsigned h0 = f2bf(v0), h1 = f2bf(v1);
+      const unsigned l0 = f2bf(v0 - bf2f((unsigned short)h0)), l1 = f2bf(v1 - bf2f((unsigned short)h1));
+      *reinterpret_cast<unsigned*>(xh + (size_t)wi * kRowB + p * 4) = h0 | (h1 << 16);
+      *reinterpret_cast<unsigned*>(xl + (size_t)wi * kRowB + p * 4) = l0 | (l1 << 16);
+      p += p_step; wi += w_step;
+      if (wi >= W) { wi -= W; ++p; }
+    }
+    __syncthreads();
+    if (wave_active) {
+      for (int j = 0; j < K; ++j) {
+        const int chunk = cg * K + j;
+        const u32x4 ch = wh, cl = wl;
+        if (chunk + 1 < nchunks) { wh = wph[(size_t)(chunk + 1) * 64]; wl = wpl[(size_t)(chunk + 1) * 64]; }   // one chunk ahead
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ch), al = __builtin_bit_cast(bf16x8, cl);
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+          const size_t o = (size_t)((tw0 + nt * 16 + tl) * s + j * d) * kRowB + g * 16;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xh + o));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + o));
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[nt], 0, 0, 0);   // small terms first
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_active) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = r0 + g * 4 + r;
+    if (n >= rows) continue;
+    const int phase = n / a.Cout, co = n - phase * a.Cout;
+    const float bias = a.bias ? a.bias[co] : 0.f;
+    const float alpha = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? co : 0] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) {
+      const int t = t0 + tw0 + nt * 16 + tl;
+      const int to = t * a.out_phases + phase - a.out_trim_left;
+      if (to < 0 || to >= a.Tout) continue;
+      float v = acc[nt][r] + bias;
+      v = apply_act(v, a.post_act, alpha);
+      const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
+      if (a.residual) v += a.residual[o];
+      a.y[o] = v;
+    }
+  }
+}
+
 __global__ void avgpool1d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int Tin, int Tout, int k) {
   const int64_t total = rows * Tout;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -186,6 +302,28 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
   UA2_CHECK(a->out_phases == 1 || (a->stride == 1 && a->dilation == 1), "ua2_conv1d: phase mode needs stride=dilation=1");
   UA2_CHECK(a->post_act != UA2_ACT_PRELU || a->post_alpha, "ua2_conv1d: PReLU needs post_alpha");
   const int tq = a->out_phases == 1 ? a->Tout : ua2_ceil_div(a->Tout + a->out_trim_left, a->out_phases);
+  if (a->precision == 1) {
+    UA2_CHECK(a->w_lo != nullptr, "ua2_conv1d: precision 1 (bf16 x 3) needs w_lo (ua2 host helper pack_conv_weight_x3)");
+    const int rows = a->Cout * a->out_phases;
+    const int rt = rows > 32 ? 4 : (rows > 16 ? 2 : 1);
+    const int row_blocks3 = ua2_ceil_div(rows, 16 * rt);
+    int ntt = 4;
+    while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / rt)) * row_blocks3 * a->B < 512) ntt >>= 1;
+    const int wgt = 16 * ntt * (4 / rt);
+    const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+    const size_t smem3 = (size_t)2 * W3 * kRowB;
+    UA2_CHECK(smem3 <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem3);
+    ua2_allow_big_lds<conv1d_x3_kernel<4>>();
+    ua2_allow_big_lds<conv1d_x3_kernel<2>>();
+    ua2_allow_big_lds<conv1d_x3_kernel<1>>();
+    const dim3 grid3(ua2_ceil_div(tq, wgt), row_blocks3, a->B);
+    if (ntt == 4) hipLaunchKernelGGL(conv1d_x3_kernel<4>, grid3, dim3(256), smem3, (hipStream_t)stream, *a, rt);
+    else if (ntt == 2) hipLaunchKernelGGL(conv1d_x3_kernel<2>, grid3, dim3(256), smem3, (hipStream_t)stream, *a, rt);
+    else hipLaunchKernelGGL(conv1d_x3_kernel<1>, grid3, dim3(256), smem3, (hipStream_t)stream, *a, rt);
+    UA2_LAUNCH_CHECK();
+    return 0;
+  }
+  UA2_CHECK(a->precision == 0, "ua2_conv1d: precision must be 0 (exact fp32) or 1 (bf16 x 3)");
   const int row_blocks = ua2_ceil_div((int64_t)a->Cout * a->out_phases, kBR);
   // largest time tile that still gives >= 512 workgroups (2 per CU); never below 16 steps
   int ntt = 4;

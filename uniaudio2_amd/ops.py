@@ -175,23 +175,41 @@ def pack_conv_weight(w):
     return pack_linear(wp.view(Cout, cin_pad * K), torch.float32), K
 
 
-def pack_convtr_weight(w, stride):
-    """nn.ConvTranspose1d weight [Cin, Cout, K] -> the `stride` phase filters of ua2_conv1d's phase mode:
+def convtr_phase_rows(w, stride):
+    """nn.ConvTranspose1d weight [Cin, Cout, K] -> [stride * Cout, Cin, M] phase filters of ua2_conv1d's phase mode:
     row phase*Cout + co, taps in descending order (x index q - m  <->  original tap phase + m*stride)."""
     Cin, Cout, K = w.shape
     M = (K + stride - 1) // stride
-    cin_pad = (Cin + 15) // 16 * 16
-    wp = torch.zeros(stride, Cout, cin_pad, M, dtype=torch.float32, device=w.device)
+    wp = torch.zeros(stride, Cout, Cin, M, dtype=torch.float32, device=w.device)
     for ph in range(stride):
         for m in range(M):
             j = ph + m * stride
             if j < K:
-                wp[ph, :, :Cin, M - 1 - m] = w[:, :, j].float().t()
-    return pack_linear(wp.view(stride * Cout, cin_pad * M), torch.float32), M
+                wp[ph, :, :, M - 1 - m] = w[:, :, j].float().t()
+    return wp.view(stride * Cout, Cin, M), M
+
+
+def pack_convtr_weight(w, stride):
+    """Packed fp32 phase filters of a transposed conv for the exact ua2_conv1d (see convtr_phase_rows)."""
+    rows, M = convtr_phase_rows(w, stride)
+    return pack_conv_weight(rows)[0], M
+
+
+def pack_conv_weight_x3(w_rows):
+    """[rows, Cin, K] fp32 filter (rows = Cout, or phases * Cout for a transposed conv) -> (hi, lo) packed bf16 buffers for
+    ua2_conv1d precision 1: reduction index (channel group of 32, tap, channel in group), Cin zero-padded to 32."""
+    rows, Cin, K = w_rows.shape
+    G = (Cin + 31) // 32
+    wp = torch.zeros(rows, G * 32, K, dtype=torch.float32, device=w_rows.device)
+    wp[:, :Cin] = w_rows.float()
+    wk = wp.view(rows, G, 32, K).permute(0, 1, 3, 2).reshape(rows, G * K * 32).contiguous()
+    hi = wk.to(torch.bfloat16)
+    lo = (wk - hi.float()).contiguous()
+    return pack_linear(hi.float().contiguous(), torch.bfloat16), pack_linear(lo, torch.bfloat16)
 
 
 def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None, bias=None, pre_act=0, pre_alpha=None,
-           post_act=0, post_alpha=None, residual=None, in_repeat=1, out_phases=1, out_trim_left=0):
+           post_act=0, post_alpha=None, residual=None, in_repeat=1, out_phases=1, out_trim_left=0, w_lo=None):
     from ._lib import Conv1dArgs
     B, Cin, Tin = x.shape
     a = Conv1dArgs()
@@ -204,6 +222,8 @@ def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None,
     a.pre_alpha, a.post_alpha = ptr(pre_alpha), ptr(post_alpha)
     a.post_alpha_n = post_alpha.numel() if post_alpha is not None else 0
     a.residual, a.y = ptr(residual), ptr(y)
+    if w_lo is not None:                  # bf16 x 3 form: (w_packed, w_lo) = pack_conv_weight_x3(...)
+        a.w_lo, a.precision = ptr(w_lo), 1
     check(lib.ua2_conv1d(C.byref(a), stream()), "ua2_conv1d")
     return y
 
