@@ -78,7 +78,11 @@ def test_fetch_codes_pipeline_vs_reference_golden_and_oracle():
     real_vq = m.audio_thinking.reasoning_vq
     # the golden was produced with identity quantisers (vector_quantize_pytorch is absent where the reference ran), so the
     # FiLM conditioning of the three branches comes from the UN-quantised query tokens: mirror that for the comparison
-    m.audio_thinking.reasoning_vq = lambda x: (x, torch.zeros(x.shape[0], x.shape[1], 8, dtype=torch.long, device=x.device), None)
+    class IdentityVQ(torch.nn.Module):
+        def forward(self, x):
+            return x, torch.zeros(x.shape[0], x.shape[1], 8, dtype=torch.long, device=x.device), None
+
+    m.audio_thinking.reasoning_vq = IdentityVQ()
     r = m.fetch_codes_from_features(f["whisper"].cuda(), f["wavlm"].cuda(), f["bestrq_acoustic"].cuda(), f["bestrq_semantic"].cuda(),
                                     film_masks=masks, return_intermediates=True)
     for name, key in (("reason_query", "fetch_reason_query"), ("pre_vq_phone", "fetch_pre_vq_phone"), ("pre_vq_semantic", "fetch_pre_vq_semantic"),
@@ -117,8 +121,9 @@ def test_inference_codes_and_euler_vs_reference_golden(tag):
         m.zero_cond_embedding1.copy_(i["zero_cond"])
     m.prepare()
 
-    class Table:
+    class Table(torch.nn.Module):
         def __init__(self, t):
+            super().__init__()
             self.t = t.cuda()
 
         def get_output_from_indices(self, idx):
@@ -194,7 +199,7 @@ def test_stage_all_decode_runs_at_real_dit_size():
 
 def test_config1_codec_plumbing_p225(tmp_path):
     """BASELINE.json config 1: samples/p225_002.wav (fixture: its 86 848 samples at 22 050 Hz) -> load ->
-    resample to 24 kHz (94 529 samples) -> ScalarModel.encode -> latent (1, 136, 98); synthetic features (1, 50, 768) seed 0
+    resample to 24 kHz (94 529 samples) -> ScalarModel.encode -> latent (1, 136, 99); synthetic features (1, 50, 768) seed 0
     -> RVQ 1 + 1 + 6 levels of 8192 x 32 (seed 1) -> codes (8, 50) -> `*_semantic.pt` round trip -> look-up ->
     stand-in latent -> ScalarModel.decode.  GPU vs the CPU oracles: resampler 1e-5, latent 1e-5 rms, codes equal (near-tie
     frames enumerated: none allowed above the fp32-noise margin), wav 1e-4 rms."""
@@ -217,7 +222,7 @@ def test_config1_codec_plumbing_p225(tmp_path):
     sq, so = _bench_scalar_model()
     lat = sq.encode(ref24.view(1, 1, -1).cuda()).cpu()
     lat_ref = so.encode(ref24.view(1, 1, -1))
-    assert lat.shape == lat_ref.shape == (1, 136, 98)
+    assert lat.shape == lat_ref.shape == (1, 136, 99)          # 94 529 samples / hop 960, causal padding: 99 latent frames
     assert float(((lat - lat_ref) ** 2).mean().sqrt()) < 1e-5
     # synthetic features -> the three RVQs (phone 1, semantic 1, acoustic 6 levels; AudioDiffusion1D.py:256-264)
     feats = torch.randn(1, 50, 768, generator=torch.Generator().manual_seed(0))

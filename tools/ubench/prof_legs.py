@@ -1,0 +1,30 @@
+"""Profile driver (rocprofv3 --kernel-trace --stats -- python tools/ubench/prof_legs.py LEG): one information leg of bench.py
+per run so that the kernel-stats table is that leg's alone.  LEG in {config3, batched, config5, codec, frame}."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+import bench
+
+leg = sys.argv[1] if len(sys.argv) > 1 else "config3"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+if leg == "codec":
+    print(bench.codec_leg(dev))
+    sys.exit(0)
+model = bench.build_model(dev)
+if leg == "config3":
+    print(bench.config3_leg(model, dev))
+elif leg == "batched":
+    print(bench.batched_leg(model, dev))
+elif leg == "config5":
+    print(bench.config5_leg(model, dev, frames=120))
+else:
+    model.setup_caches(1, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=128)
+    t, m = bench.make_prompt(dev, 1000)
+    for _ in range(3):
+        bench.utterance(model, t, m)
+    torch.cuda.synchronize()
+    print("ok")
