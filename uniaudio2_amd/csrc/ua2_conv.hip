@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
 constexpr int kCG3 = 32;       // channels per staging group
 constexpr int kRowB = 80;      // LDS bytes per window position per plane
 
-template <int NTT>
+template <int NTT, int RPW>
 __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a, const int rt) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
   const int K = a.K, s = a.stride, d = a.dilation;
@@ -157,27 +157,40 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
   const int wr = wave % rt, wt = wave / rt;
   const int t0 = blockIdx.x * wgt;
   const int tw0 = wt * kBT;
-  const int r0 = (blockIdx.y * rt + wr) * 16;
+  const int r0 = (blockIdx.y * rt + wr) * (16 * RPW);  // RPW row tiles per wave: every x fragment read from LDS feeds RPW x 3 MFMAs
   const int b = blockIdx.z;
   const int rows = a.Cout * a.out_phases;
   const int ngroups = (a.Cin + kCG3 - 1) / kCG3;
   const int nchunks = ngroups * K;
   const int tin_eff = a.Tin * a.in_repeat;
   const bool wave_active = r0 < rows;
-  const u32x4* wph = reinterpret_cast<const u32x4*>(a.w) + (size_t)(r0 / 16) * nchunks * 64 + lane;
-  const u32x4* wpl = reinterpret_cast<const u32x4*>(a.w_lo) + (size_t)(r0 / 16) * nchunks * 64 + lane;
+  const int ntile_rows = (rows + 15) / 16;
+  const u32x4* wph[RPW];
+  const u32x4* wpl[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int tile = min(r0 / 16 + q, ntile_rows - 1);  // a wave's second tile may lie past the last row tile: clamped load, masked store
+    wph[q] = reinterpret_cast<const u32x4*>(a.w) + (size_t)tile * nchunks * 64 + lane;
+    wpl[q] = reinterpret_cast<const u32x4*>(a.w_lo) + (size_t)tile * nchunks * 64 + lane;
+  }
   const float pre_alpha = (a.pre_act == UA2_ACT_PRELU && a.pre_alpha) ? a.pre_alpha[0] : 0.f;
   const int in_start = t0 * s - a.pad_left;
 
-  f32x4 acc[NTT];
+  f32x4 acc[RPW][NTT];
 #pragma unroll
-  for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < RPW; ++q)
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) acc[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // staging walk of this thread: (channel pair p, window position wi), advanced by 256 elements per step without a division
   const int p_step = 256 / W, w_step = 256 - p_step * W;
   const int p_first = tid / W, w_first = tid - p_first * W;
-  // first weight chunk
-  u32x4 wh = u32x4{0u, 0u, 0u, 0u}, wl = wh;
-  if (wave_active) { wh = wph[0]; wl = wpl[0]; }
+  u32x4 wh[RPW], wl[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) { wh[q] = u32x4{0u, 0u, 0u, 0u}; wl[q] = wh[q]; }
+  if (wave_active) {
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) { wh[q] = wph[q][0]; wl[q] = wpl[q][0]; }
+  }
 
   for (int cg = 0; cg < ngroups; ++cg) {
     __syncthreads();
@@ -201,41 +214,58 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
     if (wave_active) {
       for (int j = 0; j < K; ++j) {
         const int chunk = cg * K + j;
-        const u32x4 ch = wh, cl = wl;
-        if (chunk + 1 < nchunks) { wh = wph[(size_t)(chunk + 1) * 64]; wl = wpl[(size_t)(chunk + 1) * 64]; }   // one chunk ahead
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, ch), al = __builtin_bit_cast(bf16x8, cl);
+        bf16x8 ah[RPW], al[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) { ah[q] = __builtin_bit_cast(bf16x8, wh[q]); al[q] = __builtin_bit_cast(bf16x8, wl[q]); }
+        if (chunk + 1 < nchunks) {                                    // one chunk ahead
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) { wh[q] = wph[q][(size_t)(chunk + 1) * 64]; wl[q] = wpl[q][(size_t)(chunk + 1) * 64]; }
+        }
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
           const size_t o = (size_t)((tw0 + nt * 16 + tl) * s + j * d) * kRowB + g * 16;
           const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xh + o));
           const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + o));
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[nt], 0, 0, 0);   // small terms first
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[nt], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) {
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh, acc[q][nt], 0, 0, 0);   // small terms first
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl, acc[q][nt], 0, 0, 0);
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh, acc[q][nt], 0, 0, 0);
+          }
         }
       }
     }
   }
   if (!wave_active) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = r0 + g * 4 + r;
-    if (n >= rows) continue;
-    const int phase = n / a.Cout, co = n - phase * a.Cout;
-    const float bias = a.bias ? a.bias[co] : 0.f;
-    const float alpha = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? co : 0] : 0.f;
+  for (int q = 0; q < RPW; ++q) {
 #pragma unroll
-    for (int nt = 0; nt < NTT; ++nt) {
-      const int t = t0 + tw0 + nt * 16 + tl;
-      const int to = t * a.out_phases + phase - a.out_trim_left;
-      if (to < 0 || to >= a.Tout) continue;
-      float v = acc[nt][r] + bias;
-      v = apply_act(v, a.post_act, alpha);
-      const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
-      if (a.residual) v += a.residual[o];
-      a.y[o] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int n = r0 + q * 16 + g * 4 + r;
+      if (n >= rows) continue;
+      const int phase = n / a.Cout, co = n - phase * a.Cout;
+      const float bias = a.bias ? a.bias[co] : 0.f;
+      const float alpha = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? co : 0] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        const int t = t0 + tw0 + nt * 16 + tl;
+        const int to = t * a.out_phases + phase - a.out_trim_left;
+        if (to < 0 || to >= a.Tout) continue;
+        float v = acc[q][nt][r] + bias;
+        v = apply_act(v, a.post_act, alpha);
+        const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
+        if (a.residual) v += a.residual[o];
+        a.y[o] = v;
+      }
     }
   }
+}
+
+template <int NTT, int RPW>
+void launch_x3(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, hipStream_t s) {
+  constexpr auto kern = conv1d_x3_kernel<NTT, RPW>;
+  ua2_allow_big_lds<kern>();
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a, rt);
 }
 
 __global__ void avgpool1d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int Tin, int Tout, int k) {
@@ -305,21 +335,27 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
   if (a->precision == 1) {
     UA2_CHECK(a->w_lo != nullptr, "ua2_conv1d: precision 1 (bf16 x 3) needs w_lo (ua2 host helper pack_conv_weight_x3)");
     const int rows = a->Cout * a->out_phases;
-    const int rt = rows > 32 ? 4 : (rows > 16 ? 2 : 1);
-    const int row_blocks3 = ua2_ceil_div(rows, 16 * rt);
+    const int rpw = rows > 16 ? 2 : 1;                                   // row tiles per wave
+    const int wave_rows = 16 * rpw;
+    const int rt = rows > 2 * wave_rows ? 4 : (rows > wave_rows ? 2 : 1);  // wave row-groups per workgroup; the other waves split time
+    const int row_blocks3 = ua2_ceil_div(rows, wave_rows * rt);
     int ntt = 4;
     while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / rt)) * row_blocks3 * a->B < 512) ntt >>= 1;
     const int wgt = 16 * ntt * (4 / rt);
     const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
     const size_t smem3 = (size_t)2 * W3 * kRowB;
     UA2_CHECK(smem3 <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem3);
-    ua2_allow_big_lds<conv1d_x3_kernel<4>>();
-    ua2_allow_big_lds<conv1d_x3_kernel<2>>();
-    ua2_allow_big_lds<conv1d_x3_kernel<1>>();
     const dim3 grid3(ua2_ceil_div(tq, wgt), row_blocks3, a->B);
-    if (ntt == 4) hipLaunchKernelGGL(conv1d_x3_kernel<4>, grid3, dim3(256), smem3, (hipStream_t)stream, *a, rt);
-    else if (ntt == 2) hipLaunchKernelGGL(conv1d_x3_kernel<2>, grid3, dim3(256), smem3, (hipStream_t)stream, *a, rt);
-    else hipLaunchKernelGGL(conv1d_x3_kernel<1>, grid3, dim3(256), smem3, (hipStream_t)stream, *a, rt);
+    hipStream_t st = (hipStream_t)stream;
+    if (rpw == 2) {
+      if (ntt == 4) launch_x3<4, 2>(*a, grid3, smem3, rt, st);
+      else if (ntt == 2) launch_x3<2, 2>(*a, grid3, smem3, rt, st);
+      else launch_x3<1, 2>(*a, grid3, smem3, rt, st);
+    } else {
+      if (ntt == 4) launch_x3<4, 1>(*a, grid3, smem3, rt, st);
+      else if (ntt == 2) launch_x3<2, 1>(*a, grid3, smem3, rt, st);
+      else launch_x3<1, 1>(*a, grid3, smem3, rt, st);
+    }
     UA2_LAUNCH_CHECK();
     return 0;
   }
