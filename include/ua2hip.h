@@ -187,6 +187,16 @@ typedef struct ua2_attn_args {
                              transformer.py:405-406: delta < context); 0 = all positions <= row_pos */
   void* y_packed;         /* optional: the output rounded to `dtype` in the packed operand layout of the
                              O-projection (ua2_linear_args.x_packed), K = n_head*head_size */
+  /* Grouped form (prefill of prompts, dense encoders, the DiT): when group_rows != NULL and dtype == UA2_BF16 the rows
+     are processed by an MFMA flash kernel with LDS-staged K/V pages instead of row by row.  The host lists, per group,
+     up to group_q_tiles * 16 query rows OF ONE SEQUENCE (row indices into q / row_pos, -1 = padding); rows outside every
+     group are not computed.  Same arithmetic contract (bf16 K/V, fp32-grade q and softmax), a row's result independent
+     of how rows are grouped. */
+  const int32_t* group_rows;   /* [n_groups, group_q_tiles * 16] device */
+  const int32_t* group_seq;    /* [n_groups] page-table row of the group's sequence */
+  const int32_t* group_nkeys;  /* [n_groups] 1 + the largest row_pos in the group (keys visited: 0 .. nkeys-1) */
+  int32_t n_groups;
+  int32_t group_q_tiles;       /* 16-row tiles per group: 2 with grouped-query heads (n_head > n_kv), 4 with n_head == n_kv */
 } ua2_attn_args;
 
 int ua2_attn(const ua2_attn_args* a, void* stream);
@@ -388,6 +398,11 @@ void ua2_stage3_destroy(ua2_stage3* h);
  * The seed is written to counters[2..3] on `stream` (stream-ordered with the frames that follow); topk / temperature
  * select the captured graph, the seed does not. */
 int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint64_t seed, void* stream);
+/* Row groups (ua2_attn_args.group_*; device tables owned by the caller, alive until replaced) for the attention of the
+ * NEXT ua2_stage3_trunk call (they are cleared when it returns): prefill rows of one sequence then share LDS-staged K/V
+ * pages on the MFMA flash kernel.  ua2_stage3_frame (decode) never uses groups. */
+int ua2_stage3_set_prefill_groups(ua2_stage3* h, const int32_t* group_rows, const int32_t* group_seq, const int32_t* group_nkeys,
+                                  int32_t n_groups, int32_t group_q_tiles);
 /* cfg_scale > 1: frames of exactly two rows (conditional, unconditional) sample from the guided logits (ua2_cfg_mix). */
 int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale);
 

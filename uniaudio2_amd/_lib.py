@@ -45,7 +45,8 @@ class LinearArgs(C.Structure):
 
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("kv", KvGeom), ("y", vp),
-                ("window", i32), ("y_packed", vp)]
+                ("window", i32), ("y_packed", vp), ("group_rows", vp), ("group_seq", vp), ("group_nkeys", vp), ("n_groups", i32),
+                ("group_q_tiles", i32)]
 
 
 class Conv1dArgs(C.Structure):
@@ -110,6 +111,7 @@ _EXPORTS = {
     "ua2_stage3_destroy": (None, [vp]),
     "ua2_sample_topk": (C.c_int, [C.c_int, i32, vp, i32, i32, i32, f32, vp, C.c_uint64, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp]),
     "ua2_stage3_set_sampling": (C.c_int, [vp, i32, f32, C.c_uint64, vp]),
+    "ua2_stage3_set_prefill_groups": (C.c_int, [vp, vp, vp, vp, i32, i32]),
     "ua2_stage3_trunk": (C.c_int, [vp, i32, vp]),
     "ua2_stage3_heads": (C.c_int, [vp, i32, vp]),
     "ua2_stage3_feedback": (C.c_int, [vp, i32, i32, i32, i32, vp]),

@@ -258,6 +258,203 @@ int launch_fused(const ua2_attn_args& a, hipStream_t s) {
   return 0;
 }
 
+// ---- many query rows per sequence: MFMA flash attention (prefill, dense encoders / DiT) -------------------------
+// north_star: "MFMA ... with LDS-staged KV tiles".  The row-by-row kernel above re-reads a sequence's K/V once per
+// query row (258 us per layer at 2048 prefill rows, 1.2 ms at 32 x 195, profiles/r2_*); here a workgroup takes up to
+// QT x 16 query rows of ONE sequence for one kv head, stages each 64-position K / V page of that head in LDS once
+// (the page is contiguous in the pool), and its QT x G waves — one per (16-row tile, query head of the group) — run
+//     S^T = K Q^T      v_mfma_f32_16x16x32_bf16, A = K rows from LDS, B = the wave's Q tile (registers)
+//     online softmax   per query row = per lane column (q = lane & 15); 16 local values + two cross-group shuffles
+//     O^T += V^T P^T   A = V^T from LDS (V is transposed by the staging writes), B = P straight from the S^T registers
+// The transposed formulation keeps everything "query = lane & 15"-major: the S^T accumulator registers ARE the B operand
+// of the second product (its reduction index is simply enumerated as the accumulator holds the keys: 4 + 4 per 32-key
+// chunk, which V^T is read to match), so P never travels through LDS, and the softmax rescale is lane-local.
+// Numerics (bf16 contract, DESIGN.md §2: K/V bf16, everything else fp32): q (pre-scaled by log2(e)/sqrt(hs)) and p are
+// split into bf16 hi + lo halves (16 significant bits, two MFMAs each), accumulation fp32 — fp32-grade scores and
+// weights on bf16 keys and values, the contract the row-by-row kernel and the oracle implement.
+// A row's result is a function of its own q, its position and the cache: key blocks are visited in order 0, 1, ...,
+// masked keys contribute exact zeros, MFMA output rows do not see each other — the composition of tiles and groups never
+// changes a row's bits (tests/test_gpu_invariance.py).
+template <int HS, int G, int QT>
+__global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_args a) {
+  constexpr int NW = G * QT;
+  constexpr int DC = HS / 32;                 // 32-dim chunks of the QK product
+  constexpr int DTL = HS / 16;                // 16-dim tiles of the output
+  constexpr int KROW = HS * 2 + 16;           // bytes per key row of the K image (pad: conflict-free 16-byte reads)
+  constexpr int VROW = UA2_PAGE * 2 + 16;     // bytes per dim row of the V^T image
+  extern __shared__ __attribute__((aligned(16))) char smf[];
+  char* k_lds = smf;                          // [64 keys][KROW]
+  char* v_lds = smf + UA2_PAGE * KROW;        // [HS dims][VROW]
+  const int grp = blockIdx.x, kvh = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = wave / G, head = kvh * G + (wave % G);
+  const int ql = lane & 15, g = lane >> 4;
+  const int row = a.group_rows[(size_t)grp * (QT * 16) + qt * 16 + ql];   // this lane's query row (-1 = padding)
+  const int seq = a.group_seq[grp];
+  const int nkeys = a.group_nkeys[grp];       // 1 + the largest position any row of the group attends
+  const int qpos = row >= 0 ? a.row_pos[row] : -1;
+  const int32_t* ptab = a.kv.page_table + (size_t)seq * a.kv.max_pages;
+
+  // Q^T fragments: dims dc*32 + g*8 .. +8 of query row `row`, pre-scaled, split hi / lo
+  u32x4 qh[DC], qlo[DC];
+  {
+    const float sc = 1.44269504088896340736f / sqrtf((float)HS);
+#pragma unroll
+    for (int dc = 0; dc < DC; ++dc) {
+      float f[8];
+      if (row >= 0) {
+        const float* qp = a.q + ((size_t)row * a.kv.n_head + head) * HS + dc * 32 + g * 8;
+        const float4 t0 = *reinterpret_cast<const float4*>(qp), t1 = *reinterpret_cast<const float4*>(qp + 4);
+        f[0] = t0.x; f[1] = t0.y; f[2] = t0.z; f[3] = t0.w; f[4] = t1.x; f[5] = t1.y; f[6] = t1.z; f[7] = t1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      }
+      unsigned h[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = __fmul_rn(f[e], sc);
+        h[e] = f2bf(v);
+        l[e] = f2bf(v - bf2f((unsigned short)h[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { qh[dc][e] = h[2 * e] | (h[2 * e + 1] << 16); qlo[dc][e] = l[2 * e] | (l[2 * e + 1] << 16); }
+    }
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[DTL];
+#pragma unroll
+  for (int dt = 0; dt < DTL; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (nkeys + UA2_PAGE - 1) / UA2_PAGE;
+  constexpr int PIECES = UA2_PAGE * HS / 8;   // 16-byte pieces per page
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();                          // the previous block's readers are done
+    {
+      const size_t base = (((size_t)ptab[kb] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
+      const u32x4* kg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.k_pool) + base);
+      const u32x4* vg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.v_pool) + base);
+      for (int i = tid; i < PIECES; i += 64 * NW) {
+        const int key = i / (HS / 8), oct = i % (HS / 8);
+        const u32x4 kk = kg[i], vv = vg[i];
+        *reinterpret_cast<u32x4*>(k_lds + key * KROW + oct * 16) = kk;
+        unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds + (size_t)(oct * 8) * VROW + key * 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {         // V^T: dim row oct*8 + 2e (+1), column = key
+          vt[(size_t)(2 * e) * (VROW / 2)] = (unsigned short)(vv[e] & 0xffffu);
+          vt[(size_t)(2 * e + 1) * (VROW / 2)] = (unsigned short)(vv[e] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    // S^T tile kt: rows = keys kb*64 + kt*16 + 4g + r, column = this lane's query
+    f32x4 st[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) {
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(k_lds + (kt * 16 + ql) * KROW + dc * 64 + g * 16));
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qlo[dc]), st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qh[dc]), st[kt], 0, 0, 0);
+      }
+    }
+    // online softmax of this lane's query over the block's 64 keys: 16 local values, then the 4 lane groups
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kpos = kb * UA2_PAGE + kt * 16 + 4 * g + r;
+        if (kpos > qpos) st[kt][r] = -INFINITY;               // causal / padding mask by select: stale cache slots never leak
+        mx = fmaxf(mx, st[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+    u32x4 ph[2], pl[2];                                          // P^T fragments of the two 32-key chunks
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      unsigned h[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                              // element e <-> key kc*32 + (e < 4 ? 4g + e : 16 + 4g + e - 4)
+        const float sv = st[2 * kc + (e >> 2)][e & 3];
+        const float pv = (sv == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv - m_new);
+        ps += pv;
+        h[e] = f2bf(pv);
+        l[e] = f2bf(pv - bf2f((unsigned short)h[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ph[kc][e] = h[2 * e] | (h[2 * e + 1] << 16); pl[kc][e] = l[2 * e] | (l[2 * e + 1] << 16); }
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DTL; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    }
+    // O^T tile dt (rows = dims dt*16 + 4g + r, column = this lane's query) += V^T P^T
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+      for (int dt = 0; dt < DTL; ++dt) {
+        const char* vr = v_lds + (size_t)(dt * 16 + ql) * VROW + (kc * 32 + 4 * g) * 2;
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vr), v1 = *reinterpret_cast<const uint2*>(vr + 32);   // keys 4g..4g+3 | 16+4g..
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4{v0.x, v0.y, v1.x, v1.y});
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pl[kc]), o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, ph[kc]), o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (row < 0 || l_run == 0.f) return;
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int dt = 0; dt < DTL; ++dt) {
+    const int d0 = dt * 16 + 4 * g;
+    const float4 out = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    if (a.y) *reinterpret_cast<float4*>(a.y + ((size_t)row * a.kv.n_head + head) * HS + d0) = out;
+    if (a.y_packed) {
+      const int nch = a.kv.n_head * HS / Elem<UA2_BF16>::KC;
+      store_packed_operand<UA2_BF16>(a.y_packed, row, head * HS + d0, nch, out.x);
+      store_packed_operand<UA2_BF16>(a.y_packed, row, head * HS + d0 + 1, nch, out.y);
+      store_packed_operand<UA2_BF16>(a.y_packed, row, head * HS + d0 + 2, nch, out.z);
+      store_packed_operand<UA2_BF16>(a.y_packed, row, head * HS + d0 + 3, nch, out.w);
+    }
+  }
+}
+
+template <int HS, int G, int QT>
+void launch_flash_one(const ua2_attn_args& a, hipStream_t s) {
+  constexpr auto kern = attn_flash_kernel<HS, G, QT>;
+  ua2_allow_big_lds<kern>();
+  const size_t smem = (size_t)UA2_PAGE * (HS * 2 + 16) + (size_t)HS * (UA2_PAGE * 2 + 16);
+  hipLaunchKernelGGL(kern, dim3(a.n_groups, a.kv.n_kv), dim3(64 * G * QT), smem, s, a);
+}
+
+// group_q_tiles fixes QT (the host built its row lists for it): 2 for the LM's grouped-query heads, 4 for multi-head models
+int launch_flash(const ua2_attn_args& a, hipStream_t s) {
+  const int G = a.kv.n_head / a.kv.n_kv, hs = a.kv.head_size, qt = a.group_q_tiles;
+  if (hs == 128 && G == 3 && qt == 2) launch_flash_one<128, 3, 2>(a, s);
+  else if (hs == 128 && G == 1 && qt == 4) launch_flash_one<128, 1, 4>(a, s);
+  else if (hs == 64 && G == 1 && qt == 4) launch_flash_one<64, 1, 4>(a, s);
+  else if (hs == 64 && G == 2 && qt == 2) launch_flash_one<64, 2, 2>(a, s);
+  else if (hs == 64 && G == 4 && qt == 2) launch_flash_one<64, 4, 2>(a, s);
+  else if (hs == 128 && G == 2 && qt == 2) launch_flash_one<128, 2, 2>(a, s);
+  else if (hs == 32 && G == 2 && qt == 2) launch_flash_one<32, 2, 2>(a, s);
+  else if (hs == 32 && G == 1 && qt == 4) launch_flash_one<32, 1, 4>(a, s);
+  else {
+    ua2_set_error("ua2_attn: no grouped (flash) kernel for head_size %d, group %d, q tiles %d", hs, G, qt);
+    return -1;
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- short-context (local decoder) form: one workgroup per row, 128 / HS heads per wave pass ----
 template <int DT, int HS>
 __global__ __launch_bounds__(1024) void attn_local_kernel(const ua2_attn_args a) {
@@ -305,6 +502,10 @@ int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
   UA2_CHECK(!a.y_packed || (a.kv.n_head * a.kv.head_size) % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_attn: y_packed needs n_head*head_size %% chunk == 0");
+  if (a.group_rows && a.n_groups > 0 && a.dtype == UA2_BF16 && a.window <= 0) {   // many rows per sequence: MFMA flash form
+    UA2_CHECK(a.group_seq && a.group_nkeys && a.group_q_tiles > 0, "ua2_attn: group_seq / group_nkeys / group_q_tiles missing");
+    return launch_flash(a, s);
+  }
   if (a.dtype == UA2_BF16) return launch_fused<UA2_BF16>(a, s);
   if (a.dtype == UA2_F32) return launch_fused<UA2_F32>(a, s);
   ua2_set_error("ua2_attn: bad dtype %d", a.dtype);

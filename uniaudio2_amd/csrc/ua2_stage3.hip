@@ -38,6 +38,9 @@ struct ua2_stage3 {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
   float cfg_scale = 1.f;       // > 1: classifier-free guidance over a (conditional, unconditional) row pair
+  // row groups of the next ua2_stage3_trunk call (prefill): the trunk's attention then runs the MFMA flash kernel
+  const int32_t *group_rows = nullptr, *group_seq = nullptr, *group_nkeys = nullptr;
+  int32_t n_groups = 0, group_q_tiles = 0;
   std::map<std::tuple<int, int, int, int, int, int, int>, hipGraphExec_t> graphs;
 };
 
@@ -83,7 +86,7 @@ void fresh_args(const ua2_stage3* h, ua2_linear_args& a) {
 
 // local = the depth decoder: positions < kLocalCtx, short-context attention (fused into the O-projection when R == 1)
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
-            const int32_t* row_seq, hipStream_t s, bool local = false) {
+            const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false) {
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   for (int l = 0; l < g.n_layer; ++l) {
@@ -112,6 +115,10 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
       memset(&at, 0, sizeof(at));
       at.dtype = dt; at.R = R; at.q = h->q; at.row_pos = row_pos; at.row_seq = row_seq; at.kv = kv;
       if (pack_o) at.y_packed = h->gemm_ws; else at.y = h->yattn;
+      if (grouped && !local && h->n_groups > 0) {
+        at.group_rows = h->group_rows; at.group_seq = h->group_seq; at.group_nkeys = h->group_nkeys;
+        at.n_groups = h->n_groups; at.group_q_tiles = h->group_q_tiles;
+      }
       if (int rc = local ? ua2_attn_local_launch(at, s) : ua2_attn_launch(at, s)) return rc;
     }
     fresh_args(h, a);
@@ -227,13 +234,14 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   if (identity) d.row_seq = nullptr;
   const int C = d.backbone.n_embd, w = d.n_cb + 1;
   if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, s)) return rc;
-  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s)) return rc;
+  const bool grouped = !identity;   // prefill chunks (ua2_stage3_trunk) may carry row groups; decode frames never do
+  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
   // backbone_input = h_audio*audio_step + text_embeds*text_step   (model_new.py:607)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, s)) return rc;
-  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s)) return rc;
+  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
   // h = ln_f(x); generation_input = h*audio_step                   (model_new.py:609-610)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, s)) return rc;
-  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s)) return rc;
+  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
   // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, s)) return rc;
   return 0;
@@ -253,6 +261,15 @@ extern "C" int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temper
   return 0;
 }
 
+extern "C" int ua2_stage3_set_prefill_groups(ua2_stage3* h, const int32_t* group_rows, const int32_t* group_seq, const int32_t* group_nkeys,
+                                             int32_t n_groups, int32_t group_q_tiles) {
+  UA2_CHECK(h != nullptr, "ua2_stage3_set_prefill_groups: NULL handle");
+  UA2_CHECK(n_groups == 0 || (group_rows && group_seq && group_nkeys && group_q_tiles > 0), "ua2_stage3_set_prefill_groups: missing tables");
+  h->group_rows = group_rows; h->group_seq = group_seq; h->group_nkeys = group_nkeys;
+  h->n_groups = n_groups; h->group_q_tiles = group_q_tiles;
+  return 0;
+}
+
 extern "C" int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale) {
   UA2_CHECK(h != nullptr && cfg_scale >= 1.f, "ua2_stage3_set_cfg: NULL handle or cfg_scale < 1");
   h->cfg_scale = cfg_scale;
@@ -261,7 +278,9 @@ extern "C" int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale) {
 
 extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
   UA2_CHECK(h != nullptr, "ua2_stage3_trunk: NULL handle");
-  return trunk_impl(h, R, false, (hipStream_t)stream);
+  const int rc = trunk_impl(h, R, false, (hipStream_t)stream);
+  h->n_groups = 0;                 // row groups describe ONE chunk: they never outlive the call they were set for
+  return rc;
 }
 
 // text_only: the text head and its sample only.  The on-device text loop (feedback mode 1, asr_task.py:668-682) feeds

@@ -167,6 +167,18 @@ class Model_stage3(nn.Module):
             raise ValueError(f"position {max_pos} is outside the KV cache / RoPE tables planned for max_seq_length="
                              f"{limit} (setup_caches); shorten the prompt, generate fewer frames or plan a longer cache")
 
+    def _set_groups(self, pos, seq):
+        """Row groups of the next prefill chunk for the MFMA flash attention (bf16 plans; the exact-fp32 plan keeps the
+        row-by-row kernel).  pos, seq: the chunk's row positions / sequences (any device)."""
+        st = self._st
+        if st["dtype"] != torch.bfloat16:
+            return
+        cfg = self.backbone.config
+        g = ops.attn_groups(pos.cpu().numpy(), seq.cpu().numpy(), cfg.n_head, cfg.n_query_groups, st["device"])
+        st["groups"] = g                   # keeps the device tables alive while the executor points at them
+        check(lib.ua2_stage3_set_prefill_groups(self._h, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[0].shape[0], g[3]),
+              "ua2_stage3_set_prefill_groups")
+
     def _load_rows(self, tokens, tokens_mask, pos, seq):
         """tokens (R, 9) any int dtype, mask (R, 9) bool, pos (R,), seq (R,) -> device state."""
         st = self._st
@@ -203,6 +215,7 @@ class Model_stage3(nn.Module):
         R, mr = B * S, st["max_rows"]
         for s0 in range(0, R, mr):
             n = self._load_rows(tk[s0:s0 + mr], mk[s0:s0 + mr], ps[s0:s0 + mr], sq[s0:s0 + mr])
+            self._set_groups(ps[s0:s0 + mr], sq[s0:s0 + mr])
             check(lib.ua2_stage3_trunk(self._h, n, ops.stream()), "ua2_stage3_trunk")
         return None
 
@@ -307,6 +320,7 @@ class Model_stage3(nn.Module):
         R, mr = tk.shape[0], st["max_rows"]
         for s0 in range(0, R, mr):
             n = self._load_rows(tk[s0:s0 + mr], mk[s0:s0 + mr], ps[s0:s0 + mr], sq[s0:s0 + mr])
+            self._set_groups(ps[s0:s0 + mr], sq[s0:s0 + mr])
             check(lib.ua2_stage3_trunk(self._h, n, ops.stream()), "ua2_stage3_trunk")
         return None
 

@@ -98,8 +98,37 @@ def linear_chain_timed(args_list, iters):
     return ms.value / (len(args_list) * iters)
 
 
-def attn(*, dtype, R, q, row_pos, row_seq, kv, y, window=0):
+def attn_groups(pos, seq, n_head, n_kv, device):
+    """Row groups for the MFMA flash form of ua2_attn: pos, seq = host int sequences (position and page-table row of every
+    query row of the launch).  Rows of one sequence, ordered by position, are cut into groups of q_tiles * 16
+    (q_tiles = 2 with grouped-query heads, 4 otherwise).  -> (rows [n, q_tiles*16] int32, seq [n], nkeys [n], q_tiles), device."""
+    import numpy as np
+    pos, seq = np.asarray(pos, dtype=np.int64), np.asarray(seq, dtype=np.int64)
+    qt = 2 if n_head > n_kv else 4
+    per = qt * 16
+    order = np.lexsort((pos, seq))
+    rows, gseq, nkeys = [], [], []
+    start = 0
+    while start < len(order):
+        s0 = seq[order[start]]
+        end = start
+        while end < len(order) and seq[order[end]] == s0:
+            end += 1
+        for c in range(start, end, per):
+            idx = order[c:min(c + per, end)]
+            rows.append(np.concatenate([idx, np.full(per - len(idx), -1)]))
+            gseq.append(s0)
+            nkeys.append(int(pos[idx].max()) + 1)
+        start = end
+    to = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(device)
+    return to(np.stack(rows)).contiguous(), to(gseq), to(nkeys), qt
+
+
+def attn(*, dtype, R, q, row_pos, row_seq, kv, y, window=0, groups=None):
     a = AttnArgs()
+    if groups is not None:
+        a.group_rows, a.group_seq, a.group_nkeys = ptr(groups[0]), ptr(groups[1]), ptr(groups[2])
+        a.n_groups, a.group_q_tiles = groups[0].shape[0], groups[3]
     a.y = ptr(y)
     a.window = window
     a.dtype, a.R = dtype_code(dtype), R

@@ -63,11 +63,14 @@ class DenseKV:
         self.row_seq = torch.arange(B, **i32).repeat_interleave(T)            # ... of sequence b
         self.all_pos = torch.full((B * T,), T - 1, **i32)                     # non-causal: every row sees positions 0..T-1
         self.dtype, self.B, self.T = dtype, B, T
+        # bf16: the MFMA flash form of ua2_attn (K/V pages staged once per 64 query rows instead of once per row)
+        self.groups = ops.attn_groups(self.all_pos.cpu().numpy(), self.row_seq.cpu().numpy(), n_head, n_head, device) \
+            if dtype == torch.bfloat16 else None
 
     def attend(self, q):
         """q [B*T, n_head*hs] fp32 -> softmax(q K^T / sqrt(hs)) V, every row over all T positions of its sequence."""
         y = torch.empty_like(q)
-        ops.attn(dtype=self.dtype, R=q.shape[0], q=q, row_pos=self.all_pos, row_seq=self.row_seq, kv=self.geom, y=y)
+        ops.attn(dtype=self.dtype, R=q.shape[0], q=q, row_pos=self.all_pos, row_seq=self.row_seq, kv=self.geom, y=y, groups=self.groups)
         return y
 
 
