@@ -194,21 +194,36 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
 
   for (int cg = 0; cg < ngroups; ++cg) {
     __syncthreads();
+    // All global loads of a batch go out before the first conversion: issued one by one behind their LDS writes they
+    // cost a full memory round trip each (~20 per workgroup: the first version of this kernel was bound by exactly that).
+    constexpr int SB = 8;
     for (int p = p_first, wi = w_first; p < kCG3 / 2; ) {
-      const int ci = cg * kCG3 + 2 * p, ti = in_start + wi;
-      float v0 = 0.f, v1 = 0.f;
-      if (ti >= 0 && ti < tin_eff) {
-        const int tsrc = (a.in_repeat == 1) ? ti : (a.in_repeat == 2 ? (ti >> 1) : ti / a.in_repeat);
-        const size_t off = ((size_t)b * a.Cin + ci) * a.Tin + tsrc;
-        if (ci < a.Cin) v0 = apply_act(a.x[off], a.pre_act, pre_alpha);
-        if (ci + 1 < a.Cin) v1 = apply_act(a.x[off + a.Tin], a.pre_act, pre_alpha);
+      float v0[SB], v1[SB];
+      int pp[SB], ww[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        pp[u] = p; ww[u] = wi;
+        v0[u] = 0.f; v1[u] = 0.f;
+        const int ci = cg * kCG3 + 2 * p, ti = in_start + wi;
+        if (p < kCG3 / 2 && ti >= 0 && ti < tin_eff) {
+          const int tsrc = (a.in_repeat == 1) ? ti : (a.in_repeat == 2 ? (ti >> 1) : ti / a.in_repeat);
+          const size_t off = ((size_t)b * a.Cin + ci) * a.Tin + tsrc;
+          if (ci < a.Cin) v0[u] = a.x[off];
+          if (ci + 1 < a.Cin) v1[u] = a.x[off + a.Tin];
+        }
+        p += p_step; wi += w_step;
+        if (wi >= W) { wi -= W; ++p; }
       }
-      const unsigned h0 = f2bf(v0), h1 = f2bf(v1);
-      const unsigned l0 = f2bf(v0 - bf2f((unsigned short)h0)), l1 = f2bf(v1 - bf2f((unsigned short)h1));
-      *reinterpret_cast<unsigned*>(xh + (size_t)wi * kRowB + p * 4) = h0 | (h1 << 16);
-      *reinterpret_cast<unsigned*>(xl + (size_t)wi * kRowB + p * 4) = l0 | (l1 << 16);
-      p += p_step; wi += w_step;
-      if (wi >= W) { wi -= W; ++p; }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        if (pp[u] < kCG3 / 2) {
+          const float x0 = apply_act(v0[u], a.pre_act, pre_alpha), x1 = apply_act(v1[u], a.pre_act, pre_alpha);   // act(0) = 0 for every pre-activation
+          const unsigned h0 = f2bf(x0), h1 = f2bf(x1);
+          const unsigned l0 = f2bf(x0 - bf2f((unsigned short)h0)), l1 = f2bf(x1 - bf2f((unsigned short)h1));
+          *reinterpret_cast<unsigned*>(xh + (size_t)ww[u] * kRowB + pp[u] * 4) = h0 | (h1 << 16);
+          *reinterpret_cast<unsigned*>(xl + (size_t)ww[u] * kRowB + pp[u] * 4) = l0 | (l1 << 16);
+        }
+      }
     }
     __syncthreads();
     if (wave_active) {
