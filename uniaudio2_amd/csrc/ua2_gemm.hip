@@ -232,6 +232,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   }
   while (seg <= nw) { retire(); ++seg; }         // the last range (and any empty ones after it)
 
+  // ---- QKV epilogue, staged (half-split RoPE, head_size 128: the workgroup's 128 columns are exactly one head) ----
+  // The generic epilogue below issues, per output element, two scalar loads of the RoPE table and one 4-byte (q) or
+  // 2-byte (K/V) store into 32- / 16-byte runs: at 6240 prefill rows that was 2/3 of the launch (838 us against 280 us of
+  // MFMA work, profiles/r2_notes.md).  Here every wave parks its un-rotated 64 x 64 patch in the (now idle) operand ring,
+  // in natural dim order, and walks it row by row: a lane owns 4 consecutive dims of one row, reads its rotation partner
+  // from LDS, the cos / sin of its 4 dims with one 16-byte load each, and stores 16 bytes (q, fp32) or 8 bytes (K/V,
+  // bf16) — 128- / 64-byte runs.  Same operations in the same order as linear_epilogue: identical bits.
+  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    if (a.rope_mode == UA2_ROPE_HALF_SPLIT && a.kv.head_size == 128 && !a.bias) {
+      __syncthreads();                                   // every wave is done with the operand ring
+      float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * 64 * 64;
+      const int colq = lane & 15, gq = lane >> 4;
+#pragma unroll
+      for (int mi = 0; mi < kWM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int prow = mi * 16 + 4 * gq + r;
+            const int pcol = (colq < 8) ? ni * 8 + colq : 32 + ni * 8 + (colq - 8);   // [0,32): dims 32 wn + ..; [32,64): 64 + 32 wn + ..
+            patch[prow * 64 + pcol] = tot[0][mi][ni][r];
+          }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int h = pn;                                  // head index of this workgroup's column block
+      const int hs = 128, half = 64;
+      const bool is_q = h < a.kv.n_head, is_k = !is_q && h < a.kv.n_head + a.kv.n_kv;
+      const bool rot = is_q || is_k;
+      const int kvh = is_q ? 0 : (is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv);
+      const int j = lane & 15, jj = j & 7;
+      const bool hi = j >= 8;
+      const int d0 = 32 * wn + 4 * jj;                   // table column / low-half dim of this lane's 4 dims
+      for (int it = 0; it < 16; ++it) {
+        const int prow = it * 4 + gq;
+        const int m = (pm * kBMT + wm * kWM) * 16 + prow;
+        if (m >= a.M) continue;
+        const float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
+        const float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
+        const int pos = a.row_pos[m];
+        float4 out = own;
+        if (rot) {
+          const float4 cs = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)pos * half + d0);
+          const float4 sn = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)pos * half + d0);
+          // lo half: x1 cos + (-x2) sin ; hi half: x2 cos + x1 sin  (lit_model.py:795-806), products rounded separately
+          if (!hi) {
+            out.x = __fadd_rn(__fmul_rn(own.x, cs.x), __fmul_rn(-oth.x, sn.x)); out.y = __fadd_rn(__fmul_rn(own.y, cs.y), __fmul_rn(-oth.y, sn.y));
+            out.z = __fadd_rn(__fmul_rn(own.z, cs.z), __fmul_rn(-oth.z, sn.z)); out.w = __fadd_rn(__fmul_rn(own.w, cs.w), __fmul_rn(-oth.w, sn.w));
+          } else {
+            out.x = __fadd_rn(__fmul_rn(own.x, cs.x), __fmul_rn(oth.x, sn.x)); out.y = __fadd_rn(__fmul_rn(own.y, cs.y), __fmul_rn(oth.y, sn.y));
+            out.z = __fadd_rn(__fmul_rn(own.z, cs.z), __fmul_rn(oth.z, sn.z)); out.w = __fadd_rn(__fmul_rn(own.w, cs.w), __fmul_rn(oth.w, sn.w));
+          }
+        }
+        const int dd = (hi ? half : 0) + d0;
+        if (is_q) {
+          *reinterpret_cast<float4*>(a.q_out + (size_t)m * a.kv.n_head * hs + (size_t)h * hs + dd) = out;
+        } else {
+          const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages + pos / UA2_PAGE];
+          const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs + dd;
+          void* pool = is_k ? a.kv.k_pool : a.kv.v_pool;
+          if constexpr (DT == UA2_BF16) {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(out.x) | ((unsigned)f2bf(out.y) << 16);
+            pk.y = (unsigned)f2bf(out.z) | ((unsigned)f2bf(out.w) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(pool) + base) = pk;
+          } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(pool) + base) = out;
+          }
+        }
+      }
+      return;
+    }
+  }
+
   // ---- epilogue: lane holds D[row = 4*(lane >> 4) + r][col = lane & 15] of each 16 x 16 tile ----
   // The epilogue's loads (residual; position -> RoPE table entry / page id) are gathered for the four rows of a
   // tile before any of its stores, so the four dependent chains overlap instead of running one after the other
