@@ -143,7 +143,7 @@ constexpr int kCG3 = 32;       // channels per staging group
 constexpr int kRowB = 80;      // LDS bytes per window position per plane
 
 template <int NTT, int RPW>
-__global__ __launch_bounds__(256, 3) void conv1d_x3_kernel(const ua2_conv1d_args a, const int rt, const int nbuf) {
+__global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a, const int rt) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
   const int K = a.K, s = a.stride, d = a.dilation;
   const int tsub = 4 / rt;
@@ -181,47 +181,9 @@ __global__ __launch_bounds__(256, 3) void conv1d_x3_kernel(const ua2_conv1d_args
   for (int q = 0; q < RPW; ++q)
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) acc[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // Staging walk of this thread over (channel pair p, window position wi): 256 elements per step, no division.
-  // ALL global loads of a channel group go out before the first conversion (issued one by one behind their LDS writes they
-  // cost a memory round trip each — the first version of this kernel was bound by exactly that), and with several channel
-  // groups the loads of group cg + 1 are in flight while group cg is multiplied (two LDS images, one barrier per group).
-  constexpr int SB = 12;                                 // elements per thread per group held in registers (W <= 192)
+  // staging walk of this thread: (channel pair p, window position wi), advanced by 256 elements per step without a division
   const int p_step = 256 / W, w_step = 256 - p_step * W;
   const int p_first = tid / W, w_first = tid - p_first * W;
-  const int nelem = (kCG3 / 2 * W + 255) / 256;          // walk length per thread
-  auto issue = [&](int cg, int skip, float (&v0)[SB], float (&v1)[SB]) {
-    int p = p_first, wi = w_first;
-    for (int u = 0; u < skip; ++u) { p += p_step; wi += w_step; if (wi >= W) { wi -= W; ++p; } }
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      v0[u] = 0.f; v1[u] = 0.f;
-      const int ci = cg * kCG3 + 2 * p, ti = in_start + wi;
-      if (p < kCG3 / 2 && ti >= 0 && ti < tin_eff) {
-        const int tsrc = (a.in_repeat == 1) ? ti : (a.in_repeat == 2 ? (ti >> 1) : ti / a.in_repeat);
-        const size_t off = ((size_t)b * a.Cin + ci) * a.Tin + tsrc;
-        if (ci < a.Cin) v0[u] = a.x[off];
-        if (ci + 1 < a.Cin) v1[u] = a.x[off + a.Tin];
-      }
-      p += p_step; wi += w_step;
-      if (wi >= W) { wi -= W; ++p; }
-    }
-  };
-  auto commit = [&](char* ph, char* pl, int skip, const float (&v0)[SB], const float (&v1)[SB]) {
-    int p = p_first, wi = w_first;
-    for (int u = 0; u < skip; ++u) { p += p_step; wi += w_step; if (wi >= W) { wi -= W; ++p; } }
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      if (p < kCG3 / 2) {
-        const float x0 = apply_act(v0[u], a.pre_act, pre_alpha), x1 = apply_act(v1[u], a.pre_act, pre_alpha);   // act(0) = 0 for every pre-activation
-        const unsigned h0 = f2bf(x0), h1 = f2bf(x1);
-        const unsigned l0 = f2bf(x0 - bf2f((unsigned short)h0)), l1 = f2bf(x1 - bf2f((unsigned short)h1));
-        *reinterpret_cast<unsigned*>(ph + (size_t)wi * kRowB + p * 4) = h0 | (h1 << 16);
-        *reinterpret_cast<unsigned*>(pl + (size_t)wi * kRowB + p * 4) = l0 | (l1 << 16);
-      }
-      p += p_step; wi += w_step;
-      if (wi >= W) { wi -= W; ++p; }
-    }
-  };
   u32x4 wh[RPW], wl[RPW];
 #pragma unroll
   for (int q = 0; q < RPW; ++q) { wh[q] = u32x4{0u, 0u, 0u, 0u}; wl[q] = wh[q]; }
@@ -229,56 +191,64 @@ __global__ __launch_bounds__(256, 3) void conv1d_x3_kernel(const ua2_conv1d_args
 #pragma unroll
     for (int q = 0; q < RPW; ++q) { wh[q] = wph[q][0]; wl[q] = wpl[q][0]; }
   }
-  auto compute = [&](const char* ph, const char* pl, int cg) {
-    for (int j = 0; j < K; ++j) {
-      const int chunk = cg * K + j;
-      bf16x8 ah[RPW], al[RPW];
+
+  for (int cg = 0; cg < ngroups; ++cg) {
+    __syncthreads();
+    // All global loads of a batch go out before the first conversion: issued one by one behind their LDS writes they
+    // cost a full memory round trip each (~20 per workgroup: the first version of this kernel was bound by exactly that).
+    constexpr int SB = 8;
+    for (int p = p_first, wi = w_first; p < kCG3 / 2; ) {
+      float v0[SB], v1[SB];
+      int pp[SB], ww[SB];
 #pragma unroll
-      for (int q = 0; q < RPW; ++q) { ah[q] = __builtin_bit_cast(bf16x8, wh[q]); al[q] = __builtin_bit_cast(bf16x8, wl[q]); }
-      if (chunk + 1 < nchunks) {                                    // weights: one chunk ahead
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) { wh[q] = wph[q][(size_t)(chunk + 1) * 64]; wl[q] = wpl[q][(size_t)(chunk + 1) * 64]; }
+      for (int u = 0; u < SB; ++u) {
+        pp[u] = p; ww[u] = wi;
+        v0[u] = 0.f; v1[u] = 0.f;
+        const int ci = cg * kCG3 + 2 * p, ti = in_start + wi;
+        if (p < kCG3 / 2 && ti >= 0 && ti < tin_eff) {
+          const int tsrc = (a.in_repeat == 1) ? ti : (a.in_repeat == 2 ? (ti >> 1) : ti / a.in_repeat);
+          const size_t off = ((size_t)b * a.Cin + ci) * a.Tin + tsrc;
+          if (ci < a.Cin) v0[u] = a.x[off];
+          if (ci + 1 < a.Cin) v1[u] = a.x[off + a.Tin];
+        }
+        p += p_step; wi += w_step;
+        if (wi >= W) { wi -= W; ++p; }
       }
 #pragma unroll
-      for (int nt = 0; nt < NTT; ++nt) {
-        const size_t o = (size_t)((tw0 + nt * 16 + tl) * s + j * d) * kRowB + g * 16;
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ph + o));
-        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pl + o));
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh, acc[q][nt], 0, 0, 0);   // small terms first
-          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl, acc[q][nt], 0, 0, 0);
-          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh, acc[q][nt], 0, 0, 0);
+      for (int u = 0; u < SB; ++u) {
+        if (pp[u] < kCG3 / 2) {
+          const float x0 = apply_act(v0[u], a.pre_act, pre_alpha), x1 = apply_act(v1[u], a.pre_act, pre_alpha);   // act(0) = 0 for every pre-activation
+          const unsigned h0 = f2bf(x0), h1 = f2bf(x1);
+          const unsigned l0 = f2bf(x0 - bf2f((unsigned short)h0)), l1 = f2bf(x1 - bf2f((unsigned short)h1));
+          *reinterpret_cast<unsigned*>(xh + (size_t)ww[u] * kRowB + pp[u] * 4) = h0 | (h1 << 16);
+          *reinterpret_cast<unsigned*>(xl + (size_t)ww[u] * kRowB + pp[u] * 4) = l0 | (l1 << 16);
         }
       }
     }
-  };
-
-  const size_t plane = (size_t)W * kRowB;
-  if (nbuf == 2 && nelem <= SB) {                        // pipelined: image (cg & 1) is multiplied while group cg + 1 loads
-    float v0[SB], v1[SB];
-    issue(0, 0, v0, v1);
-    commit(smc, smc + plane, 0, v0, v1);
     __syncthreads();
-    for (int cg = 0; cg < ngroups; ++cg) {
-      char* cur = smc + (size_t)(cg & 1) * 2 * plane;
-      char* nxt = smc + (size_t)((cg + 1) & 1) * 2 * plane;
-      const bool more = cg + 1 < ngroups;
-      if (more) issue(cg + 1, 0, v0, v1);
-      if (wave_active) compute(cur, cur + plane, cg);
-      if (more) commit(nxt, nxt + plane, 0, v0, v1);
-      __syncthreads();
-    }
-  } else {                                               // one image (a single channel group, or a window too long for the registers)
-    for (int cg = 0; cg < ngroups; ++cg) {
-      if (cg) __syncthreads();
-      for (int skip = 0; skip < nelem; skip += SB) {
-        float v0[SB], v1[SB];
-        issue(cg, skip, v0, v1);
-        commit(xh, xl, skip, v0, v1);
+    if (wave_active) {
+      for (int j = 0; j < K; ++j) {
+        const int chunk = cg * K + j;
+        bf16x8 ah[RPW], al[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) { ah[q] = __builtin_bit_cast(bf16x8, wh[q]); al[q] = __builtin_bit_cast(bf16x8, wl[q]); }
+        if (chunk + 1 < nchunks) {                                    // one chunk ahead
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) { wh[q] = wph[q][(size_t)(chunk + 1) * 64]; wl[q] = wpl[q][(size_t)(chunk + 1) * 64]; }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+          const size_t o = (size_t)((tw0 + nt * 16 + tl) * s + j * d) * kRowB + g * 16;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xh + o));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xl + o));
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) {
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh, acc[q][nt], 0, 0, 0);   // small terms first
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl, acc[q][nt], 0, 0, 0);
+            acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh, acc[q][nt], 0, 0, 0);
+          }
+        }
       }
-      __syncthreads();
-      if (wave_active) compute(xh, xl, cg);
     }
   }
   if (!wave_active) return;
@@ -307,10 +277,10 @@ __global__ __launch_bounds__(256, 3) void conv1d_x3_kernel(const ua2_conv1d_args
 }
 
 template <int NTT, int RPW>
-void launch_x3(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, int nbuf, hipStream_t s) {
+void launch_x3(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, hipStream_t s) {
   constexpr auto kern = conv1d_x3_kernel<NTT, RPW>;
   ua2_allow_big_lds<kern>();
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a, rt, nbuf);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a, rt);
 }
 
 __global__ void avgpool1d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int Tin, int Tout, int k) {
@@ -386,24 +356,20 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
     const int row_blocks3 = ua2_ceil_div(rows, wave_rows * rt);
     int ntt = 4;
     while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / rt)) * row_blocks3 * a->B < 512) ntt >>= 1;
-    // the staging registers hold 12 elements per thread (window <= 192 positions): prefer a time tile that fits in one pass
-    while (ntt > 1 && (16 * ntt * (4 / rt) - 1) * a->stride + (a->K - 1) * a->dilation + 1 > 192) ntt >>= 1;
     const int wgt = 16 * ntt * (4 / rt);
     const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
-    const int ngroups3 = ua2_ceil_div(a->Cin, kCG3);
-    const int nbuf = (ngroups3 > 1 && (size_t)4 * W3 * kRowB <= 64 * 1024 && (kCG3 / 2 * W3 + 255) / 256 <= 12) ? 2 : 1;   // two images: next group loads while this one multiplies
-    const size_t smem3 = (size_t)2 * nbuf * W3 * kRowB;
+    const size_t smem3 = (size_t)2 * W3 * kRowB;
     UA2_CHECK(smem3 <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem3);
     const dim3 grid3(ua2_ceil_div(tq, wgt), row_blocks3, a->B);
     hipStream_t st = (hipStream_t)stream;
     if (rpw == 2) {
-      if (ntt == 4) launch_x3<4, 2>(*a, grid3, smem3, rt, nbuf, st);
-      else if (ntt == 2) launch_x3<2, 2>(*a, grid3, smem3, rt, nbuf, st);
-      else launch_x3<1, 2>(*a, grid3, smem3, rt, nbuf, st);
+      if (ntt == 4) launch_x3<4, 2>(*a, grid3, smem3, rt, st);
+      else if (ntt == 2) launch_x3<2, 2>(*a, grid3, smem3, rt, st);
+      else launch_x3<1, 2>(*a, grid3, smem3, rt, st);
     } else {
-      if (ntt == 4) launch_x3<4, 1>(*a, grid3, smem3, rt, nbuf, st);
-      else if (ntt == 2) launch_x3<2, 1>(*a, grid3, smem3, rt, nbuf, st);
-      else launch_x3<1, 1>(*a, grid3, smem3, rt, nbuf, st);
+      if (ntt == 4) launch_x3<4, 1>(*a, grid3, smem3, rt, st);
+      else if (ntt == 2) launch_x3<2, 1>(*a, grid3, smem3, rt, st);
+      else launch_x3<1, 1>(*a, grid3, smem3, rt, st);
     }
     UA2_LAUNCH_CHECK();
     return 0;

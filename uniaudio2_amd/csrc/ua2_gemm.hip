@@ -304,6 +304,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
       }
       return;
     }
+    // Other RoPE flavours / head sizes (Moshi family): the generic per-element epilogue, but fed from LDS.  Fed from the
+    // accumulator registers, its control flow (shuffles, early exits per row) made the compiler keep `tot` in scratch memory
+    // for the WHOLE kernel — 605 scratch instructions, every retire() a round trip: the round-1 QKV launch ran at a third of
+    // the SwiGLU launch's rate for that reason alone (profiles/r2_notes.md).
+    __syncthreads();
+    float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * 64 * 64;
+#pragma unroll
+    for (int mi = 0; mi < kWM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[((mi * WN + ni) * 4 + r) * 64 + lane] = tot[0][mi][ni][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int colg = lane & 15, gg = lane >> 4;
+#pragma unroll 1
+    for (int mi = 0; mi < kWM; ++mi) {
+      const int m0 = (pm * kBMT + wm * kWM + mi) * 16;
+      if (m0 >= a.M) continue;                    // wave-uniform
+      const int rows = min(16, a.M - m0);
+#pragma unroll 1
+      for (int ni = 0; ni < WN; ++ni) {
+        const int nt = pn * BNT + wn * WN + ni;
+        if (nt >= ntiles) continue;               // wave-uniform
+        int tile[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile[t] = nt;
+        EpiPre pre[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epilogue_prefetch<DT, EPI>(a, nt, 4 * gg + r, colg, pre[r], m0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v[NT];
+          v[0] = patch[((mi * WN + ni) * 4 + r) * 64 + lane];
+          linear_epilogue<DT, EPI, NT>(a, v, tile, 4 * gg + r, colg, pre[r], m0, rows);
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue: lane holds D[row = 4*(lane >> 4) + r][col = lane & 15] of each 16 x 16 tile ----

@@ -15,9 +15,10 @@ Differences, all explicit:
   * --topk > 1 samples on the device with a counter-based generator seeded by --seed: reproducible, same
     distribution as the reference's sample_topk, but not torch's random stream.  --decode_type
     ngram/beamsearch raise NotImplementedError (the reference's beam search is dead code).
-  * Encoding raw audio (--audio / --audio_dir) and stage 2 (tokens -> wav) need the codec's frozen SSL
-    encoders / flow-matching DiT, which are out of scope: they raise with that message.
-    Pre-tokenised `--reason_pt/--semantic_pt/--token_dir` inputs work.
+  * Encoding raw audio (--audio / --audio_dir) needs the codec's frozen SSL encoders (Whisper, WavLM, BEST-RQ), which are
+    out of scope: it raises with that message; pre-tokenised `--reason_pt/--semantic_pt/--token_dir`
+    inputs work.  Stage 2 (tokens -> wav: RVQ look-ups, flow-matching DiT, SQ-Codec) runs on the device; wav files are
+    written with scipy (16-bit PCM) because torchaudio is not a dependency.
 """
 import argparse
 import glob
@@ -304,10 +305,48 @@ def _run_speech_s2s(args, generator, task_prompt):
     return args.output_dir
 
 
+def _load_codec(args, device):
+    """multi_task_inference.py:84-97."""
+    from .tools.tokenizer.ReasoningCodec_film.reason_tokenizer import ReasoningTokenizer
+    if not args.codec_config:
+        raise ValueError("Stage 2 requires --codec_config (the codec's infer yaml) and --codec_ckpt.")
+    return ReasoningTokenizer(train_config=args.codec_config, model_path=args.codec_ckpt, music_ssl_folder=args.music_ssl_folder, device=device)
+
+
+def save_wav(path, wave, sample_rate):
+    """torchaudio.save(path, wave (1, N) float32, sr) of the reference (:546) without torchaudio: 16-bit PCM, the
+    default encoding torchaudio picks for float input to a .wav."""
+    import numpy as np
+    from scipy.io import wavfile
+    x = wave.detach().cpu().float().clamp(-1.0, 1.0).numpy()
+    wavfile.write(path, int(sample_rate), np.round(x.T * 32767.0).astype(np.int16))
+
+
 def run_generation_stage2(args):
-    raise NotImplementedError("stage 2 (tokens -> wav) needs the codec's flow-matching DiT, out of scope this round "
-                              "(SURVEY.md §8f #1); the in-scope part (RVQ lookup, ScalarModel.decode, windowing, cross-fade) "
-                              "is uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer.ReasoningTokenizer")
+    """multi_task_inference.py:529-549: every `*_semantic.pt` of --token_dir (default: --output_dir) -> `{wav_dir}/{name}.wav`
+    through ReasoningTokenizer.detokenize_no_reason (RVQ look-ups -> flow-matching DiT + guided Euler ODE -> SQ-Codec decode ->
+    cross-faded 20-s windows)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("uniaudio2_amd needs a ROCm GPU (no CPU fallback)")
+    rank = int(os.environ.get("LOCAL_RANK", getattr(args, "rank", 0)))
+    device = torch.device(f"cuda:{rank % torch.cuda.device_count()}")
+    torch.cuda.set_device(device)
+    codec = _load_codec(args, device)
+    token_dir = args.token_dir or args.output_dir
+    names = [os.path.basename(p).replace("_reason.pt", "") for p in sorted(glob.glob(os.path.join(token_dir, "*_reason.pt")))]
+    wav_dir = args.wav_dir or os.path.join(token_dir, "wavs")
+    os.makedirs(wav_dir, exist_ok=True)
+    for name in names:
+        sp = os.path.join(token_dir, f"{name}_semantic.pt")
+        if not os.path.isfile(sp):
+            print(f"[Skip] {name}: missing {sp}")
+            continue
+        rec_codec = torch.load(sp, map_location=device)
+        wave = codec.detokenize_no_reason(rec_codec.long(), return_reasoning_text=False, steps=args.codec_steps)
+        wav_path = os.path.join(wav_dir, f"{name}.wav")
+        save_wav(wav_path, wave, codec.sample_rate)
+        print(f"[Stage2] {name} -> {wav_path}")
+    return wav_dir
 
 
 def get_parser():
@@ -368,7 +407,8 @@ def main(argv=None):
             if args.stage == "1":
                 print("[Done] Stage 1 only. Run with --stage 2 --token_dir ... to decode to wav.")
                 return
-        run_generation_stage2(args)
+        if int(os.environ.get("RANK", "0")) == 0:          # stage 2 decodes what rank 0 wrote
+            run_generation_stage2(args)
         return
     raise ValueError(f"Unsupported task: {task}. Understanding: {UNDERSTANDING_TASKS}. Generation: {GENERATION_TASKS}.")
 

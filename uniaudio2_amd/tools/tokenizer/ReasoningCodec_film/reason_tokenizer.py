@@ -159,9 +159,39 @@ class ReasoningTokenizer:
         self.vq = (vq_phone, vq_semantic, vq_acoustic)
         if model is not None:
             self.vq = (model.vq_pronunciation_semantic, model.vq_structure_semantic, model.vq_acoustic)
-        if train_config is not None or model_path is not None:
-            raise NotImplementedError("loading the released codec checkpoint needs its yaml / SSL model folders, which are not in the "
-                                      "repository (SURVEY.md §0.5); build AudioDiffusion1D + ScalarModel, load_state_dict, and pass them in")
+        if train_config is not None:
+            self._load_released(train_config, model_path)
+
+    def _load_released(self, train_config, model_path):
+        """The reference's constructor (:22-66): yaml -> SQ-Codec (sq_config yaml `generator.config`, sq_resume['codec_model'],
+        scalar24k.py:423-437) + AudioDiffusion1D (transformer_diffusion_config json; model_path['model'], 'module.' prefixes
+        stripped, strict=False).  The frozen SSL encoders / Whisper front end named in the yaml are not loaded (out of scope):
+        decoding works, `tokenize(path)` needs `model.ssl_features`.  Widths of the encode side are read off the checkpoint."""
+        import yaml
+        from .models.AudioDiffusion1D import AudioDiffusion1D
+        from .models.scalar24k import ScalarModel
+        with open(train_config, "r", encoding="utf-8") as f:
+            ta = yaml.safe_load(f)
+        with open(ta["sq_config"], "r", encoding="utf-8") as f:
+            sq_cfg = yaml.safe_load(f)["generator"]["config"]
+        sq = ScalarModel(**sq_cfg)
+        sq.load_state_dict(torch.load(ta["sq_resume"], map_location="cpu")["codec_model"])
+        self.SQCodec = sq.to(self.device).prepare()
+        sd = {}
+        if model_path is not None:
+            sd = torch.load(model_path, map_location="cpu")["model"]
+            sd = {(k.split("module.")[-1] if k.startswith("module.") else k): v for k, v in sd.items()}
+        dims = dict(whisper_fea_dim=sd["d_conv_whisper.weight"].shape[0], wavlm_fea_dim=sd["d_conv_wavlm.weight"].shape[0],
+                    codec_dim=sd["cond_feature_emb.weight"].shape[0],
+                    encoder_depth=1 + max(int(k.split(".")[2]) for k in sd if k.startswith("audio_thinking.encoder_transformers."))) if sd else {}
+        model = AudioDiffusion1D(num_channels=ta.get("num_channels"), unet_model_config_path=ta["transformer_diffusion_config"], **dims)
+        mine = model.state_dict()
+        model.load_state_dict({k: v for k, v in sd.items() if k in mine}, strict=False)       # SSL / LLM keys of the checkpoint are not ours
+        self.model = model.to(self.device)
+        self.model.sq_codec_latent = sq_cfg["latent_hidden_dim"]
+        self.model.prepare()
+        self.model.init_device_dtype(self.device, torch.float32)
+        self.vq = (model.vq_pronunciation_semantic, model.vq_structure_semantic, model.vq_acoustic)
 
     @property
     def is_discrete(self):
