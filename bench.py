@@ -171,6 +171,53 @@ def codec_leg(dev):
             "rvq_encode_us_125x6x8192x32": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "config": "placeholder init_channel=32, hop 960"}
 
 
+def stage2_leg(dev, steps=10):
+    """Codec RTF of the whole stage 2 (`--stage all`'s second half): one 20-s window of semantic codes
+    (8, 250) -> RVQ look-ups -> cond_feature_emb -> x2 -> flow-matching DiT at the released shape (32 layers x 1536, 24 heads,
+    in 1040 / out 136; classifier-free guidance = batch 2) x `steps` Euler steps (test.sh runs 10) -> SQ-Codec decode ->
+    480 000 samples on the host.  Random-init weights, placeholder SQ-Codec widths (the yaml is not in the repo).
+    DiT flops per guided step: 2 x 500 rows x 32 layers x 2 x 12 x 1536^2 (attention's own flops excluded)."""
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.AudioDiffusion1D import AudioDiffusion1D
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.transformer_1d_flow import RELEASED_CONFIG
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer import ReasoningTokenizer
+    torch.manual_seed(2)
+    model = AudioDiffusion1D(unet_model_config_path=dict(RELEASED_CONFIG), encoder_depth=1)
+    with torch.no_grad():
+        for _, p_ in model.named_parameters():
+            if p_.dim() > 1:
+                p_.normal_(0, 0.02)
+        for n_, b_ in model.named_buffers():
+            if n_.endswith("_codebook.embed"):
+                b_.normal_(0, 0.5)
+    model = model.to(dev).prepare()
+    sq = ScalarModel(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
+                     downsample_kernel_sizes=[4, 8, 8, 10, 6], upsample_factors=[3, 5, 4, 4, 2],
+                     upsample_kernel_sizes=[6, 10, 8, 8, 4], latent_hidden_dim=136, default_kernel_size=7,
+                     delay_kernel_size=5, init_channel=32, res_kernel_size=7).to(dev).prepare()
+    tok = ReasoningTokenizer(sq_codec=sq, model=model, device=dev)
+    codes = torch.randint(0, 8192, (8, 250))
+    tok.detokenize_no_reason(codes, steps=2)                       # warm: packs, graph capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wav = tok.detokenize_no_reason(codes, steps=steps)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    est = model.cfm_wrapper.estimator
+    x = torch.randn(2, 500, RELEASED_CONFIG["in_channels"], device=dev)
+    est(x, 0.5); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        est(x, 0.5)
+    e1.record(); torch.cuda.synchronize()
+    step_ms = e0.elapsed_time(e1) / 5
+    flop = 2.0 * 500 * 32 * 2 * 12 * 1536 ** 2
+    return {"euler_steps": steps, "window_s": 20.0, "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
+            "dit_ms_per_guided_step": round(step_ms, 2), "dit_tflops": round(flop / (step_ms * 1e-3) / 1e12, 1),
+            "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
+
+
 def batched_leg(model, dev, B=64, frames=24):
     """Information beside the B = 1 headline: one GPU decoding B = 64 sequences together
     (32..33-token prompts, greedy, same kernels; rows bit-identical to their B = 1 runs, tests/test_gpu_configs.py).
@@ -457,6 +504,7 @@ def main():
                                "parity-UNPINNED against the package itself (absent here)")
     if solo and not a.no_legs:
         res["codec"] = codec_leg(dev)
+        res["codec"]["stage2_codes_to_wav"] = stage2_leg(dev)
         res["config5_ttm_500_frames"] = config5_leg(model, dev)
         res["batched_decode"] = batched_leg(model, dev)
         res["config3_asr_batch32"] = config3_leg(model, dev)

@@ -14,6 +14,9 @@ torch.cuda.set_device(0)
 if leg == "codec":
     print(bench.codec_leg(dev))
     sys.exit(0)
+if leg == "stage2":
+    print(bench.stage2_leg(dev))
+    sys.exit(0)
 model = bench.build_model(dev)
 if leg == "config3":
     print(bench.config3_leg(model, dev))

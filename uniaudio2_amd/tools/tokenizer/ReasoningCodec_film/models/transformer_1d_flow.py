@@ -142,12 +142,15 @@ class AdaLayerNormSingleFlow(nn.Module):
         self._p = dict(l1=PackedLinear(te.linear_1.weight, te.linear_1.bias, dtype), l2=PackedLinear(te.linear_2.weight, te.linear_2.bias, dtype),
                        lin=PackedLinear(self.linear.weight, self.linear.bias, dtype))
 
-    def run(self, t: float, device):
-        """t: the step's time in [0, 1] (host scalar: the Euler schedule is host-side) -> (ts [6D], embedded [D])."""
-        half = self.emb.flow_t_size // 2                                      # :57-72, a 512-entry table of cos | sin: host-side
+    def sinusoid(self, t: float):
+        """:57-72: the 512-entry cos | sin vector of the step's time t in [0, 1] (host side: the Euler schedule is host-side)."""
+        half = self.emb.flow_t_size // 2
         freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
         args = torch.tensor([t], dtype=torch.float32)[:, None] * freqs[None] * 1000
-        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(device)
+        return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+    def run(self, emb):
+        """emb [1, 512] device (sinusoid(t)) -> (ts [6D], embedded [D])."""
         p = self._p
         e = p["l2"](ops.ew_act(p["l1"](emb), EW_SILU))
         return p["lin"](ops.ew_act(e, EW_SILU)).view(-1), e.view(-1)
@@ -197,27 +200,56 @@ class Transformer1DModel(nn.Module):
         pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
         self._pe = pe.to(dev).contiguous()
         self._table = self.scale_shift_table.detach().float().contiguous().view(-1)
-        self._dtype, self._ready, self._kv = dtype, True, None
+        self._dtype, self._ready, self._kv, self._graphs = dtype, True, None, {}
         return self
 
-    @torch.inference_mode()
-    def forward(self, hidden_states, timestep: float):
-        """hidden_states (B, T, in_channels) fp32, one timestep for the whole batch -> (B, T, out_channels) fp32
-        (transformer_1d_flow.py:279-386 `.sample`)."""
-        if not self._ready:
-            self.prepare()
+    def _forward_impl(self, hidden_states, emb):
         B, T, Cin = hidden_states.shape
         D = self.inner_dim
         x = hidden_states.reshape(B * T, Cin).float().contiguous()
         h = self.proj_in.run(x, B, T)
         h = ops.ew_fma(h, c=self._pe[:T])                                     # + pos_embed (:338); the modulo broadcast repeats it per batch element
-        ts, emb = self.adaln_single.run(float(timestep), h.device)
-        if self._kv is None or self._kv.B != B or self._kv.T != T:
-            self._kv = DenseKV(B, T, self.heads, self.head_dim, self._dtype, h.device)
+        ts, e = self.adaln_single.run(emb)
         for blk in self.transformer_blocks:
             blk.run(h, ts, self._kv)
-        mod = ops.ew_fma(self._table, c=emb)                                  # (2, D): scale_shift_table + embedded_timestep  :378
+        mod = ops.ew_fma(self._table, c=e)                                    # (2, D): scale_shift_table + embedded_timestep  :378
         shift, scale = mod[:D], mod[D:]
         hn = ops.layernorm_rows(h, None, None, 1e-6)                          # norm_out :379
         hm = ops.ew_fma(hn, b=ops.ew_fma(scale, beta=1.0), c=shift)           # * (1 + scale) + shift  :381
         return self.proj_out.run(hm, B, T).view(B, T, self.out_channels)
+
+    @torch.inference_mode()
+    def forward(self, hidden_states, timestep: float, use_graph: bool = True):
+        """hidden_states (B, T, in_channels) fp32, one timestep for the whole batch -> (B, T, out_channels) fp32
+        (transformer_1d_flow.py:279-386 `.sample`).  The ~400 launches of a step are captured once per (B, T) into a HIP
+        graph and replayed (the Euler loop calls this 10-50 times per window with identical shapes; issued one by one from
+        Python the step was host-bound: 39 ms at the released size against ~8 ms of kernel time)."""
+        if not self._ready:
+            self.prepare()
+        B, T, Cin = hidden_states.shape
+        dev = hidden_states.device
+        if self._kv is None or self._kv.B != B or self._kv.T != T:
+            self._kv = DenseKV(B, T, self.heads, self.head_dim, self._dtype, dev)
+            self._graphs = {}
+        emb = self.adaln_single.sinusoid(float(timestep))
+        if not use_graph:
+            return self._forward_impl(hidden_states, emb.to(dev))
+        g = self._graphs.get((B, T))
+        if g is None:
+            x_in = torch.empty(B, T, Cin, dtype=torch.float32, device=dev)
+            e_in = torch.empty(1, emb.shape[1], dtype=torch.float32, device=dev)
+            x_in.copy_(hidden_states); e_in.copy_(emb)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                                     # warm-up outside capture: one-time kernel attributes, allocator pools
+                self._forward_impl(x_in, e_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                y = self._forward_impl(x_in, e_in)
+            g = self._graphs[(B, T)] = (graph, x_in, e_in, y)
+        graph, x_in, e_in, y = g
+        x_in.copy_(hidden_states)
+        e_in.copy_(emb, non_blocking=True)
+        graph.replay()
+        return y.clone()
