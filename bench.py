@@ -218,11 +218,11 @@ def stage2_leg(dev, steps=10):
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
 
 
-def batched_leg(model, dev, B=64, frames=24):
+def batched_leg(model, dev, B=64, frames=24, max_seq=2048):
     """Information beside the B = 1 headline: one GPU decoding B = 64 sequences together
     (32..33-token prompts, greedy, same kernels; rows bit-identical to their B = 1 runs, tests/test_gpu_configs.py).
     Re-plans the caches for 64 sequences, so it runs last."""
-    model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=2048, max_rows=B * PROMPT_LEN, log_frames=frames + 8)
+    model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=max_seq, max_rows=B * PROMPT_LEN, log_frames=frames + 8)
     g = torch.Generator().manual_seed(99)
     t = torch.zeros(B, PROMPT_LEN, 9, dtype=torch.long)
     t[:, :, -1] = torch.randint(0, 128000, (B, PROMPT_LEN), generator=g)
@@ -242,9 +242,12 @@ def batched_leg(model, dev, B=64, frames=24):
         model.generate_frames(frames, B, 0, reason_eos=-1, reason_card=REASON_CARD, max_pos=PROMPT_LEN + frames)
         e2.record()
         torch.cuda.synchronize()
+        ms = e1.elapsed_time(e2) / frames
         res = {"B": B, "prefill_rows": B * (PROMPT_LEN - 1), "prefill_ms": round(e0.elapsed_time(e1), 2),
-               "decode_ms_per_frame": round(e1.elapsed_time(e2) / frames, 3),
-               "audio_tokens_per_s": round(8 * B * frames / (e1.elapsed_time(e2) * 1e-3), 1)}
+               "decode_ms_per_frame": round(ms, 3), "audio_tokens_per_s": round(8 * B * frames / (e1.elapsed_time(e2) * 1e-3), 1),
+               # 11.8 GFLOP per sequence and frame against the dense bf16 MFMA peak
+               "decode_gemm_frac_bf16_mfma_peak": round(11.8e9 * B / (ms * 1e-3) / 2.5e15, 4),
+               "decode_frac_hbm_streamed_weights": round(11.8e9 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return res
 
 
@@ -507,6 +510,7 @@ def main():
         res["codec"]["stage2_codes_to_wav"] = stage2_leg(dev)
         res["config5_ttm_500_frames"] = config5_leg(model, dev)
         res["batched_decode"] = batched_leg(model, dev)
+        res["batched_decode_256"] = batched_leg(model, dev, B=256, frames=12, max_seq=128)
         res["config3_asr_batch32"] = config3_leg(model, dev)
     if rank == 0:
         print(json.dumps(res), flush=True)
