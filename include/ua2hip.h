@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 2
+#define UA2_VERSION 3
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -107,6 +107,10 @@ typedef struct ua2_kv_geom {
   int32_t n_kv;      /* n_query_groups */
   int32_t n_head;
   int32_t head_size;
+  int32_t ring_pages; /* 0: linear cache (page of position p = p / UA2_PAGE).  > 0: ring cache — position p lives in table column
+                         (p / UA2_PAGE) % ring_pages, so a streaming session of any length re-uses ring_pages pages per sequence
+                         (RingKVCache, llm_modules/transformer.py:211-278).  The caller guarantees ring_pages * UA2_PAGE exceeds
+                         the attention window plus the positions written per launch; ua2_attn needs window > 0 with it. */
 } ua2_kv_geom;
 
 typedef struct ua2_linear_args {
@@ -292,6 +296,13 @@ typedef struct ua2_conv1d_args {
   float* y;                        /* [B, Cout, Tout] */
   const void* w_lo;                /* precision 1: packed bf16 low halves of the filter */
   int32_t precision;               /* 0 = exact fp32 (f32-input MFMA), 1 = bf16 x 3 */
+  /* precision 1, optional: fused residual unit (scalar24k.py:143-151) — y = residual + PReLU(alpha2, W2 h + bias2) with
+     h = post_act(conv(x) + bias) kept on chip; W2 a 1 x 1 conv [Cout, Cout] packed like w / w_lo (pack_conv_weight_x3 of
+     [Cout, Cout, 1]).  Needs Cin == Cout in {32, 64, 128}, stride 1, Tin == Tout, residual. */
+  const void* w2;
+  const void* w2_lo;
+  const float* bias2;              /* [Cout] or NULL */
+  const float* alpha2;             /* PReLU slope (1 value) of the second activation, NULL = 0 (ReLU) */
 } ua2_conv1d_args;
 
 int ua2_conv1d(const ua2_conv1d_args* a, void* stream);

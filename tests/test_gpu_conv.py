@@ -184,3 +184,29 @@ def test_seanet_streaming_equals_whole_sequence():
     lat_s = torch.cat(outs, dim=-1)
     assert lat_s.shape == lat.shape
     assert (lat_s - lat).norm() / lat.norm() <= 1e-5
+
+
+@pytest.mark.parametrize("C,dil,T", [(32, 9, 1000), (64, 1, 333), (128, 5, 257), (32, 3, 70)])
+def test_fused_residual_unit_matches_torch(C, dil, T):
+    """The fused residual unit of the bf16 x 3 conv kernel (scalar24k.py:143-151): y = x + prelu2(W2 prelu1(conv1(x) + b1) + b2)
+    in one launch, against the torch composition; and against the two-launch route through the same kernel (1e-4 of scale:
+    the fused route rounds h to 16 bits through the same hi / lo split the unfused route applies when it re-stages h)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import ACT_PRELU
+    g = torch.Generator().manual_seed(C + dil)
+    x = torch.randn(2, C, T, generator=g)
+    w1 = torch.randn(C, C, 7, generator=g) / (7 * C) ** 0.5
+    w2 = torch.randn(C, C, 1, generator=g) / C ** 0.5
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    a1, a2 = torch.tensor([0.2]), torch.tensor([0.3])
+    h = F.prelu(F.conv1d(F.pad(x, (dil * 6, 0)), w1, b1, dilation=dil), a1)
+    ref = F.prelu(F.conv1d(h, w2, b2), a2) + x
+    w1h, w1l = ops.pack_conv_weight_x3(w1.cuda())
+    w2h, w2l = ops.pack_conv_weight_x3(w2.cuda())
+    xc = x.cuda()
+    y = ops.conv1d(xc, w1h, 7, C, dilation=dil, pad_left=dil * 6, Tout=T, bias=b1.cuda(), post_act=ACT_PRELU, post_alpha=a1.cuda(),
+                   residual=xc, w_lo=w1l, fused2=(w2h, w2l, b2.cuda(), a2.cuda()))
+    _close(y, ref, tol=1e-4)
+    hh = ops.conv1d(xc, w1h, 7, C, dilation=dil, pad_left=dil * 6, Tout=T, bias=b1.cuda(), post_act=ACT_PRELU, post_alpha=a1.cuda(), w_lo=w1l)
+    y2 = ops.conv1d(hh, w2h, 1, C, Tout=T, bias=b2.cuda(), post_act=ACT_PRELU, post_alpha=a2.cuda(), residual=xc, w_lo=w2l)
+    _close(y, y2.cpu(), tol=1e-5)

@@ -56,3 +56,33 @@ def test_streaming_session_equals_whole_sequence(golden_dir):
                 step = step % 7 + 1
         assert not m.is_streaming
         np.testing.assert_allclose(torch.cat(parts, 1).cpu().numpy(), d[name + "_out"], atol=2e-4, rtol=0)
+
+
+def test_ring_cache_streams_past_the_linear_capacity():
+    """RingKVCache (llm_modules/transformer.py:211-278) role: with a finite `context` a streaming session re-uses a fixed
+    ring of cache pages, so it may run past any linear capacity.  2500 positions (> the 2048-slot linear cache round 1 capped
+    sessions at) streamed in chunks of 1..150 equal the whole-sequence forward over a 2500-slot linear cache with the same
+    context window — bit for bit: the ring only changes WHERE a key is stored, the attention visits the same keys in the
+    same order.  (The reference ring's off-by-one, SURVEY A.16, is consciously not reproduced: streaming == whole sequence.)"""
+    from uniaudio2_amd.tools.tokenizer.MimiCodec.model.modules.transformer import StreamingTransformer
+    cfg = dict(MIMI, context=100)
+    T = 2500
+    whole_m = StreamingTransformer(**cfg)
+    sd = moshi_state_dict({k: tuple(v.shape) for k, v in whole_m.state_dict().items()}, 51)
+    whole_m.load_state_dict(sd)
+    whole_m = whole_m.cuda()
+    x = seeded_tensor((1, T, cfg["d_model"]), 777, std=1.0).cuda()
+    whole_m.prepare(max_batch=1, max_seq_length=T, dtype=torch.float32)
+    whole = whole_m(x)
+    m = StreamingTransformer(**cfg)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    parts, t, step = [], 0, 1
+    with m.streaming(1):
+        while t < T:
+            parts.append(m(x[:, t:t + step].contiguous()))
+            t += step
+            step = step * 3 % 151 + 1
+        assert m._plan["ring_pages"] > 0 and m._plan["k"][0].shape[0] == m._plan["ring_pages"]      # a handful of pages, not T / 64
+    got = torch.cat(parts, 1)
+    assert got.shape == whole.shape and torch.equal(got, whole)

@@ -29,7 +29,7 @@ vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
 
 class KvGeom(C.Structure):
     _fields_ = [("k_pool", vp), ("v_pool", vp), ("page_table", vp), ("max_pages", i32), ("n_kv", i32),
-                ("n_head", i32), ("head_size", i32)]
+                ("n_head", i32), ("head_size", i32), ("ring_pages", i32)]
 
 
 class LinearArgs(C.Structure):
@@ -53,7 +53,7 @@ class Conv1dArgs(C.Structure):
     _fields_ = [("B", i32), ("Cin", i32), ("Cout", i32), ("Tin", i32), ("Tout", i32), ("K", i32), ("stride", i32),
                 ("dilation", i32), ("pad_left", i32), ("in_repeat", i32), ("out_phases", i32), ("out_trim_left", i32),
                 ("pre_act", i32), ("post_act", i32), ("x", vp), ("w", vp), ("bias", vp), ("pre_alpha", vp),
-                ("post_alpha", vp), ("post_alpha_n", i32), ("residual", vp), ("y", vp), ("w_lo", vp), ("precision", i32)]
+                ("post_alpha", vp), ("post_alpha_n", i32), ("residual", vp), ("y", vp), ("w_lo", vp), ("precision", i32), ("w2", vp), ("w2_lo", vp), ("bias2", vp), ("alpha2", vp)]
 
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_TANH, ACT_ROUND9 = 0, 1, 2, 3, 4

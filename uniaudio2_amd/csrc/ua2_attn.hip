@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
     for (int u = 0; u < UNR; ++u) {
       const int j = jb + u * RPW + rin;
       const int jc = (j < j1) ? j : j0;           // clamp: unconditional loads, masked in the math
-      const size_t off = ((((size_t)ptab[jc / UA2_PAGE] * a.kv.n_kv + kvh) * UA2_PAGE + (jc % UA2_PAGE)) * HS +
+      const size_t off = ((((size_t)ptab[ua2_page_slot(a.kv, jc)] * a.kv.n_kv + kvh) * UA2_PAGE + (jc % UA2_PAGE)) * HS +
                           (size_t)sub * EPL) * BYTES;
       kr[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.k_pool + off);
       vr[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.v_pool + off);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();                          // the previous block's readers are done
     {
-      const size_t base = (((size_t)ptab[kb] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
+      const size_t base = (((size_t)ptab[ua2_page_slot(a.kv, kb * UA2_PAGE)] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
       const u32x4* kg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.k_pool) + base);
       const u32x4* vg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.v_pool) + base);
       for (int i = tid; i < PIECES; i += 64 * NW) {
@@ -501,6 +501,8 @@ int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
+  UA2_CHECK(a.kv.ring_pages == 0 || (a.window > 0 && a.kv.ring_pages <= a.kv.max_pages && a.window <= (a.kv.ring_pages - 1) * UA2_PAGE + 1),
+            "ua2_attn: a ring cache (ring_pages=%d) needs 0 < window <= (ring_pages - 1) * %d + 1", a.kv.ring_pages, UA2_PAGE);
   UA2_CHECK(!a.y_packed || (a.kv.n_head * a.kv.head_size) % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_attn: y_packed needs n_head*head_size %% chunk == 0");
   if (a.group_rows && a.n_groups > 0 && a.dtype == UA2_BF16 && a.window <= 0) {   // many rows per sequence: MFMA flash form
     UA2_CHECK(a.group_seq && a.group_nkeys && a.group_q_tiles > 0, "ua2_attn: group_seq / group_nkeys / group_q_tiles missing");

@@ -154,7 +154,7 @@ __global__ void qknorm_rope_kv_kernel(const float* __restrict__ qkv, const int32
   }
   q_out[(size_t)r * dim + h * hs + d] = q;
   const int seq = row_seq ? row_seq[r] : r;
-  const int page = kv.page_table[(size_t)seq * kv.max_pages + pos / UA2_PAGE];
+  const int page = kv.page_table[(size_t)seq * kv.max_pages + ua2_page_slot(kv, pos)];
   const size_t base = (((size_t)page * kv.n_kv + h) * UA2_PAGE + (pos % UA2_PAGE)) * hs + d;
   store_elem<DT>(kv.k_pool, base, k);
   store_elem<DT>(kv.v_pool, base, v);

@@ -84,6 +84,13 @@ __device__ __forceinline__ void store_packed_operand(void* base, int m, int k, i
   store_elem<DT>(base, elem, v);
 }
 
+// Page-table column of position `pos`: linear caches index by pos / 64; ring caches (kv.ring_pages > 0: the streaming
+// transformers of the Moshi family, llm_modules/transformer.py:211-278) wrap over ring_pages pages.
+__device__ __forceinline__ int ua2_page_slot(const ua2_kv_geom& kv, int pos) {
+  const int lp = pos / UA2_PAGE;
+  return kv.ring_pages > 0 ? lp % kv.ring_pages : lp;
+}
+
 static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised.  The

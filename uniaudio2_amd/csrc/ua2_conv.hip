@@ -251,6 +251,85 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
       }
     }
   }
+  if (a.w2) {
+    // ---- fused residual unit (scalar24k.py:143-151): y = x + act2(W2 act1(conv1(x) + b1) + b2), W2 a 1 x 1 conv ----
+    // The workgroup holds ALL C output channels of its time tile (launcher: gridDim.y == 1), so the 1 x 1 conv's reduction
+    // over channels closes inside it: the intermediate h never goes to HBM (un-fused: written, re-read, plus a second
+    // launch — 5 passes over a C x T tensor per unit instead of 2, on layers that are HBM-bound).
+    const int C = a.Cout, ng2 = C / kCG3;
+    char* hbase = smc + 2 * (size_t)W * kRowB;                          // [ng2][2 planes][wgt][kRowB]
+    const size_t hplane = (size_t)wgt * kRowB;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      const int nb = r0 + q * 16 + g * 4;                               // this lane's 4 consecutive channels nb .. nb+3
+      const int grp = nb / kCG3, pc = nb % kCG3;
+      float bs[4], al1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bs[r] = a.bias ? a.bias[nb + r] : 0.f;
+        al1[r] = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? nb + r : 0] : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        const int tw = tw0 + nt * 16 + tl;
+        unsigned hh[4], hl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = apply_act(acc[q][nt][r] + bs[r], a.post_act, al1[r]);
+          hh[r] = f2bf(hv);
+          hl[r] = f2bf(hv - bf2f((unsigned short)hh[r]));
+        }
+        char* dst = hbase + (size_t)grp * 2 * hplane + (size_t)tw * kRowB + pc * 2;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
+        *reinterpret_cast<uint2*>(dst + hplane) = make_uint2(hl[0] | (hl[1] << 16), hl[2] | (hl[3] << 16));
+      }
+    }
+    __syncthreads();
+    f32x4 acc2[RPW][NTT];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) acc2[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cg = 0; cg < ng2; ++cg) {
+      bf16x8 ah[RPW], al[RPW];
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const size_t wo = ((size_t)(r0 / 16 + q) * ng2 + cg) * 64 + lane;
+        ah[q] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(a.w2)[wo]);
+        al[q] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(a.w2_lo)[wo]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        const size_t o = (size_t)cg * 2 * hplane + (size_t)(tw0 + nt * 16 + tl) * kRowB + g * 16;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(hbase + o));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(hbase + o + hplane));
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          acc2[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh, acc2[q][nt], 0, 0, 0);
+          acc2[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl, acc2[q][nt], 0, 0, 0);
+          acc2[q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh, acc2[q][nt], 0, 0, 0);
+        }
+      }
+    }
+    const float alpha2 = a.alpha2 ? a.alpha2[0] : 0.f;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = r0 + q * 16 + g * 4 + r;
+        const float b2 = a.bias2 ? a.bias2[n] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+          const int t = t0 + tw0 + nt * 16 + tl;
+          if (t >= a.Tout) continue;
+          const size_t o = ((size_t)b * C + n) * a.Tout + t;
+          float v = acc2[q][nt][r] + b2;
+          v = v >= 0.f ? v : alpha2 * v;
+          a.y[o] = v + a.residual[o];
+        }
+      }
+    return;
+  }
   if (!wave_active) return;
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
@@ -354,11 +433,16 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
     const int wave_rows = 16 * rpw;
     const int rt = rows > 2 * wave_rows ? 4 : (rows > wave_rows ? 2 : 1);  // wave row-groups per workgroup; the other waves split time
     const int row_blocks3 = ua2_ceil_div(rows, wave_rows * rt);
+    if (a->w2) {   // fused residual unit: one workgroup must hold every output channel of its time tile
+      UA2_CHECK(a->w2_lo && a->residual && a->out_phases == 1 && a->stride == 1 && a->in_repeat == 1 && a->Cin == a->Cout &&
+                    (a->Cout == 32 || a->Cout == 64 || a->Cout == 128) && row_blocks3 == 1 && a->Tin == a->Tout,
+                "ua2_conv1d: the fused residual unit needs Cin == Cout in {32, 64, 128}, stride 1, Tin == Tout, w2_lo and residual");
+    }
     int ntt = 4;
     while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / rt)) * row_blocks3 * a->B < 512) ntt >>= 1;
     const int wgt = 16 * ntt * (4 / rt);
     const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
-    const size_t smem3 = (size_t)2 * W3 * kRowB;
+    const size_t smem3 = (size_t)2 * W3 * kRowB + (a->w2 ? (size_t)(a->Cout / 32) * 2 * wgt * kRowB : 0);
     UA2_CHECK(smem3 <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem3);
     const dim3 grid3(ua2_ceil_div(tq, wgt), row_blocks3, a->B);
     hipStream_t st = (hipStream_t)stream;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
         if (is_q) {
           *reinterpret_cast<float4*>(a.q_out + (size_t)m * a.kv.n_head * hs + (size_t)h * hs + dd) = out;
         } else {
-          const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages + pos / UA2_PAGE];
+          const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages + ua2_page_slot(a.kv, pos)];
           const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs + dd;
           void* pool = is_k ? a.kv.k_pool : a.kv.v_pool;
           if constexpr (DT == UA2_BF16) {

@@ -138,7 +138,7 @@ __device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, in
       p.cs = a.rope_cos[(size_t)p.pos * half + d];
       p.sn = a.rope_sin[(size_t)p.pos * half + d];
     }
-    if (h >= a.kv.n_head) p.page = a.kv.page_table[(size_t)p.page * a.kv.max_pages + p.pos / UA2_PAGE];
+    if (h >= a.kv.n_head) p.page = a.kv.page_table[(size_t)p.page * a.kv.max_pages + ua2_page_slot(a.kv, p.pos)];
   }
 }
 template <int DT, int EPI>

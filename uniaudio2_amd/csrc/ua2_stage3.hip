@@ -90,7 +90,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   for (int l = 0; l < g.n_layer; ++l) {
-    ua2_kv_geom kv;
+    ua2_kv_geom kv{};                      // ring_pages = 0: the LM's caches are linear
     kv.k_pool = h->pools[gi][0][l]; kv.v_pool = h->pools[gi][1][l]; kv.page_table = g.page_table;
     kv.max_pages = g.max_pages; kv.n_kv = g.n_kv; kv.n_head = g.n_head; kv.head_size = g.head_size;
 

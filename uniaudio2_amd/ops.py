@@ -48,8 +48,9 @@ def pack_linear(weight, dtype, transposed=False, rope_head_size=0):
     return out
 
 
-def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size):
+def kv_geom(k_pool, v_pool, page_table, n_head, n_kv, head_size, ring_pages=0):
     g = KvGeom()
+    g.ring_pages = ring_pages
     g.k_pool, g.v_pool, g.page_table = ptr(k_pool), ptr(v_pool), ptr(page_table)
     g.max_pages = page_table.shape[-1] if page_table is not None else 0
     g.n_kv, g.n_head, g.head_size = n_kv, n_head, head_size
@@ -238,7 +239,7 @@ def pack_conv_weight_x3(w_rows):
 
 
 def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None, bias=None, pre_act=0, pre_alpha=None,
-           post_act=0, post_alpha=None, residual=None, in_repeat=1, out_phases=1, out_trim_left=0, w_lo=None):
+           post_act=0, post_alpha=None, residual=None, in_repeat=1, out_phases=1, out_trim_left=0, w_lo=None, fused2=None):
     from ._lib import Conv1dArgs
     B, Cin, Tin = x.shape
     a = Conv1dArgs()
@@ -253,6 +254,8 @@ def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None,
     a.residual, a.y = ptr(residual), ptr(y)
     if w_lo is not None:                  # bf16 x 3 form: (w_packed, w_lo) = pack_conv_weight_x3(...)
         a.w_lo, a.precision = ptr(w_lo), 1
+    if fused2 is not None:                # (w2_hi, w2_lo, bias2, alpha2): the 1 x 1 conv + PReLU + residual of a residual unit, fused
+        a.w2, a.w2_lo, a.bias2, a.alpha2 = ptr(fused2[0]), ptr(fused2[1]), ptr(fused2[2]), ptr(fused2[3])
     check(lib.ua2_conv1d(C.byref(a), stream()), "ua2_conv1d")
     return y
 

@@ -149,13 +149,20 @@ class StreamingTransformer(StreamingModule):
                                                                rope=self.rope, device=device, **kwargs) for _ in range(num_layers)])
         self._plan = None
         self._plan_capacity = self._plan_batch = 0
-        self.streaming_capacity = 2048          # positions one streaming session may span (linear cache; transformer.py's ring is not built)
+        self.streaming_capacity = 2048          # positions one streaming session may span WITHOUT a context (linear cache)
+        self.ring_chunk = 64                    # positions per launch of a ring-cached streaming session
+        self.rope_capacity = 1 << 16            # positions the RoPE table of a ring-cached session covers (about 87 min at 12.5 Hz)
 
     def _init_streaming_state(self, batch_size: int):
         return {"offset": 0}
 
     # ---- device plan -----------------------------------------------------------------------------
-    def prepare(self, max_batch=1, max_seq_length=1024, dtype=torch.float32):
+    def prepare(self, max_batch=1, max_seq_length=1024, dtype=torch.float32, ring=False):
+        """ring: streaming with a finite `context` (transformer.py:211-278 RingKVCache) — position p lives in page
+        (p / 64) % ring_pages, so a session of any length re-uses ceil((context + ring_chunk) / 64) + 1 pages per sequence; the
+        RoPE table is replaced by a long one (positions are unbounded).  The reference ring's off-by-one (the slot
+        about to be overwritten is masked, so the streaming window is context - 1) is consciously NOT reproduced: streaming equals
+        the non-streaming forward, which keeps `context` keys."""
         self._plan_capacity, self._plan_batch = max_seq_length, max_batch
         dev = self.layers[0].self_attn.in_proj_weight.device
         if dev.type != "cuda":
@@ -187,6 +194,10 @@ class StreamingTransformer(StreamingModule):
                                     for g in gs])
             plan["layers"].append(e)
         n_pages = (max_seq_length + UA2_PAGE - 1) // UA2_PAGE
+        plan["ring_pages"] = 0
+        if ring:
+            n_pages = (self.context + self.ring_chunk + UA2_PAGE - 1) // UA2_PAGE + 1
+            plan["ring_pages"] = n_pages
         plan["max_pages"] = n_pages
         shape = (max_batch * n_pages, H, UA2_PAGE, hs)
         plan["k"] = [torch.zeros(shape, dtype=dtype, device=dev) for _ in self.layers]
@@ -208,7 +219,7 @@ class StreamingTransformer(StreamingModule):
         for li, e in enumerate(p["layers"]):
             s = step if e["wps"] > 1 else 0
             kind, w, b, eps = e["n1"]
-            geom = ops.kv_geom(p["k"][li], p["v"][li], p["ptab"], H, H, hs)
+            geom = ops.kv_geom(p["k"][li], p["v"][li], p["ptab"], H, H, hs, ring_pages=p["ring_pages"])
             ops.linear(dtype=dt, M=R, N=3 * d, K=d, w0=e["qkv"][s], prologue=PRO_NORM, epilogue=EPI_QKV_ROPE, x=xs, norm_w=w,
                        norm_b=b, norm_kind=kind, eps=eps, row_pos=row_pos, row_seq=row_seq, rope_cos=p.get("cos"),
                        rope_sin=p.get("sin"), rope_mode=rope_mode, q_out=q, kv=geom)
@@ -238,10 +249,19 @@ class StreamingTransformer(StreamingModule):
             assert offset == 0, "pass either an explicit offset or use streaming(), not both"
             offset = state["offset"]
             state["offset"] = offset + x.shape[1]
-            if offset + x.shape[1] > self.streaming_capacity:
-                raise RuntimeError(f"streaming past {self.streaming_capacity} positions needs the ring cache (not built)")
-            if self._plan is None or self._plan_capacity < self.streaming_capacity or self._plan_batch < x.shape[0]:
-                self.prepare(max_batch=x.shape[0], max_seq_length=self.streaming_capacity)
+            if self.context:                                  # finite context: ring cache, unbounded session length
+                if self._plan is None or not self._plan["ring_pages"] or self._plan_batch < x.shape[0]:
+                    self.prepare(max_batch=x.shape[0], max_seq_length=self.rope_capacity, ring=True)
+                if offset + x.shape[1] > self.rope_capacity and self.rope is not None:
+                    raise RuntimeError(f"the RoPE table covers {self.rope_capacity} positions; raise rope_capacity for longer sessions")
+                if x.shape[1] > self.ring_chunk:       # keep (context + positions per launch) inside the ring
+                    state["offset"] = offset
+                    return torch.cat([self.forward(x[:, t:t + self.ring_chunk]) for t in range(0, x.shape[1], self.ring_chunk)], dim=1)
+            else:
+                if offset + x.shape[1] > self.streaming_capacity:
+                    raise RuntimeError(f"streaming past {self.streaming_capacity} positions without a context (an unbounded cache)")
+                if self._plan is None or self._plan_capacity < self.streaming_capacity or self._plan_batch < x.shape[0]:
+                    self.prepare(max_batch=x.shape[0], max_seq_length=self.streaming_capacity)
         if self._plan is None:
             self.prepare(max_batch=x.shape[0], max_seq_length=max(UA2_PAGE, offset + x.shape[1]))
         B, T, Cc = x.shape

@@ -132,8 +132,18 @@ class ResidualUnit(nn.Module):
     def prepare(self):
         self._op1 = _ConvOp(self.conv1, ACT_PRELU, self.activation1.weight)
         self._op2 = _ConvOp(self.conv2, ACT_PRELU, self.activation2.weight)
+        # bf16 x 3 form with up to 128 channels: both convs, both PReLUs and the residual add in ONE launch (the 1 x 1 conv's
+        # reduction over channels closes inside the workgroup that holds them), h never leaves the chip
+        c = self.conv1.out_channels
+        self._fused = None
+        if self._op1.w_lo is not None and self.conv1.in_channels == c and c in (32, 64, 128) and self.conv2.kernel_size[0] == 1:
+            self._fused = (self._op2.w, self._op2.w_lo, self._op2.bias, self._op2.alpha)
 
     def run(self, x):
+        if self._fused is not None:
+            o = self._op1
+            return ops.conv1d(x, o.w, o.K, o.cout, dilation=o.dil, pad_left=o.pad_l, Tout=x.shape[-1], bias=o.bias, post_act=o.post_act,
+                              post_alpha=o.alpha, residual=x, w_lo=o.w_lo, fused2=self._fused)
         return self._op2(self._op1(x), residual=x)                    # :148-151
 
 
