@@ -143,7 +143,7 @@ constexpr int kCG3 = 32;       // channels per staging group
 constexpr int kRowB = 80;      // LDS bytes per window position per plane
 
 template <int NTT, int RPW>
-__global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a, const int rt) {
+__global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args a, const int rt) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
   const int K = a.K, s = a.stride, d = a.dilation;
   const int tsub = 4 / rt;
@@ -191,6 +191,24 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
 #pragma unroll
     for (int q = 0; q < RPW; ++q) { wh[q] = wph[q][0]; wl[q] = wpl[q][0]; }
   }
+
+  // Residual values of this wave's output tile, requested up front: read in the epilogue one by one (each load in front of a
+  // store the compiler must assume it aliases) they cost a memory round trip apiece — 32 of them, ~30 us of a 40 us launch.
+  float resv[RPW][4][NTT];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        resv[q][r][nt] = 0.f;
+        if (a.residual) {
+          const int n = r0 + q * 16 + g * 4 + r;
+          const int phase = n / a.Cout, co = n - phase * a.Cout;
+          const int to = (t0 + tw0 + nt * 16 + tl) * a.out_phases + phase - a.out_trim_left;
+          if (n < rows && to >= 0 && to < a.Tout) resv[q][r][nt] = a.residual[((size_t)b * a.Cout + co) * a.Tout + to];
+        }
+      }
 
   for (int cg = 0; cg < ngroups; ++cg) {
     __syncthreads();
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
           const size_t o = ((size_t)b * C + n) * a.Tout + t;
           float v = acc2[q][nt][r] + b2;
           v = v >= 0.f ? v : alpha2 * v;
-          a.y[o] = v + a.residual[o];
+          a.y[o] = v + resv[q][r][nt];
         }
       }
     return;
@@ -348,8 +366,7 @@ __global__ __launch_bounds__(256) void conv1d_x3_kernel(const ua2_conv1d_args a,
         float v = acc[q][nt][r] + bias;
         v = apply_act(v, a.post_act, alpha);
         const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
-        if (a.residual) v += a.residual[o];
-        a.y[o] = v;
+        a.y[o] = v + resv[q][r][nt];
       }
     }
   }
@@ -440,9 +457,14 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
     }
     int ntt = 4;
     while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / rt)) * row_blocks3 * a->B < 512) ntt >>= 1;
+    auto lds_bytes = [&](int n) {
+      const int wg = 16 * n * (4 / rt);
+      return (size_t)2 * ((wg - 1) * a->stride + (a->K - 1) * a->dilation + 1) * kRowB + (a->w2 ? (size_t)(a->Cout / 32) * 2 * wg * kRowB : 0);
+    };
+    while (ntt > 1 && lds_bytes(ntt) > 52 * 1024) ntt >>= 1;            // keep three workgroups per CU resident (latency hiding beats tile size here)
     const int wgt = 16 * ntt * (4 / rt);
     const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
-    const size_t smem3 = (size_t)2 * W3 * kRowB + (a->w2 ? (size_t)(a->Cout / 32) * 2 * wgt * kRowB : 0);
+    const size_t smem3 = lds_bytes(ntt);
     UA2_CHECK(smem3 <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem3);
     const dim3 grid3(ua2_ceil_div(tq, wgt), row_blocks3, a->B);
     hipStream_t st = (hipStream_t)stream;
