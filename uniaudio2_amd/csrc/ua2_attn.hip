@@ -328,25 +328,38 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
 
   const int nkb = (nkeys + UA2_PAGE - 1) / UA2_PAGE;
   constexpr int PIECES = UA2_PAGE * HS / 8;   // 16-byte pieces per page
+  constexpr int NP = (PIECES + 64 * NW - 1) / (64 * NW);      // pieces per thread
+  u32x4 kk[NP], vv[NP];
+  // the pages of block kb + 1 are requested right after block kb's image is complete and travel while block kb is multiplied
+  auto request = [&](int kb) {
+    const size_t base = (((size_t)ptab[ua2_page_slot(a.kv, kb * UA2_PAGE)] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
+    const u32x4* kg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.k_pool) + base);
+    const u32x4* vg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.v_pool) + base);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = tid + u * 64 * NW;
+      if (i < PIECES) { kk[u] = kg[i]; vv[u] = vg[i]; }
+    }
+  };
+  if (nkb > 0) request(0);
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();                          // the previous block's readers are done
-    {
-      const size_t base = (((size_t)ptab[ua2_page_slot(a.kv, kb * UA2_PAGE)] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
-      const u32x4* kg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.k_pool) + base);
-      const u32x4* vg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.v_pool) + base);
-      for (int i = tid; i < PIECES; i += 64 * NW) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = tid + u * 64 * NW;
+      if (i < PIECES) {
         const int key = i / (HS / 8), oct = i % (HS / 8);
-        const u32x4 kk = kg[i], vv = vg[i];
-        *reinterpret_cast<u32x4*>(k_lds + key * KROW + oct * 16) = kk;
+        *reinterpret_cast<u32x4*>(k_lds + key * KROW + oct * 16) = kk[u];
         unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds + (size_t)(oct * 8) * VROW + key * 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {         // V^T: dim row oct*8 + 2e (+1), column = key
-          vt[(size_t)(2 * e) * (VROW / 2)] = (unsigned short)(vv[e] & 0xffffu);
-          vt[(size_t)(2 * e + 1) * (VROW / 2)] = (unsigned short)(vv[e] >> 16);
+          vt[(size_t)(2 * e) * (VROW / 2)] = (unsigned short)(vv[u][e] & 0xffffu);
+          vt[(size_t)(2 * e + 1) * (VROW / 2)] = (unsigned short)(vv[u][e] >> 16);
         }
       }
     }
     __syncthreads();
+    if (kb + 1 < nkb) request(kb + 1);
     // S^T tile kt: rows = keys kb*64 + kt*16 + 4g + r, column = this lane's query
     f32x4 st[4];
 #pragma unroll
