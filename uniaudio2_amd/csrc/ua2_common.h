@@ -55,6 +55,14 @@ template <> struct Elem<UA2_F32> {
   static constexpr int BYTES = 4;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() / s_barrier through the compiler costs more than it looks
+// on gfx9-family targets: the waitcnt pass puts a full `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of every s_barrier it sees
+// (no automatic wait-before-barrier in hardware), which drains every global load a kernel meant to keep in flight across
+// the barrier — register prefetch of the next tile, weight refills, the lot.  Spelled as inline asm the barrier is opaque
+// to that pass; the LDS writes the barrier publishes are waited for explicitly.  Use only where the data exchanged
+// through the barrier lives in LDS (global-memory hand-offs between waves still need __syncthreads()).
+__device__ __forceinline__ void ua2_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // fp32 -> bf16 bits, round to nearest even (same as torch's .to(torch.bfloat16)).
 __device__ __forceinline__ unsigned short f2bf(float f) {
   unsigned int u = __float_as_uint(f);

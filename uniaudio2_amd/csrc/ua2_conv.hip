@@ -26,6 +26,7 @@
 // weight fragments come pre-tiled (ua2_pack_linear fp32 layout over [rows][Cin_pad*K]) as one 16-byte
 // load per lane per chunk, reused by the 16 MFMAs of the four time tiles.
 #include "ua2_common.h"
+#include <string.h>
 
 namespace {
 
@@ -373,6 +374,339 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
   }
 }
 
+// ---- bf16 x 3, software-pipelined ---------------------------------------------------------------------------
+// conv1d_x3_kernel above runs its phases back to back inside a workgroup — request a channel group's window, wait a
+// memory round trip, convert, barrier, MFMAs with the weights one chunk (~100 cycles of MFMA) ahead of an ~600-cycle
+// L2 hit, epilogue — and leans on 3 co-resident workgroups to fill the gaps.  Measured per phase (UA2_CONV_DBG
+// experiments, profiles/r2_notes.md): the phases add up almost linearly; the 512-channel layers at T = 1500 (16
+// channel groups x a round trip each) ran at 1/10 of either roofline.  Here a workgroup walks a sequence of UNITS
+// (time tile, run of `gpu` channel groups) and every global load is consumed one whole unit after it was issued:
+//   * the x window of unit u+1 is requested right after the barrier that opens unit u, rides in registers (<= 16
+//     (channel pair, position) elements per thread) through u's MFMAs, and is converted + written to the OTHER LDS image;
+//   * all weight chunks of a unit (<= 8 of 16 B per lane per operand half) live in registers; chunk c of unit u+1 is
+//     requested into the registers of chunk c the moment u's MFMAs have read them.  vmcnt retires in order, so the
+//     x request goes out BEFORE those refills: the wait in front of the conversion then covers only the x loads, and
+//     each refill is first waited for one unit later;
+//   * a workgroup takes `tpw` consecutive time tiles, so the layers with one or two channel groups (C = 32, 64: all of
+//     the 120 / 240 kHz-rate work) pipeline across tiles.
+// One barrier per unit (two more inside a fused residual-unit epilogue).  Arithmetic, operand split and summation
+// order are those of conv1d_x3_kernel: the two kernels are bit-identical (tests/test_gpu_conv.py).
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+// (lo half = bf16(a), hi half = bf16(b)), round to nearest even: one v_cvt_pk_bf16_f32 (finite values: same bits as f2bf)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const f32x2_hw v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
+}
+// hi/lo split of a pair: hi = RNE(x), lo = RNE(x - hi)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(x0, x1);
+  lo = pack_bf16x2(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+constexpr int kKC = 8;         // most weight chunks (tap x channel group) a unit holds in registers
+
+// NTT 16-step time tiles per wave (one 16-row tile per wave), CPU weight chunks per unit = GPU channel groups x K taps.
+//
+// Staging map.  A unit's window is GPU x 16 channel pairs x W positions.  Wave w owns the 4 * GPU pairs
+// 4*GPU*w .. 4*GPU*(w+1)-1 and walks the window 64 positions at a time: element k of a thread is (position group k / PPW,
+// pair k % PPW) — both compile-time — so the channel row is wave-uniform (scalar base address, scalar validity), a wave-load
+// is 256 contiguous bytes, and the per-lane index work (clamp, repeat-upsampling division, padding mask, LDS row) is done
+// once per position group, not per element.  (The first pipelined version walked (pair, position) with per-element index
+// arithmetic: ~1400 VALU instructions per unit against 84 MFMAs — VALU-bound at 6 us per unit.)
+//
+// The unit loop is straight-line on purpose — the request for the unit after the last one is clamped onto the last, its
+// conversion lands in the idle LDS image — so that the s_waitcnt the compiler places in front of the conversion counts
+// exactly the weight refills issued behind the x loads, and nothing pending crosses the loop's back edge except those.
+template <int NTT, int CPU, int GPU, int NPG, bool UPT1>
+__global__ __launch_bounds__(256, 2) void conv1d_x3p_kernel(const ua2_conv1d_args a, const int rt, const int tpw, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  constexpr int K = CPU / GPU;
+  constexpr int PPW = 4 * GPU;                          // channel pairs per wave
+  constexpr int SB = PPW * NPG;                         // NPG position groups of 64 staged per unit (launcher: W <= 64 * NPG)
+  const int s = a.stride, d = a.dilation;
+  const int tsub = 4 / rt;
+  constexpr int kBT = 16 * NTT;
+  const int wgt = kBT * tsub;
+  const int W = (wgt - 1) * s + (K - 1) * d + 1;
+  // LDS image rows are padded to whole position groups: every lane of a staged group writes a row (rows >= W are never
+  // read) and a group past the window (NPG is the next instantiated count) goes to a dump area, so neither request nor
+  // conversion carries a predicate.  (With a lane predicate the compiler wraps conversion + s_waitcnt in an `execz` skip;
+  // on that path the loads stay formally pending and the next write to their registers — at the loop top — becomes an
+  // s_waitcnt vmcnt(0) that also drains the tile's stores and the weight refills.  With a uniform `skip this group`
+  // branch around the loads, the phi copies of the loaded registers wait for each load right behind its issue.)
+  const int npg = (W + 63) >> 6;
+  const unsigned planeB = (unsigned)(npg * 64) * kRowB, groupB = 2 * planeB, bufB = (unsigned)GPU * groupB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = lane & 15, g = lane >> 4;
+  const int wr = wave % rt, wt = wave / rt;
+  const int tw0 = wt * kBT;
+  const int r0 = (blockIdx.y * rt + wr) * 16;
+  const int b = blockIdx.z;
+  const int rows = a.Cout * a.out_phases;
+  const int ngroups = (a.Cin + kCG3 - 1) / kCG3;
+  const int nchunks = ngroups * K;
+  const int upt = ngroups / GPU;                        // units per tile (launcher: GPU divides the channel-group count)
+  const int tin_eff = a.Tin * a.in_repeat;
+  const int ntile_rows = (rows + 15) / 16;
+  const int tile_first = blockIdx.x * tpw;
+  if (tile_first >= ntiles) return;
+  const int wtile = min(r0 / 16, ntile_rows - 1);       // a wave past the last row tile computes on a clamped tile and stores nothing
+  const u32x4* wph = reinterpret_cast<const u32x4*>(a.w) + (size_t)wtile * nchunks * 64 + lane;
+  const u32x4* wpl = reinterpret_cast<const u32x4*>(a.w_lo) + (size_t)wtile * nchunks * 64 + lane;
+  const float pre_neg = (a.pre_act == UA2_ACT_PRELU && a.pre_alpha) ? a.pre_alpha[0] : 1.f;   // launcher: pre_act is PReLU or none (slope 1)
+  const float* xbat = a.x + (size_t)b * a.Cin * a.Tin;
+  const unsigned hbytes = a.w2 ? (unsigned)(a.Cout / kCG3) * 2 * wgt * kRowB : 0u;   // fused unit: the h image sits behind the two x images
+  const unsigned rep_magic = a.in_repeat > 1 ? (unsigned)(0x100000000ull / (unsigned)a.in_repeat + 1) : 0u;   // ti / in_repeat = umulhi(ti, magic)
+
+  u32x4 wregh[CPU], wregl[CPU];
+#pragma unroll
+  for (int c = 0; c < CPU; ++c) { wregh[c] = wph[(size_t)c * 64]; wregl[c] = wpl[(size_t)c * 64]; }
+
+  float v0[SB], v1[SB];
+  auto request = [&](int tile, int ug) {                // clamped (always valid) addresses; padding is applied at conversion
+    const int in_start = tile * wgt * s - a.pad_left;
+    const int c0 = ug * GPU * kCG3 + 2 * PPW * wave;    // this wave's first channel
+#pragma unroll
+    for (int pg = 0; pg < NPG; ++pg) {
+      const int ti = min(max(in_start + lane + 64 * pg, 0), tin_eff - 1);
+      const int tsrc = rep_magic ? (int)__umulhi((unsigned)ti, rep_magic) : ti;
+#pragma unroll
+      for (int pi = 0; pi < PPW; ++pi) {
+        const float* row0 = xbat + (size_t)min(c0 + 2 * pi, a.Cin - 1) * a.Tin;
+        const float* row1 = xbat + (size_t)min(c0 + 2 * pi + 1, a.Cin - 1) * a.Tin;
+        v0[pg * PPW + pi] = row0[tsrc];
+        v1[pg * PPW + pi] = row1[tsrc];
+      }
+    }
+  };
+  auto commit = [&](char* buf, int tile, int ug) {      // zero padding, pre-activation, hi/lo split, LDS image
+    const int in_start = tile * wgt * s - a.pad_left;
+    const int c0 = ug * GPU * kCG3 + 2 * PPW * wave;
+    char* wbase = buf + (unsigned)((PPW * wave) >> 4) * groupB + ((PPW * wave) & 15) * 4;   // this wave's group image, first pair column
+    char* dump = smc + 2 * bufB + hbytes + ((PPW * wave) & 15) * 4;                            // [2 planes][64 rows] past the images
+#pragma unroll
+    for (int pg = 0; pg < NPG; ++pg) {
+      const int wi = lane + 64 * pg, ti = in_start + wi;
+      const bool pos_ok = ti >= 0 && ti < tin_eff;
+      const bool live = pg < npg;                       // uniform
+      char* dst = live ? wbase + (unsigned)wi * kRowB : dump + (unsigned)lane * kRowB;
+      const unsigned lo_off = live ? planeB : 64u * kRowB;
+#pragma unroll
+      for (int pi = 0; pi < PPW; ++pi) {
+        float x0 = (pos_ok && c0 + 2 * pi < a.Cin) ? v0[pg * PPW + pi] : 0.f;
+        float x1 = (pos_ok && c0 + 2 * pi + 1 < a.Cin) ? v1[pg * PPW + pi] : 0.f;
+        x0 = x0 >= 0.f ? x0 : pre_neg * x0;
+        x1 = x1 >= 0.f ? x1 : pre_neg * x1;
+        unsigned hi, lo;
+        split_pair(x0, x1, hi, lo);
+        *reinterpret_cast<unsigned*>(dst + pi * 4) = hi;
+        *reinterpret_cast<unsigned*>(dst + pi * 4 + lo_off) = lo;
+      }
+    }
+  };
+
+  f32x4 acc[NTT];
+  unsigned bofs[NTT];                                   // this lane's B-fragment offset per time tile, tap 0 of group 0
+#pragma unroll
+  for (int nt = 0; nt < NTT; ++nt) {
+    acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bofs[nt] = (unsigned)((tw0 + nt * 16 + tl) * s) * kRowB + g * 16;
+  }
+  const bool has_res = a.residual != nullptr;
+  const float* resp = has_res ? a.residual : a.x;       // branch-free residual: without one, a valid address and a zero select
+  // per-row epilogue constants, loaded once: left inside the tile epilogue the compiler schedules these loads into the
+  // MFMA phase and the (conditional) epilogue leaves them pending over the loop's back edge — a vmcnt(0) at the loop top
+  unsigned yo[4];                                       // launcher: B * Cout * Tout < 2^31
+  int ph[4];
+  float bias[4], alpha[4], bias2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = min(r0 + g * 4 + r, rows - 1);
+    const int phase = n / a.Cout, co = n - phase * a.Cout;
+    ph[r] = phase - a.out_trim_left;
+    yo[r] = (unsigned)((b * a.Cout + co) * a.Tout);
+    bias[r] = a.bias ? a.bias[co] : 0.f;
+    alpha[r] = (a.post_act == UA2_ACT_PRELU) ? a.post_alpha[a.post_alpha_n > 1 ? co : 0] : 1.f;   // launcher: PReLU or none (slope 1)
+    bias2[r] = (a.w2 && a.bias2) ? a.bias2[co] : 0.f;
+  }
+  const float alpha2 = (a.w2 && a.alpha2) ? a.alpha2[0] : 0.f;
+  const bool rows_ok = r0 + 16 <= rows;
+  // fused unit: the 1 x 1 conv's weights (C <= 64 here: at most two chunks per row tile), loaded once — requested inside the
+  // epilogue they were waited for on the spot, an L2 round trip per tile
+  u32x4 w2h[2], w2l[2];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg) {
+    w2h[cg] = u32x4{0u, 0u, 0u, 0u};
+    w2l[cg] = w2h[cg];
+    if (a.w2 && cg < a.Cout / kCG3) {
+      const size_t wo = ((size_t)(r0 / 16) * (a.Cout / kCG3) + cg) * 64 + lane;
+      w2h[cg] = reinterpret_cast<const u32x4*>(a.w2)[wo];
+      w2l[cg] = reinterpret_cast<const u32x4*>(a.w2_lo)[wo];
+    }
+  }
+
+  // Loop shape.  vmcnt retires in order, so what a wait costs is decided by what was issued BEFORE the thing waited for:
+  //   tile:  residual request (oldest of the tile)
+  //     unit:  barrier | x request of the next unit | MFMAs, each chunk refilled in place behind its last use |
+  //            conversion of the next unit (waits for its x only: the refills behind it stay in flight)
+  //   tile epilogue (stores; a fused residual unit adds LDS image + second GEMM)
+  // With one channel-group run per tile (UPT1: every layer at the 120 / 240 kHz rates) the whole body is straight-line
+  // and every count the compiler derives is exact.  Loads under a branch the compiler cannot see through — a conditional
+  // epilogue inside the unit loop, a predicated conversion, a skipped position group — each ended in an s_waitcnt vmcnt(0)
+  // somewhere in the loop during development, draining the prefetch this kernel exists for (profiles/r2_notes.md).
+  float resv[4][NTT];
+  auto request_residual = [&](int tile) {               // clamped addresses; without a residual a valid address and a zero select
+    const int t0 = tile * wgt + tw0 + tl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        const int to = min(max((t0 + nt * 16) * a.out_phases + ph[r], 0), a.Tout - 1);
+        resv[r][nt] = resp[has_res ? yo[r] + to : 0];
+      }
+  };
+  int u = 0;                                            // units done: parity = LDS image
+  auto unit = [&](int tile_n, int ug_n) {
+    ua2_lds_barrier();
+    const char* xb = smc + (unsigned)(u & 1) * bufB;
+    request(tile_n, ug_n);
+    const size_t chunk_n = (size_t)ug_n * CPU;
+#pragma unroll
+    for (int c = 0; c < CPU; ++c) {
+      const unsigned cofs = (unsigned)(c / K) * groupB + (unsigned)((c % K) * d) * kRowB;   // group image, tap
+      bf16x8 bh[NTT], bl[NTT];
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        const char* src = xb + cofs + bofs[nt];
+        bh[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src));
+        bl[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + planeB));
+      }
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, wregh[c]), al = __builtin_bit_cast(bf16x8, wregl[c]);
+      // per accumulator the order is al*bh, ah*bl, ah*bh (small terms first, as in conv1d_x3_kernel); across accumulators
+      // the MFMAs interleave so that back-to-back issues are independent
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
+      wregh[c] = wph[(chunk_n + c) * 64];               // refill in place: first needed one unit from now
+      wregl[c] = wpl[(chunk_n + c) * 64];
+    }
+    commit(smc + (unsigned)((u + 1) & 1) * bufB, tile_n, ug_n);
+    ++u;
+  };
+  auto epilogue = [&](int tile) {                       // D[row = g*4 + r][col = tl]
+    const int t0 = tile * wgt + tw0 + tl;
+    const bool interior = rows_ok && a.out_phases == 1 && a.out_trim_left == 0 && tile * wgt + wgt <= a.Tout;   // no store needs a mask
+    f32x4 res[NTT];
+    if (a.w2) {   // fused residual unit (scalar24k.py:143-151), see conv1d_x3_kernel: h -> LDS image -> 1 x 1 conv -> PReLU -> + x
+      const int ng2 = a.Cout / kCG3;
+      char* hbase = smc + 2 * bufB;                                       // [ng2][2 planes][wgt][kRowB]
+      const unsigned hplane = (unsigned)wgt * kRowB;
+      const int nb = r0 + g * 4;
+      char* hdst = hbase + (unsigned)(nb / kCG3) * 2 * hplane + (unsigned)(tw0 + tl) * kRowB + (nb % kCG3) * 2;
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) {
+        float hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[nt][r] + bias[r];
+          hv[r] = t >= 0.f ? t : alpha[r] * t;
+        }
+        unsigned h01, l01, h23, l23;
+        split_pair(hv[0], hv[1], h01, l01);
+        split_pair(hv[2], hv[3], h23, l23);
+        *reinterpret_cast<uint2*>(hdst + nt * 16 * kRowB) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(hdst + nt * 16 * kRowB + hplane) = make_uint2(l01, l23);
+      }
+      ua2_lds_barrier();
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt) res[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        if (cg >= ng2) break;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, w2h[cg]), al = __builtin_bit_cast(bf16x8, w2l[cg]);
+        bf16x8 bh[NTT], bl[NTT];
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+          const char* src = hbase + (unsigned)cg * 2 * hplane + (unsigned)(tw0 + nt * 16 + tl) * kRowB + g * 16;
+          bh[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src));
+          bl[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + hplane));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) res[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], res[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) res[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], res[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) res[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], res[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = res[nt][r] + bias2[r];
+          res[nt][r] = v >= 0.f ? v : alpha2 * v;
+        }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[nt][r] + bias[r];
+          res[nt][r] = v >= 0.f ? v : alpha[r] * v;
+        }
+    }
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) a.y[yo[r] + t0 + nt * 16] = res[nt][r] + (has_res ? resv[r][nt] : 0.f);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+          const int to = (t0 + nt * 16) * a.out_phases + ph[r];
+          if (r0 + g * 4 + r < rows && to >= 0 && to < a.Tout) a.y[yo[r] + to] = res[nt][r] + (has_res ? resv[r][nt] : 0.f);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  const int my_tiles = min(tpw, ntiles - tile_first);
+  request(tile_first, 0);
+  commit(smc, tile_first, 0);
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int tile = tile_first + ti;
+    const int tile_nx = ti + 1 < my_tiles ? tile + 1 : tile;   // past the last tile: the last unit again, into the idle image
+    request_residual(tile);
+    if constexpr (UPT1) {
+      unit(tile_nx, 0);
+    } else {
+      for (int ug = 0; ug + 1 < upt; ++ug) unit(tile, ug + 1);
+      unit(tile_nx, ti + 1 < my_tiles ? 0 : upt - 1);
+    }
+    epilogue(tile);
+  }
+}
+
+template <int NTT, int CPU, int GPU, int NPG>
+void launch_x3p(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, int tpw, int ntiles, bool upt1, hipStream_t s) {
+  constexpr auto k1 = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, true>;
+  constexpr auto kn = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, false>;
+  if (upt1) {
+    ua2_allow_big_lds<k1>();
+    hipLaunchKernelGGL(k1, grid, dim3(256), smem, s, a, rt, tpw, ntiles);
+  } else {
+    ua2_allow_big_lds<kn>();
+    hipLaunchKernelGGL(kn, grid, dim3(256), smem, s, a, rt, tpw, ntiles);
+  }
+}
+
 template <int NTT, int RPW>
 void launch_x3(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, hipStream_t s) {
   constexpr auto kern = conv1d_x3_kernel<NTT, RPW>;
@@ -451,14 +785,102 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
     a = &dbg_args;
     UA2_CHECK(a->w_lo != nullptr, "ua2_conv1d: precision 1 (bf16 x 3) needs w_lo (ua2 host helper pack_conv_weight_x3)");
     const int rows = a->Cout * a->out_phases;
-    const int rpw = rows > 16 ? 2 : 1;                                   // row tiles per wave
-    const int wave_rows = 16 * rpw;
-    const int rt = rows > 2 * wave_rows ? 4 : (rows > wave_rows ? 2 : 1);  // wave row-groups per workgroup; the other waves split time
+    int rpw = rows > 16 ? 2 : 1;                                   // row tiles per wave
+    int wave_rows = 16 * rpw;
+    int rt = rows > 2 * wave_rows ? 4 : (rows > wave_rows ? 2 : 1);  // wave row-groups per workgroup; the other waves split time
+    int ntt_force = 0;
+    if (const char* e = getenv("UA2_CONV_TILE")) {                       // experiment hook: "ntt,rpw,rt"
+      int v[3] = {0, 0, 0};
+      if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && !a->w2) { ntt_force = v[0]; rpw = v[1]; rt = v[2]; wave_rows = 16 * rpw; }
+    }
     const int row_blocks3 = ua2_ceil_div(rows, wave_rows * rt);
     if (a->w2) {   // fused residual unit: one workgroup must hold every output channel of its time tile
       UA2_CHECK(a->w2_lo && a->residual && a->out_phases == 1 && a->stride == 1 && a->in_repeat == 1 && a->Cin == a->Cout &&
                     (a->Cout == 32 || a->Cout == 64 || a->Cout == 128) && row_blocks3 == 1 && a->Tin == a->Tout,
                 "ua2_conv1d: the fused residual unit needs Cin == Cout in {32, 64, 128}, stride 1, Tin == Tout, w2_lo and residual");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // ---- software-pipelined kernel whenever a unit's weights and window fit its register budget ----
+    {
+      int p_rt = rows > 32 ? 4 : (rows > 16 ? 2 : 1), p_ntt = 0, p_tpw = 0, p_gpu = 0;
+      if (const char* e = getenv("UA2_CONV_PIPE")) {                     // experiment hook: "ntt,rt,tpw,gpu" (0 = automatic) or "off"
+        int v[4] = {0, 0, 0, 0};
+        if (!strcmp(e, "off")) p_ntt = -1;
+        else if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) {
+          p_ntt = v[0]; p_tpw = v[2]; p_gpu = v[3];
+          if (!a->w2 && v[1]) p_rt = v[1];
+        }
+      }
+      const int p_rb = ua2_ceil_div(rows, 16 * p_rt);
+      const int ngroups = ua2_ceil_div(a->Cin, kCG3);
+      // instantiated (K, gpu) pairs and position-group counts; a window needing fewer groups than the next instantiated
+      // count sends the excess to a dump area (10 KB)
+      auto npg_inst = [&](int gp, int need) {
+        if (a->K == 7) return need <= 3 ? need : 0;
+        if (gp == 1) return need <= 2 ? 2 : (need <= 4 ? 4 : 0);
+        if (gp == 2) return need <= 2 ? need : 0;
+        return need == 1 ? 1 : 0;
+      };
+      auto lds_of = [&](int n, int gp) {
+        const int wg = 16 * n * (4 / p_rt);
+        const int64_t Wn = (int64_t)(wg - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+        const int need = (int)((Wn + 63) / 64), inst = npg_inst(gp, need);
+        return 4 * gp * (int64_t)need * 64 * kRowB + (a->w2 ? (int64_t)(a->Cout / 32) * 2 * wg * kRowB : 0) + (inst > need ? 2 * 64 * kRowB : 0);
+      };
+      auto fits = [&](int n, int gp) {
+        const bool inst = (a->K == 7 && gp == 1) || ((a->K == 1 || a->K == 2) && (gp == 1 || gp == 2 || gp == 4));
+        if (!inst || ngroups % gp) return false;
+        const int wg = 16 * n * (4 / p_rt);
+        const int64_t Wn = (int64_t)(wg - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+        return npg_inst(gp, (int)((Wn + 63) / 64)) > 0 && lds_of(n, gp) <= 80 * 1024;
+      };
+      const bool slope_acts = (a->pre_act == UA2_ACT_NONE || a->pre_act == UA2_ACT_PRELU) && (a->post_act == UA2_ACT_NONE || a->post_act == UA2_ACT_PRELU);
+      const bool small_index = (int64_t)a->B * a->Cin * a->Tin < (1ll << 31) && (int64_t)a->B * a->Cout * a->Tout < (1ll << 31) &&
+                               (int64_t)a->Tin * a->in_repeat * a->in_repeat < (1ll << 32);
+      int ntt = 4;
+      if (p_ntt > 0) ntt = p_ntt;
+      else {
+        while (ntt > 1 && !fits(ntt, 1)) ntt >>= 1;
+        while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / p_rt)) * p_rb * a->B < 256) ntt >>= 1;
+      }
+      if (p_ntt >= 0 && slope_acts && small_index && fits(ntt, 1) && (!a->w2 || p_rb == 1)) {
+        int gpu = 1;
+        for (int gp = 2; gp <= ngroups && gp <= 4; ++gp)
+          if (fits(ntt, gp)) gpu = gp;
+        if (p_gpu > 0 && fits(ntt, p_gpu)) gpu = p_gpu;
+        const int wgt = 16 * ntt * (4 / p_rt);
+        const int ntiles = ua2_ceil_div(tq, wgt);
+        const int64_t total = (int64_t)ntiles * p_rb * a->B;
+        int tpw = (int)std::min<int64_t>(8, std::max<int64_t>(1, total / 1024));
+        if (p_tpw > 0) tpw = p_tpw;
+        const int64_t Wn = (int64_t)(wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+        const size_t smem = (size_t)lds_of(ntt, gpu);
+        const int npgi = npg_inst(gpu, (int)((Wn + 63) / 64));
+        const dim3 grid(ua2_ceil_div(ntiles, tpw), p_rb, a->B);
+        const int cpu = gpu * a->K;
+#define UA2_X3P(N, C, G, P) launch_x3p<N, C, G, P>(*a, grid, smem, p_rt, tpw, ntiles, ngroups == gpu, st)
+#define UA2_X3P_N(C, G, P) (ntt == 4 ? UA2_X3P(4, C, G, P) : ntt == 2 ? UA2_X3P(2, C, G, P) : UA2_X3P(1, C, G, P))
+        switch ((cpu * 8 + gpu) * 8 + npgi) {
+          case (7 * 8 + 1) * 8 + 1: UA2_X3P_N(7, 1, 1); break;
+          case (7 * 8 + 1) * 8 + 2: UA2_X3P_N(7, 1, 2); break;
+          case (7 * 8 + 1) * 8 + 3: UA2_X3P_N(7, 1, 3); break;
+          case (1 * 8 + 1) * 8 + 2: UA2_X3P_N(1, 1, 2); break;
+          case (1 * 8 + 1) * 8 + 4: UA2_X3P_N(1, 1, 4); break;
+          case (2 * 8 + 1) * 8 + 2: UA2_X3P_N(2, 1, 2); break;
+          case (2 * 8 + 1) * 8 + 4: UA2_X3P_N(2, 1, 4); break;
+          case (2 * 8 + 2) * 8 + 1: UA2_X3P_N(2, 2, 1); break;
+          case (2 * 8 + 2) * 8 + 2: UA2_X3P_N(2, 2, 2); break;
+          case (4 * 8 + 2) * 8 + 1: UA2_X3P_N(4, 2, 1); break;
+          case (4 * 8 + 2) * 8 + 2: UA2_X3P_N(4, 2, 2); break;
+          case (4 * 8 + 4) * 8 + 1: UA2_X3P_N(4, 4, 1); break;
+          case (8 * 8 + 4) * 8 + 1: UA2_X3P_N(8, 4, 1); break;
+          default: UA2_CHECK(false, "ua2_conv1d: no pipelined instantiation for K=%d gpu=%d npg=%d", a->K, gpu, npgi);
+        }
+#undef UA2_X3P_N
+#undef UA2_X3P
+        UA2_LAUNCH_CHECK();
+        return 0;
+      }
     }
     int ntt = 4;
     while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / rt)) * row_blocks3 * a->B < 512) ntt >>= 1;
@@ -467,12 +889,12 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
       return (size_t)2 * ((wg - 1) * a->stride + (a->K - 1) * a->dilation + 1) * kRowB + (a->w2 ? (size_t)(a->Cout / 32) * 2 * wg * kRowB : 0);
     };
     while (ntt > 1 && lds_bytes(ntt) > 52 * 1024) ntt >>= 1;            // keep three workgroups per CU resident (latency hiding beats tile size here)
+    if (ntt_force) ntt = ntt_force;
     const int wgt = 16 * ntt * (4 / rt);
     const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
     const size_t smem3 = lds_bytes(ntt);
     UA2_CHECK(smem3 <= 150 * 1024, "ua2_conv1d: window too large (%zu B LDS)", smem3);
     const dim3 grid3(ua2_ceil_div(tq, wgt), row_blocks3, a->B);
-    hipStream_t st = (hipStream_t)stream;
     if (rpw == 2) {
       if (ntt == 4) launch_x3<4, 2>(*a, grid3, smem3, rt, st);
       else if (ntt == 2) launch_x3<2, 2>(*a, grid3, smem3, rt, st);
