@@ -418,14 +418,14 @@ constexpr int kKC = 8;         // most weight chunks (tap x channel group) a uni
 // The unit loop is straight-line on purpose — the request for the unit after the last one is clamped onto the last, its
 // conversion lands in the idle LDS image — so that the s_waitcnt the compiler places in front of the conversion counts
 // exactly the weight refills issued behind the x loads, and nothing pending crosses the loop's back edge except those.
-template <int NTT, int CPU, int GPU, int NPG, bool UPT1>
-__global__ __launch_bounds__(256, 2) void conv1d_x3p_kernel(const ua2_conv1d_args a, const int rt, const int tpw, const int ntiles) {
+template <int NTT, int CPU, int GPU, int NPG, bool UPT1, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(const ua2_conv1d_args a, const int rt, const int tpw, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
   constexpr int K = CPU / GPU;
-  constexpr int PPW = 4 * GPU;                          // channel pairs per wave
+  constexpr int PPW = 16 * GPU / NW;                    // channel pairs per wave (NW = 4 waves, or 8 for the fused 128-channel unit)
   constexpr int SB = PPW * NPG;                         // NPG position groups of 64 staged per unit (launcher: W <= 64 * NPG)
   const int s = a.stride, d = a.dilation;
-  const int tsub = 4 / rt;
+  const int tsub = NW / rt;
   constexpr int kBT = 16 * NTT;
   const int wgt = kBT * tsub;
   const int W = (wgt - 1) * s + (K - 1) * d + 1;
@@ -533,11 +533,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3p_kernel(const ua2_conv1d_arg
   }
   const float alpha2 = (a.w2 && a.alpha2) ? a.alpha2[0] : 0.f;
   const bool rows_ok = r0 + 16 <= rows;
-  // fused unit: the 1 x 1 conv's weights (C <= 64 here: at most two chunks per row tile), loaded once — requested inside the
+  // fused unit: the 1 x 1 conv's weights (C <= 64 with 4 waves, 128 with 8: at most kNG2 chunks per row tile), loaded once — requested inside the
   // epilogue they were waited for on the spot, an L2 round trip per tile
-  u32x4 w2h[2], w2l[2];
+  constexpr int kNG2 = NW == 8 ? 4 : 2;
+  u32x4 w2h[kNG2], w2l[kNG2];
 #pragma unroll
-  for (int cg = 0; cg < 2; ++cg) {
+  for (int cg = 0; cg < kNG2; ++cg) {
     w2h[cg] = u32x4{0u, 0u, 0u, 0u};
     w2l[cg] = w2h[cg];
     if (a.w2 && cg < a.Cout / kCG3) {
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3p_kernel(const ua2_conv1d_arg
 #pragma unroll
       for (int nt = 0; nt < NTT; ++nt) res[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int cg = 0; cg < 2; ++cg) {
+      for (int cg = 0; cg < kNG2; ++cg) {
         if (cg >= ng2) break;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, w2h[cg]), al = __builtin_bit_cast(bf16x8, w2l[cg]);
         bf16x8 bh[NTT], bl[NTT];
@@ -694,16 +695,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3p_kernel(const ua2_conv1d_arg
   }
 }
 
-template <int NTT, int CPU, int GPU, int NPG>
+template <int NTT, int CPU, int GPU, int NPG, int NW = 4>
 void launch_x3p(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, int tpw, int ntiles, bool upt1, hipStream_t s) {
-  constexpr auto k1 = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, true>;
-  constexpr auto kn = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, false>;
+  constexpr auto k1 = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, true, NW>;
+  constexpr auto kn = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, false, NW>;
   if (upt1) {
     ua2_allow_big_lds<k1>();
-    hipLaunchKernelGGL(k1, grid, dim3(256), smem, s, a, rt, tpw, ntiles);
+    hipLaunchKernelGGL(k1, grid, dim3(64 * NW), smem, s, a, rt, tpw, ntiles);
   } else {
     ua2_allow_big_lds<kn>();
-    hipLaunchKernelGGL(kn, grid, dim3(256), smem, s, a, rt, tpw, ntiles);
+    hipLaunchKernelGGL(kn, grid, dim3(64 * NW), smem, s, a, rt, tpw, ntiles);
   }
 }
 
@@ -802,7 +803,8 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // ---- software-pipelined kernel whenever a unit's weights and window fit its register budget ----
     {
-      int p_rt = rows > 32 ? 4 : (rows > 16 ? 2 : 1), p_ntt = 0, p_tpw = 0, p_gpu = 0;
+      const int nw = (a->w2 && rows == 128) ? 8 : 4;                     // the fused 128-channel unit: 8 waves hold its 8 row tiles
+      int p_rt = rows > 64 && nw == 8 ? 8 : (rows > 32 ? 4 : (rows > 16 ? 2 : 1)), p_ntt = 0, p_tpw = 0, p_gpu = 0;
       if (const char* e = getenv("UA2_CONV_PIPE")) {                     // experiment hook: "ntt,rt,tpw,gpu" (0 = automatic) or "off"
         int v[4] = {0, 0, 0, 0};
         if (!strcmp(e, "off")) p_ntt = -1;
@@ -822,7 +824,7 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
         return need == 1 ? 1 : 0;
       };
       auto lds_of = [&](int n, int gp) {
-        const int wg = 16 * n * (4 / p_rt);
+        const int wg = 16 * n * (nw / p_rt);
         const int64_t Wn = (int64_t)(wg - 1) * a->stride + (a->K - 1) * a->dilation + 1;
         const int need = (int)((Wn + 63) / 64), inst = npg_inst(gp, need);
         return 4 * gp * (int64_t)need * 64 * kRowB + (a->w2 ? (int64_t)(a->Cout / 32) * 2 * wg * kRowB : 0) + (inst > need ? 2 * 64 * kRowB : 0);
@@ -830,9 +832,9 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
       auto fits = [&](int n, int gp) {
         const bool inst = (a->K == 7 && gp == 1) || ((a->K == 1 || a->K == 2) && (gp == 1 || gp == 2 || gp == 4));
         if (!inst || ngroups % gp) return false;
-        const int wg = 16 * n * (4 / p_rt);
+        const int wg = 16 * n * (nw / p_rt);
         const int64_t Wn = (int64_t)(wg - 1) * a->stride + (a->K - 1) * a->dilation + 1;
-        return npg_inst(gp, (int)((Wn + 63) / 64)) > 0 && lds_of(n, gp) <= 80 * 1024;
+        return npg_inst(gp, (int)((Wn + 63) / 64)) > 0 && lds_of(n, gp) <= (nw == 8 ? 150 : 80) * 1024;   // two workgroups per CU (one of 8 waves)
       };
       const bool slope_acts = (a->pre_act == UA2_ACT_NONE || a->pre_act == UA2_ACT_PRELU) && (a->post_act == UA2_ACT_NONE || a->post_act == UA2_ACT_PRELU);
       const bool small_index = (int64_t)a->B * a->Cin * a->Tin < (1ll << 31) && (int64_t)a->B * a->Cout * a->Tout < (1ll << 31) &&
@@ -841,17 +843,22 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
       if (p_ntt > 0) ntt = p_ntt;
       else {
         while (ntt > 1 && !fits(ntt, 1)) ntt >>= 1;
-        while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (4 / p_rt)) * p_rb * a->B < 256) ntt >>= 1;
+        while (ntt > 1 && (int64_t)ua2_ceil_div(tq, 16 * ntt * (nw / p_rt)) * p_rb * a->B < 256) ntt >>= 1;
       }
-      if (p_ntt >= 0 && slope_acts && small_index && fits(ntt, 1) && (!a->w2 || p_rb == 1)) {
+      const int64_t W0 = (int64_t)(16 * ntt * (nw / p_rt) - 1) * a->stride + (a->K - 1) * a->dilation + 1;
+      const bool nw_ok = nw == 4 || (ntt == 4 && a->K == 7 && (W0 + 63) / 64 == 2);    // the one 8-wave instantiation
+      if (p_ntt >= 0 && slope_acts && small_index && nw_ok && fits(ntt, 1) && (!a->w2 || p_rb == 1)) {
         int gpu = 1;
         for (int gp = 2; gp <= ngroups && gp <= 4; ++gp)
           if (fits(ntt, gp)) gpu = gp;
         if (p_gpu > 0 && fits(ntt, p_gpu)) gpu = p_gpu;
-        const int wgt = 16 * ntt * (4 / p_rt);
+        const int wgt = 16 * ntt * (nw / p_rt);
         const int ntiles = ua2_ceil_div(tq, wgt);
         const int64_t total = (int64_t)ntiles * p_rb * a->B;
-        int tpw = (int)std::min<int64_t>(8, std::max<int64_t>(1, total / 1024));
+        // consecutive tiles per workgroup: one resident round (2 workgroups per CU) where the layer is long enough — a
+        // workgroup's first window is the only one nothing hides (measured on the 120 / 240 kHz layers: 43 -> 35, 33 -> 24.5 us)
+        const int slots = nw == 8 ? 256 : 512;
+        int tpw = (int)std::min<int64_t>(8, std::max<int64_t>(1, (total + slots - 1) / slots));
         if (p_tpw > 0) tpw = p_tpw;
         const int64_t Wn = (int64_t)(wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
         const size_t smem = (size_t)lds_of(ntt, gpu);
@@ -860,6 +867,10 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
         const int cpu = gpu * a->K;
 #define UA2_X3P(N, C, G, P) launch_x3p<N, C, G, P>(*a, grid, smem, p_rt, tpw, ntiles, ngroups == gpu, st)
 #define UA2_X3P_N(C, G, P) (ntt == 4 ? UA2_X3P(4, C, G, P) : ntt == 2 ? UA2_X3P(2, C, G, P) : UA2_X3P(1, C, G, P))
+        if (nw == 8) {
+          UA2_CHECK(ntt == 4 && cpu == 7 && npgi == 2, "ua2_conv1d: fused 128-channel unit outside its instantiation (ntt=%d K=%d npg=%d)", ntt, a->K, npgi);
+          launch_x3p<4, 7, 1, 2, 8>(*a, grid, smem, p_rt, tpw, ntiles, false, st);
+        } else
         switch ((cpu * 8 + gpu) * 8 + npgi) {
           case (7 * 8 + 1) * 8 + 1: UA2_X3P_N(7, 1, 1); break;
           case (7 * 8 + 1) * 8 + 2: UA2_X3P_N(7, 1, 2); break;
