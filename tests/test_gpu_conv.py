@@ -210,3 +210,44 @@ def test_fused_residual_unit_matches_torch(C, dil, T):
     hh = ops.conv1d(xc, w1h, 7, C, dilation=dil, pad_left=dil * 6, Tout=T, bias=b1.cuda(), post_act=ACT_PRELU, post_alpha=a1.cuda(), w_lo=w1l)
     y2 = ops.conv1d(hh, w2h, 1, C, Tout=T, bias=b2.cuda(), post_act=ACT_PRELU, post_alpha=a2.cuda(), residual=xc, w_lo=w2l)
     _close(y, y2.cpu(), tol=1e-5)
+
+
+PIPE_CASES = [
+    # Cin, Cout, K, dil, T, residual, fused, in_repeat: every (K, channel-group run, position-group) instantiation family of the
+    # pipelined kernel, windows that end inside a tile, ragged channel counts, one and many units per tile
+    (32, 32, 7, 9, 1000, True, True, 1), (64, 64, 7, 1, 4097, True, True, 1), (128, 128, 7, 5, 700, True, True, 1),
+    (512, 512, 7, 3, 150, False, False, 1), (256, 256, 1, 1, 777, True, False, 1), (17, 19, 7, 3, 70, False, False, 1),
+    (48, 40, 1, 1, 333, True, False, 1), (64, 32, 7, 1, 2049, False, False, 2), (1, 32, 7, 1, 5000, False, False, 1),
+    (136, 512, 7, 1, 100, False, False, 1), (32, 32, 7, 7, 24000, True, True, 1), (128, 64, 2, 1, 513, False, False, 1),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,K,dil,T,residual,fused,rep", PIPE_CASES)
+def test_pipelined_conv_kernel_is_bit_identical_to_plain(Cin, Cout, K, dil, T, residual, fused, rep, monkeypatch):
+    """conv1d_x3p_kernel (software-pipelined: x window one unit ahead in registers, weights refilled in place, hardware
+    bf16 pack conversion) against conv1d_x3_kernel (UA2_CONV_PIPE=off): same split, same products, same summation order —
+    torch.equal, not a tolerance."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import ACT_PRELU
+    g = torch.Generator().manual_seed(Cin * 3 + K + dil)
+    x = torch.randn(2, Cin, T, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5).cuda()
+    hi, lo = ops.pack_conv_weight_x3(w)
+    b = torch.randn(Cout, generator=g).cuda()
+    a1, a0 = torch.tensor([0.2]).cuda(), torch.tensor([0.1]).cuda()
+    Tout = T * rep
+    kw = dict(dilation=dil, pad_left=dil * (K - 1), Tout=Tout, bias=b, pre_act=ACT_PRELU, pre_alpha=a0, post_act=ACT_PRELU, post_alpha=a1,
+              w_lo=lo, in_repeat=rep)
+    if fused:
+        w2 = (torch.randn(Cout, Cout, 1, generator=g) / Cout ** 0.5).cuda()
+        w2h, w2l = ops.pack_conv_weight_x3(w2)
+        kw.update(residual=x, fused2=(w2h, w2l, torch.randn(Cout, generator=g).cuda(), torch.tensor([0.3]).cuda()))
+    elif residual:
+        kw.update(residual=torch.randn(2, Cout, Tout, generator=g).cuda())
+    monkeypatch.setenv("UA2_CONV_PIPE", "off")
+    ref = ops.conv1d(x, hi, K, Cout, **kw)
+    monkeypatch.delenv("UA2_CONV_PIPE")
+    got = ops.conv1d(x, hi, K, Cout, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref), f"max diff {(got - ref).abs().max().item():.3e}"

@@ -176,7 +176,6 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
   }
   const float pre_alpha = (a.pre_act == UA2_ACT_PRELU && a.pre_alpha) ? a.pre_alpha[0] : 0.f;
   const int in_start = t0 * s - a.pad_left;
-  const int dbg = a.precision >> 8;      // experiment hook (UA2_CONV_DBG): 1 no MFMAs, 2 no global loads, 4 no stores, 8 no LDS image writes
 
   f32x4 acc[RPW][NTT];
 #pragma unroll
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
         pp[u] = p; ww[u] = wi;
         v0[u] = 0.f; v1[u] = 0.f;
         const int ci = cg * kCG3 + 2 * p, ti = in_start + wi;
-        if (p < kCG3 / 2 && ti >= 0 && ti < tin_eff && !(dbg & 2)) {
+        if (p < kCG3 / 2 && ti >= 0 && ti < tin_eff) {
           const int tsrc = (a.in_repeat == 1) ? ti : (a.in_repeat == 2 ? (ti >> 1) : ti / a.in_repeat);
           const size_t off = ((size_t)b * a.Cin + ci) * a.Tin + tsrc;
           if (ci < a.Cin) v0[u] = a.x[off];
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
       }
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
-        if (pp[u] < kCG3 / 2 && !(dbg & 8)) {
+        if (pp[u] < kCG3 / 2) {
           const float x0 = apply_act(v0[u], a.pre_act, pre_alpha), x1 = apply_act(v1[u], a.pre_act, pre_alpha);   // act(0) = 0 for every pre-activation
           const unsigned h0 = f2bf(x0), h1 = f2bf(x1);
           const unsigned l0 = f2bf(x0 - bf2f((unsigned short)h0)), l1 = f2bf(x1 - bf2f((unsigned short)h1));
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
       }
     }
     __syncthreads();
-    if (wave_active && !(dbg & 1)) {
+    if (wave_active) {
       for (int j = 0; j < K; ++j) {
         const int chunk = cg * K + j;
         bf16x8 ah[RPW], al[RPW];
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
           const size_t o = ((size_t)b * C + n) * a.Tout + t;
           float v = acc2[q][nt][r] + b2;
           v = v >= 0.f ? v : alpha2 * v;
-          if (!(dbg & 4)) a.y[o] = v + resv[q][r][nt];
+          a.y[o] = v + resv[q][r][nt];
         }
       }
     return;
@@ -368,7 +367,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
         float v = acc[q][nt][r] + bias;
         v = apply_act(v, a.post_act, alpha);
         const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
-        if (!(dbg & 4)) a.y[o] = v + resv[q][r][nt];
+        a.y[o] = v + resv[q][r][nt];
       }
     }
   }
@@ -779,21 +778,12 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
   UA2_CHECK(a->out_phases == 1 || (a->stride == 1 && a->dilation == 1), "ua2_conv1d: phase mode needs stride=dilation=1");
   UA2_CHECK(a->post_act != UA2_ACT_PRELU || a->post_alpha, "ua2_conv1d: PReLU needs post_alpha");
   const int tq = a->out_phases == 1 ? a->Tout : ua2_ceil_div(a->Tout + a->out_trim_left, a->out_phases);
-  if ((a->precision & 0xff) == 1) {
-    static const int dbg_bits = getenv("UA2_CONV_DBG") ? atoi(getenv("UA2_CONV_DBG")) : 0;   // experiment hook: see the kernel
-    ua2_conv1d_args dbg_args = *a;
-    dbg_args.precision = 1 | (dbg_bits << 8);
-    a = &dbg_args;
+  if (a->precision == 1) {
     UA2_CHECK(a->w_lo != nullptr, "ua2_conv1d: precision 1 (bf16 x 3) needs w_lo (ua2 host helper pack_conv_weight_x3)");
     const int rows = a->Cout * a->out_phases;
-    int rpw = rows > 16 ? 2 : 1;                                   // row tiles per wave
-    int wave_rows = 16 * rpw;
-    int rt = rows > 2 * wave_rows ? 4 : (rows > wave_rows ? 2 : 1);  // wave row-groups per workgroup; the other waves split time
-    int ntt_force = 0;
-    if (const char* e = getenv("UA2_CONV_TILE")) {                       // experiment hook: "ntt,rpw,rt"
-      int v[3] = {0, 0, 0};
-      if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && !a->w2) { ntt_force = v[0]; rpw = v[1]; rt = v[2]; wave_rows = 16 * rpw; }
-    }
+    const int rpw = rows > 16 ? 2 : 1;                                   // row tiles per wave
+    const int wave_rows = 16 * rpw;
+    const int rt = rows > 2 * wave_rows ? 4 : (rows > wave_rows ? 2 : 1);  // wave row-groups per workgroup; the other waves split time
     const int row_blocks3 = ua2_ceil_div(rows, wave_rows * rt);
     if (a->w2) {   // fused residual unit: one workgroup must hold every output channel of its time tile
       UA2_CHECK(a->w2_lo && a->residual && a->out_phases == 1 && a->stride == 1 && a->in_repeat == 1 && a->Cin == a->Cout &&
@@ -900,7 +890,6 @@ extern "C" int ua2_conv1d(const ua2_conv1d_args* a, void* stream) {
       return (size_t)2 * ((wg - 1) * a->stride + (a->K - 1) * a->dilation + 1) * kRowB + (a->w2 ? (size_t)(a->Cout / 32) * 2 * wg * kRowB : 0);
     };
     while (ntt > 1 && lds_bytes(ntt) > 52 * 1024) ntt >>= 1;            // keep three workgroups per CU resident (latency hiding beats tile size here)
-    if (ntt_force) ntt = ntt_force;
     const int wgt = 16 * ntt * (4 / rt);
     const int W3 = (wgt - 1) * a->stride + (a->K - 1) * a->dilation + 1;
     const size_t smem3 = lds_bytes(ntt);

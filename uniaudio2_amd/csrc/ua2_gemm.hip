@@ -219,15 +219,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   commit(0, stg0);
   if (nstages > 1) fetch(stg0, 1);
   if (nstages > 2) fetch(stg1, 2);
-  __syncthreads();
+  // ua2_lds_barrier, not __syncthreads(): in front of an s_barrier it can see, the compiler drains vmcnt to 0 — with it
+  // the two register staging sets never had more than one stage of MFMAs to cover a memory round trip
+  ua2_lds_barrier();
   for (int s = 0; s < nstages; s += 2) {
     compute(0, s);                               // even stage: lds[0]; stg0 = stage s+1, stg1 = stage s+2
     if (s + 1 < nstages) commit(1, stg0);
-    __syncthreads();
+    ua2_lds_barrier();
     if (s + 3 < nstages) fetch(stg0, s + 3);
     if (s + 1 < nstages) compute(1, s + 1);      // odd stage: lds[1]
     if (s + 2 < nstages) commit(0, stg1);
-    __syncthreads();
+    ua2_lds_barrier();
     if (s + 4 < nstages) fetch(stg1, s + 4);
   }
   while (seg <= nw) { retire(); ++seg; }         // the last range (and any empty ones after it)
