@@ -2,6 +2,8 @@
 other rows share the launch (rows per workgroup and launch geometry are functions of N, K and the
 dtype only; per-row statistics are reduced in one fixed order).  Bit-exact comparisons of M = 1 launches against
 the same rows inside M = 2, 5, 16, 17 and 40-row launches."""
+import os
+
 import pytest
 import torch
 
@@ -56,10 +58,16 @@ def linear_mode():
     """ua2_debug_force_general_linear: 2 = row-tiled decode kernel only, 4 / 5 = skinny / tiled large-M kernel."""
     from uniaudio2_amd._lib import lib
 
-    def set_mode(m):
+    def set_mode(m, bmt=None):
+        """bmt: row tiles per workgroup of the tiled kernel (UA2_GEMM_BMT: 8 = 128 x 128 tile, 4 = 64 x 128), None = its own choice."""
         lib.ua2_debug_force_general_linear(m)
+        if bmt is None:
+            os.environ.pop("UA2_GEMM_BMT", None)
+        else:
+            os.environ["UA2_GEMM_BMT"] = str(bmt)
     yield set_mode
     lib.ua2_debug_force_general_linear(0)
+    os.environ.pop("UA2_GEMM_BMT", None)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -105,11 +113,11 @@ def test_large_m_kernel_is_bit_identical_to_the_decode_kernel(dtype, N, K, linea
         for M in (1, 5, 40, 130, 300):
             linear_mode(2)
             ref = run(M, pro, epi, nk)
-            for mode in (4, 5):             # skinny form, 128-row tiled form
-                linear_mode(mode)
+            for mode, bmt in ((4, None), (5, 8), (5, 4)):     # skinny form, 128 x 128 tiled form, 64 x 128 tiled form
+                linear_mode(mode, bmt)
                 got = run(M, pro, epi, nk)
                 for r, o, name in zip(ref, got, ("y", "part_max", "part_idx")):
-                    assert torch.equal(r, o), (pro, epi, nk, M, mode, name, (r.float() - o.float()).abs().max().item())
+                    assert torch.equal(r, o), (pro, epi, nk, M, mode, bmt, name, (r.float() - o.float()).abs().max().item())
         linear_mode(0)                      # the launcher's own choice (cost model between the two forms)
         got = run(300, pro, epi, nk)
         for r, o in zip(ref, got):
@@ -137,8 +145,8 @@ def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mo
     pt = torch.arange(32, dtype=torch.int32, device=dev).flip(0).contiguous().view(1, 32)
     ws = ops.linear_workspace(dtype, M, C, dev)
     outs = []
-    for mode in (2, 4, 5):
-        linear_mode(mode)
+    for mode, bmt in ((2, None), (4, None), (5, 8), (5, 4)):          # decode kernel, skinny, 128 x 128 and 64 x 128 tiled (staged RoPE epilogue in both)
+        linear_mode(mode, bmt)
         kp = torch.zeros(32, nkv, 64, hs, dtype=dtype, device=dev)
         vp = torch.zeros_like(kp)
         q = torch.zeros(M, nh * hs, device=dev)

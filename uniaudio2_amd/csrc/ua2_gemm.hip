@@ -92,15 +92,17 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
 }
 
 // ---- the GEMM ------------------------------------------------------------------------------------------
-constexpr int kBMT = 8;     // 16-row tiles per workgroup (128 rows)
-constexpr int kWM = 4;      // row tiles per wave
+// BMT 16-row tiles per workgroup: 8 (128 x 128 tile, 64 x 64 per wave) or 4 (64 x 128, 32 x 64 per wave — for launches
+// whose 128-row grid would leave most CUs idle: M ~ 1000 rows x N = 1536 is 96 workgroups on 256 CUs).  A row's bits do
+// not depend on the tile (same chains, same retire points).
 constexpr int kKS = 2;      // chunks per LDS stage
 constexpr int kGroupM = 8;  // row-blocks per L2 patch
 
-template <int DT, int EPI>
+template <int DT, int EPI, int kBMT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
                                                       const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
+  constexpr int kWM = kBMT / 2;       // row tiles per wave
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int WN = 4 / NT;          // column tiles per wave, per matrix
   constexpr int BNT = 2 * WN;         // column tiles per workgroup, per matrix
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   if constexpr (EPI == UA2_EPI_QKV_ROPE) {
     if (a.rope_mode == UA2_ROPE_HALF_SPLIT && a.kv.head_size == 128 && !a.bias) {
       __syncthreads();                                   // every wave is done with the operand ring
-      float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * 64 * 64;
+      float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * (kWM * 16) * 64;
       const int colq = lane & 15, gq = lane >> 4;
 #pragma unroll
       for (int mi = 0; mi < kWM; ++mi)
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
       const int j = lane & 15, jj = j & 7;
       const bool hi = j >= 8;
       const int d0 = 32 * wn + 4 * jj;                   // table column / low-half dim of this lane's 4 dims
-      for (int it = 0; it < 16; ++it) {
+      for (int it = 0; it < kWM * 4; ++it) {
         const int prow = it * 4 + gq;
         const int m = (pm * kBMT + wm * kWM) * 16 + prow;
         if (m >= a.M) continue;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
     // for the WHOLE kernel — 605 scratch instructions, every retire() a round trip: the round-1 QKV launch ran at a third of
     // the SwiGLU launch's rate for that reason alone (profiles/r2_notes.md).
     __syncthreads();
-    float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * 64 * 64;
+    float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * (kWM * 16) * 64;
 #pragma unroll
     for (int mi = 0; mi < kWM; ++mi)
 #pragma unroll
@@ -496,10 +498,20 @@ template <int DT, int EPI>
 void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int BNT = 2 * (4 / NT);
-  const int mblocks = ua2_ceil_div(ua2_ceil_div(a.M, 16), kBMT), nblocks = ua2_ceil_div(ua2_ceil_div(a.N, 16), BNT);
+  const int mtiles = ua2_ceil_div(a.M, 16), nblocks = ua2_ceil_div(ua2_ceil_div(a.N, 16), BNT);
   static const int group_m = getenv("UA2_GEMM_GROUP_M") ? std::max(1, atoi(getenv("UA2_GEMM_GROUP_M"))) : kGroupM;   // experiment hook
-  hipLaunchKernelGGL((gemm_kernel<DT, EPI>), dim3(mblocks * nblocks), dim3(256), 0, s, a,
-                     reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), nw, mblocks, nblocks, group_m);
+  const char* bmt_env = getenv("UA2_GEMM_BMT");                                                                       // experiment / test hook: 4 or 8 (read per call)
+  const int force_bmt = bmt_env ? atoi(bmt_env) : 0;
+  // 64-row tiles when the 128-row grid cannot give every CU a workgroup (the codec's transformers: ~1000 rows)
+  const bool small = force_bmt ? force_bmt == 4 : (int64_t)ua2_ceil_div(mtiles, 8) * nblocks < 256;
+  const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
+  if (small) {
+    const int mblocks = ua2_ceil_div(mtiles, 4);
+    hipLaunchKernelGGL((gemm_kernel<DT, EPI, 4>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
+  } else {
+    const int mblocks = ua2_ceil_div(mtiles, 8);
+    hipLaunchKernelGGL((gemm_kernel<DT, EPI, 8>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
+  }
 }
 
 // Which of the two forms is faster — both give the same bits, so this is purely a cost model, fitted on
