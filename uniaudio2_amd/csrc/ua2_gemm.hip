@@ -502,8 +502,8 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   static const int group_m = getenv("UA2_GEMM_GROUP_M") ? std::max(1, atoi(getenv("UA2_GEMM_GROUP_M"))) : kGroupM;   // experiment hook
   const char* bmt_env = getenv("UA2_GEMM_BMT");                                                                       // experiment / test hook: 4 or 8 (read per call)
   const int force_bmt = bmt_env ? atoi(bmt_env) : 0;
-  // 64-row tiles when the 128-row grid cannot give every CU a workgroup (the codec's transformers: ~1000 rows)
-  const bool small = force_bmt ? force_bmt == 4 : (int64_t)ua2_ceil_div(mtiles, 8) * nblocks < 256;
+
+  const bool small = force_bmt ? force_bmt == 4 : (int64_t)ua2_ceil_div(mtiles, 8) * nblocks < 512;   // 64-row tiles when the 128-row grid cannot give every CU two workgroups (measured on the DiT, M = 1000: 12.0 -> 9.5 ms per step; no change at 2048 rows)
   const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
   if (small) {
     const int mblocks = ua2_ceil_div(mtiles, 4);
