@@ -34,9 +34,11 @@ class PackedLinear:
     def __call__(self, x, *, epilogue=EPI_STORE, norm=None, resid=None, out_scale=None, act_kind=0, w1=None, y=None, M=None, **kw):
         """x [M, K] fp32 contiguous rows.  norm = (w, b, eps) -> LayerNorm prologue (F.layer_norm then * w + b)."""
         M = M or x.shape[0]
-        if y is None and epilogue != EPI_QKV_ROPE:                   # QKV: the results go to q_out and the K/V pools
-            y = torch.empty(M, self.N, dtype=torch.float32, device=x.device)
-        ws = ops.linear_workspace(self.dtype, M, self.K, x.device) if M > 16 else None
+        dev = self.w.device
+        packed_in, packed_out = kw.get("x_packed") is not None, kw.get("y_packed") is not None   # operand handed over / handed on in fragment order
+        if y is None and epilogue != EPI_QKV_ROPE and not packed_out:  # QKV: the results go to q_out and the K/V pools
+            y = torch.empty(M, self.N, dtype=torch.float32, device=dev)
+        ws = ops.linear_workspace(self.dtype, M, self.K, dev) if M > 16 and not packed_in else None
         extra = {}
         if norm is not None:
             extra = dict(prologue=PRO_NORM, norm_w=norm[0], norm_b=norm[1], eps=norm[2], norm_kind=NORM_LAYERNORM)
@@ -67,10 +69,12 @@ class DenseKV:
         self.groups = ops.attn_groups(self.all_pos.cpu().numpy(), self.row_seq.cpu().numpy(), n_head, n_head, device) \
             if dtype == torch.bfloat16 else None
 
-    def attend(self, q):
-        """q [B*T, n_head*hs] fp32 -> softmax(q K^T / sqrt(hs)) V, every row over all T positions of its sequence."""
-        y = torch.empty_like(q)
-        ops.attn(dtype=self.dtype, R=q.shape[0], q=q, row_pos=self.all_pos, row_seq=self.row_seq, kv=self.geom, y=y, groups=self.groups)
+    def attend(self, q, y_packed=None):
+        """q [B*T, n_head*hs] fp32 -> softmax(q K^T / sqrt(hs)) V, every row over all T positions of its sequence; with
+        y_packed (a ua2_linear workspace) the rows are written in the consumer's operand order instead and nothing is returned."""
+        y = torch.empty_like(q) if y_packed is None else None
+        ops.attn(dtype=self.dtype, R=q.shape[0], q=q, row_pos=self.all_pos, row_seq=self.row_seq, kv=self.geom, y=y, groups=self.groups,
+                 y_packed=y_packed)
         return y
 
 

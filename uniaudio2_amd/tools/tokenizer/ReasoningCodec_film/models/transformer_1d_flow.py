@@ -82,6 +82,8 @@ class _FeedForward(nn.Module):
 
 
 class BasicTransformerBlock(nn.Module):
+    packed_handoff = True      # tests switch it off to compare against the route through the consumer's own prep launch
+
     def __init__(self, dim, num_attention_heads, attention_head_dim, attention_bias=True, norm_eps=1e-6):
         super().__init__()
         self.dim, self.heads, self.head_dim, self.eps = dim, num_attention_heads, attention_head_dim, norm_eps
@@ -109,6 +111,16 @@ class BasicTransformerBlock(nn.Module):
         q = torch.empty(h.shape[0], D, dtype=torch.float32, device=h.device)
         p["qkv"](h, epilogue=EPI_QKV_ROPE, norm=(w_a, sh_a, self.eps), rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq,
                  q_out=q, kv=kv.geom)
+        M = h.shape[0]
+        if self.packed_handoff and kv.groups is not None and M > 16 and D % 32 == 0:
+            # bf16 plan at many rows: attention and GELU write their consumer's operand in fragment order (same rounding as
+            # the consumer's own prep launch would apply: identical bits, two launches less per layer)
+            ws_o, ws_f = ops.linear_workspace(p["dtype"], M, D, h.device), ops.linear_workspace(p["dtype"], M, p["ff2"].K, h.device)
+            kv.attend(q, y_packed=ws_o)
+            p["out"](None, M=M, x_packed=ws_o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
+            p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH, y_packed=ws_f)
+            p["ff2"](None, M=M, x_packed=ws_f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h)
+            return h
         o = kv.attend(q)
         p["out"](o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
         f = p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH)
