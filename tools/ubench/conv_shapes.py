@@ -40,6 +40,9 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1e3 / (5 * N)
 
 
+FUSED = os.environ.get("UA2_UBENCH_FUSED", "0") == "1"      # the residual-unit launches (conv + 1 x 1 conv fused) of the big-T levels
+if FUSED:
+    SHAPES = [("F2 k7 d9", 128, 30000, 7, 9), ("F3 k7 d1", 64, 120000, 7, 1), ("F3 k7 d9", 64, 120000, 7, 9), ("F4 k7 d1", 32, 240000, 7, 1), ("F4 k7 d9", 32, 240000, 7, 9)]
 for name, Cc, T, K, d in SHAPES:
     x = torch.randn(1, Cc, T, device=dev)
     w = torch.randn(Cc, Cc, K, device=dev) / (Cc * K) ** 0.5
@@ -47,6 +50,9 @@ for name, Cc, T, K, d in SHAPES:
     bias = torch.randn(Cc, device=dev)
     alpha = torch.full((1,), 0.25, device=dev)
     pad = (K - 1) * d // 2
+    if FUSED:
+        w2h, w2l = ops.pack_conv_weight_x3(torch.randn(Cc, Cc, 1, device=dev) / Cc ** 0.5)
+        f2 = (w2h, w2l, bias, alpha)
     ref = None
     row = []
     for tile in TILES:
@@ -54,7 +60,11 @@ for name, Cc, T, K, d in SHAPES:
             os.environ.pop("UA2_CONV_PIPE", None)
         else:
             os.environ["UA2_CONV_PIPE"] = tile
-        call = lambda: ops.conv1d(x, hi, K, Cc, dilation=d, pad_left=pad, Tout=T, bias=bias, pre_act=1, pre_alpha=alpha, residual=x, w_lo=lo)
+        if FUSED:
+            call = lambda: ops.conv1d(x, hi, K, Cc, dilation=d, pad_left=(K - 1) * d, Tout=T, bias=bias, pre_act=0, post_act=1, post_alpha=alpha,
+                                      residual=x, w_lo=lo, fused2=f2)
+        else:
+            call = lambda: ops.conv1d(x, hi, K, Cc, dilation=d, pad_left=pad, Tout=T, bias=bias, pre_act=1, pre_alpha=alpha, residual=x, w_lo=lo)
         try:
             y = call()
             torch.cuda.synchronize()

@@ -36,7 +36,7 @@ constexpr int kMaxK = 32;
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   switch (act) {
-    case UA2_ACT_PRELU: return v >= 0.f ? v : alpha * v;
+    case UA2_ACT_PRELU: return v >= 0.f ? v : __fmul_rn(alpha, v);   // single roundings: hipcc would otherwise contract a*v + c differently per kernel
     case UA2_ACT_ELU: return v > 0.f ? v : expm1f(v);               // nn.ELU(alpha=1)
     case UA2_ACT_TANH: return tanhf(v);
     case UA2_ACT_ROUND9: return rintf(9.f * v) / 9.f;               // torch.round(9*x)/9, scalar24k.py:289
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const ua2_conv1d_args a) {
       const int t = t0 + nt * 16 + tl;
       const int to = t * a.out_phases + phase - a.out_trim_left;
       if (to < 0 || to >= a.Tout) continue;
-      float v = acc[nt][r] + bias;
+      float v = __fadd_rn(acc[nt][r], bias);
       v = apply_act(v, a.post_act, alpha);
       const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
       if (a.residual) v += a.residual[o];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
         if (pp[u] < kCG3 / 2) {
           const float x0 = apply_act(v0[u], a.pre_act, pre_alpha), x1 = apply_act(v1[u], a.pre_act, pre_alpha);   // act(0) = 0 for every pre-activation
           const unsigned h0 = f2bf(x0), h1 = f2bf(x1);
-          const unsigned l0 = f2bf(x0 - bf2f((unsigned short)h0)), l1 = f2bf(x1 - bf2f((unsigned short)h1));
+          const unsigned l0 = f2bf(__fsub_rn(x0, bf2f((unsigned short)h0))), l1 = f2bf(__fsub_rn(x1, bf2f((unsigned short)h1)));
           *reinterpret_cast<unsigned*>(xh + (size_t)ww[u] * kRowB + pp[u] * 4) = h0 | (h1 << 16);
           *reinterpret_cast<unsigned*>(xl + (size_t)ww[u] * kRowB + pp[u] * 4) = l0 | (l1 << 16);
         }
@@ -294,9 +294,9 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
         unsigned hh[4], hl[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float hv = apply_act(acc[q][nt][r] + bs[r], a.post_act, al1[r]);
+          const float hv = apply_act(__fadd_rn(acc[q][nt][r], bs[r]), a.post_act, al1[r]);
           hh[r] = f2bf(hv);
-          hl[r] = f2bf(hv - bf2f((unsigned short)hh[r]));
+          hl[r] = f2bf(__fsub_rn(hv, bf2f((unsigned short)hh[r])));
         }
         char* dst = hbase + (size_t)grp * 2 * hplane + (size_t)tw * kRowB + pc * 2;
         *reinterpret_cast<uint2*>(dst) = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
           const int t = t0 + tw0 + nt * 16 + tl;
           if (t >= a.Tout) continue;
           const size_t o = ((size_t)b * C + n) * a.Tout + t;
-          float v = acc2[q][nt][r] + b2;
-          v = v >= 0.f ? v : alpha2 * v;
-          a.y[o] = v + resv[q][r][nt];
+          float v = __fadd_rn(acc2[q][nt][r], b2);
+          v = v >= 0.f ? v : __fmul_rn(alpha2, v);
+          a.y[o] = __fadd_rn(v, resv[q][r][nt]);
         }
       }
     return;
@@ -364,10 +364,10 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
         const int t = t0 + tw0 + nt * 16 + tl;
         const int to = t * a.out_phases + phase - a.out_trim_left;
         if (to < 0 || to >= a.Tout) continue;
-        float v = acc[q][nt][r] + bias;
+        float v = __fadd_rn(acc[q][nt][r], bias);
         v = apply_act(v, a.post_act, alpha);
         const size_t o = ((size_t)b * a.Cout + co) * a.Tout + to;
-        a.y[o] = v + resv[q][r][nt];
+        a.y[o] = __fadd_rn(v, resv[q][r][nt]);
       }
     }
   }
@@ -400,7 +400,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 // hi/lo split of a pair: hi = RNE(x), lo = RNE(x - hi)
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
   hi = pack_bf16x2(x0, x1);
-  lo = pack_bf16x2(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+  lo = pack_bf16x2(__fsub_rn(x0, __uint_as_float(hi << 16)), __fsub_rn(x1, __uint_as_float(hi & 0xffff0000u)));
 }
 
 constexpr int kKC = 8;         // most weight chunks (tap x channel group) a unit holds in registers
@@ -496,8 +496,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(co
       for (int pi = 0; pi < PPW; ++pi) {
         float x0 = (pos_ok && c0 + 2 * pi < a.Cin) ? v0[pg * PPW + pi] : 0.f;
         float x1 = (pos_ok && c0 + 2 * pi + 1 < a.Cin) ? v1[pg * PPW + pi] : 0.f;
-        x0 = x0 >= 0.f ? x0 : pre_neg * x0;
-        x1 = x1 >= 0.f ? x1 : pre_neg * x1;
+        x0 = x0 >= 0.f ? x0 : __fmul_rn(pre_neg, x0);
+        x1 = x1 >= 0.f ? x1 : __fmul_rn(pre_neg, x1);
         unsigned hi, lo;
         split_pair(x0, x1, hi, lo);
         *reinterpret_cast<unsigned*>(dst + pi * 4) = hi;
@@ -613,8 +613,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(co
         float hv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float t = acc[nt][r] + bias[r];
-          hv[r] = t >= 0.f ? t : alpha[r] * t;
+          const float t = __fadd_rn(acc[nt][r], bias[r]);
+          hv[r] = t >= 0.f ? t : __fmul_rn(alpha[r], t);
         }
         unsigned h01, l01, h23, l23;
         split_pair(hv[0], hv[1], h01, l01);
@@ -647,30 +647,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(co
       for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = res[nt][r] + bias2[r];
-          res[nt][r] = v >= 0.f ? v : alpha2 * v;
+          const float v = __fadd_rn(res[nt][r], bias2[r]);
+          res[nt][r] = v >= 0.f ? v : __fmul_rn(alpha2, v);
         }
     } else {
 #pragma unroll
       for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[nt][r] + bias[r];
-          res[nt][r] = v >= 0.f ? v : alpha[r] * v;
+          const float v = __fadd_rn(acc[nt][r], bias[r]);
+          res[nt][r] = v >= 0.f ? v : __fmul_rn(alpha[r], v);
         }
     }
     if (interior) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int nt = 0; nt < NTT; ++nt) a.y[yo[r] + t0 + nt * 16] = res[nt][r] + (has_res ? resv[r][nt] : 0.f);
+        for (int nt = 0; nt < NTT; ++nt) a.y[yo[r] + t0 + nt * 16] = __fadd_rn(res[nt][r], has_res ? resv[r][nt] : 0.f);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
           const int to = (t0 + nt * 16) * a.out_phases + ph[r];
-          if (r0 + g * 4 + r < rows && to >= 0 && to < a.Tout) a.y[yo[r] + to] = res[nt][r] + (has_res ? resv[r][nt] : 0.f);
+          if (r0 + g * 4 + r < rows && to >= 0 && to < a.Tout) a.y[yo[r] + to] = __fadd_rn(res[nt][r], has_res ? resv[r][nt] : 0.f);
         }
     }
 #pragma unroll
