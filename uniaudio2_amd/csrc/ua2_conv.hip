@@ -418,7 +418,8 @@ constexpr int kKC = 8;         // most weight chunks (tap x channel group) a uni
 // conversion lands in the idle LDS image — so that the s_waitcnt the compiler places in front of the conversion counts
 // exactly the weight refills issued behind the x loads, and nothing pending crosses the loop's back edge except those.
 template <int NTT, int CPU, int GPU, int NPG, bool UPT1, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(const ua2_conv1d_args a, const int rt, const int tpw, const int ntiles) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(const ua2_conv1d_args a, const int rt, const int tpw, const int ntiles,
+                                                                               const int nrb, const int ngx) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
   constexpr int K = CPU / GPU;
   constexpr int PPW = 16 * GPU / NW;                    // channel pairs per wave (NW = 4 waves, or 8 for the fused 128-channel unit)
@@ -441,15 +442,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1d_x3p_kernel(co
   const int tl = lane & 15, g = lane >> 4;
   const int wr = wave % rt, wt = wave / rt;
   const int tw0 = wt * kBT;
-  const int r0 = (blockIdx.y * rt + wr) * 16;
-  const int b = blockIdx.z;
+  // Workgroup id -> (row block, tile run, batch), row block fastest: ids are dealt round-robin to the 8 XCDs, so an XCD's
+  // L2 only ever sees the weight slices of the row blocks congruent to it.  With the row block in blockIdx.y every XCD
+  // streamed ALL row blocks' weights through its 4 MB L2: the 512-channel layers (7.3 MB of split weights) fetched 86 MB
+  // per launch from the fabric; 31 MB with this mapping (PMC FETCH_SIZE, profiles/r2_pmc_codec.txt).  No change in time:
+  // those layers are bound by per-unit latency (16 small units per tile), not by that traffic.
+  const int wg_rb = blockIdx.x % nrb, wg_rest = blockIdx.x / nrb;
+  const int wg_tx = wg_rest % ngx, b = wg_rest / ngx;
+  const int r0 = (wg_rb * rt + wr) * 16;
   const int rows = a.Cout * a.out_phases;
   const int ngroups = (a.Cin + kCG3 - 1) / kCG3;
   const int nchunks = ngroups * K;
   const int upt = ngroups / GPU;                        // units per tile (launcher: GPU divides the channel-group count)
   const int tin_eff = a.Tin * a.in_repeat;
   const int ntile_rows = (rows + 15) / 16;
-  const int tile_first = blockIdx.x * tpw;
+  const int tile_first = wg_tx * tpw;
   if (tile_first >= ntiles) return;
   const int wtile = min(r0 / 16, ntile_rows - 1);       // a wave past the last row tile computes on a clamped tile and stores nothing
   const u32x4* wph = reinterpret_cast<const u32x4*>(a.w) + (size_t)wtile * nchunks * 64 + lane;
@@ -700,10 +707,10 @@ void launch_x3p(const ua2_conv1d_args& a, dim3 grid, size_t smem, int rt, int tp
   constexpr auto kn = conv1d_x3p_kernel<NTT, CPU, GPU, NPG, false, NW>;
   if (upt1) {
     ua2_allow_big_lds<k1>();
-    hipLaunchKernelGGL(k1, grid, dim3(64 * NW), smem, s, a, rt, tpw, ntiles);
+    hipLaunchKernelGGL(k1, dim3(grid.x * grid.y * grid.z), dim3(64 * NW), smem, s, a, rt, tpw, ntiles, (int)grid.y, (int)grid.x);
   } else {
     ua2_allow_big_lds<kn>();
-    hipLaunchKernelGGL(kn, grid, dim3(64 * NW), smem, s, a, rt, tpw, ntiles);
+    hipLaunchKernelGGL(kn, dim3(grid.x * grid.y * grid.z), dim3(64 * NW), smem, s, a, rt, tpw, ntiles, (int)grid.y, (int)grid.x);
   }
 }
 
