@@ -254,3 +254,47 @@ def test_pipelined_conv_kernel_is_bit_identical_to_plain(Cin, Cout, K, dil, T, r
     torch.cuda.synchronize()
     assert torch.isfinite(ref).all()
     assert torch.equal(got, ref), f"max diff {(got - ref).abs().max().item():.3e}"
+
+
+def test_pipelined_conv_kernel_fuzz_bit_identical():
+    """40 seeded random geometries through both bf16 x 3 kernels (UA2_CONV_PIPE=off vs default): channel counts that are not
+    multiples of the 32-channel group, K in {1, 2, 7}, dilations, repeat-upsampled inputs, transposed-conv phase outputs with a
+    left trim, batch 1-3, lengths that end inside a tile.  torch.equal on every case."""
+    import os
+    import random
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import ACT_PRELU
+    rnd = random.Random(20260927)
+    for case in range(40):
+        K = rnd.choice([1, 2, 7, 7])
+        Cin = rnd.choice([1, 17, 32, 48, 64, 96, 128, 136, 256])
+        Cout = rnd.choice([16, 19, 32, 40, 64, 128, 200])
+        dil = rnd.choice([1, 3, 5, 9]) if K == 7 else 1
+        T = rnd.choice([37, 64, 333, 1000, 2049, 5000])
+        B = rnd.choice([1, 2, 3])
+        rep = rnd.choice([1, 1, 2]) if K != 2 else 1
+        phases = rnd.choice([2, 4, 5]) if K == 2 else 1             # K = 2: the phase form of ConvTranspose1d(k = 2 s)
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(B, Cin, T, generator=g).cuda()
+        rows = Cout * phases
+        w = (torch.randn(rows, Cin, K, generator=g) / (Cin * K) ** 0.5).cuda()
+        hi, lo = ops.pack_conv_weight_x3(w)
+        trim = rnd.choice([0, 1]) if phases > 1 else 0
+        Tout = T * rep * phases - trim * 2 if phases > 1 else T * rep
+        kw = dict(dilation=dil, pad_left=dil * (K - 1), Tout=Tout, bias=torch.randn(Cout, generator=g).cuda(), w_lo=lo, in_repeat=rep,
+                  out_phases=phases, out_trim_left=trim)
+        if rnd.random() < 0.5:
+            kw.update(pre_act=ACT_PRELU, pre_alpha=torch.tensor([0.1]).cuda())
+        if rnd.random() < 0.5:
+            kw.update(post_act=ACT_PRELU, post_alpha=(torch.rand(Cout, generator=g) if rnd.random() < 0.5 else torch.tensor([0.2])).cuda())
+        if rnd.random() < 0.5:
+            kw.update(residual=torch.randn(B, Cout, Tout, generator=g).cuda())
+        os.environ["UA2_CONV_PIPE"] = "off"
+        try:
+            ref = ops.conv1d(x, hi, K, Cout, **kw)
+        finally:
+            os.environ.pop("UA2_CONV_PIPE", None)
+        got = ops.conv1d(x, hi, K, Cout, **kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ref).all(), case
+        assert torch.equal(got, ref), (case, K, Cin, Cout, dil, T, B, rep, phases, trim, (got - ref).abs().max().item())
