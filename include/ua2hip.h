@@ -108,7 +108,7 @@ typedef struct ua2_kv_geom {
   int32_t n_head;
   int32_t head_size;
   int32_t ring_pages; /* 0: linear cache (page of position p = p / UA2_PAGE).  > 0: ring cache — position p lives in table column
-                         (p / UA2_PAGE) % ring_pages, so a streaming session of any length re-uses ring_pages pages per sequence
+                         (p / UA2_PAGE) % ring_pages (ring_pages a power of two), so a streaming session of any length re-uses ring_pages pages per sequence
                          (RingKVCache, llm_modules/transformer.py:211-278).  The caller guarantees ring_pages * UA2_PAGE exceeds
                          the attention window plus the positions written per launch; ua2_attn needs window > 0 with it. */
 } ua2_kv_geom;

@@ -514,8 +514,9 @@ int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s) {
             "ua2_attn: NULL pointer argument");
   UA2_CHECK(a.kv.n_kv > 0 && a.kv.n_head % a.kv.n_kv == 0 && a.kv.n_head / a.kv.n_kv <= kMaxG,
             "ua2_attn: n_head=%d n_kv=%d not supported (group size <= %d)", a.kv.n_head, a.kv.n_kv, kMaxG);
-  UA2_CHECK(a.kv.ring_pages == 0 || (a.window > 0 && a.kv.ring_pages <= a.kv.max_pages && a.window <= (a.kv.ring_pages - 1) * UA2_PAGE + 1),
-            "ua2_attn: a ring cache (ring_pages=%d) needs 0 < window <= (ring_pages - 1) * %d + 1", a.kv.ring_pages, UA2_PAGE);
+  UA2_CHECK(a.kv.ring_pages == 0 || (a.window > 0 && a.kv.ring_pages <= a.kv.max_pages && a.window <= (a.kv.ring_pages - 1) * UA2_PAGE + 1 &&
+                                     (a.kv.ring_pages & (a.kv.ring_pages - 1)) == 0),
+            "ua2_attn: a ring cache (ring_pages=%d) needs a power-of-two page count and 0 < window <= (ring_pages - 1) * %d + 1", a.kv.ring_pages, UA2_PAGE);
   UA2_CHECK(!a.y_packed || (a.kv.n_head * a.kv.head_size) % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_attn: y_packed needs n_head*head_size %% chunk == 0");
   if (a.group_rows && a.n_groups > 0 && a.dtype == UA2_BF16 && a.window <= 0) {   // many rows per sequence: MFMA flash form
     UA2_CHECK(a.group_seq && a.group_nkeys && a.group_q_tiles > 0, "ua2_attn: group_seq / group_nkeys / group_q_tiles missing");

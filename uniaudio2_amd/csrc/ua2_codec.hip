@@ -210,6 +210,7 @@ extern "C" int ua2_qknorm_rope_kv(int dtype, const float* qkv, int64_t R, const 
   UA2_CHECK(qkv && row_pos && q_out && kv && kv->k_pool && kv->v_pool && kv->page_table && R > 0, "ua2_qknorm_rope_kv: NULL argument");
   UA2_CHECK(kv->n_kv == kv->n_head && kv->head_size >= 16 && kv->head_size <= 256 && kv->head_size % 16 == 0,
             "ua2_qknorm_rope_kv: multi-head attention only (n_kv == n_head), head_size in 16..256");
+  UA2_CHECK(kv->ring_pages == 0 || (kv->ring_pages & (kv->ring_pages - 1)) == 0, "ua2_qknorm_rope_kv: ring_pages=%d must be a power of two", kv->ring_pages);
   UA2_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr) && (!q_norm_w || (q_norm_b && k_norm_b)), "ua2_qknorm_rope_kv: norm weights come in pairs with biases");
   UA2_CHECK(rot_dim >= 0 && rot_dim <= kv->head_size && rot_dim % 2 == 0 && (rot_dim == 0 || (cos_t && sin_t)), "ua2_qknorm_rope_kv: bad rot_dim / tables");
   const size_t smem = (size_t)(2 * kv->head_size + 8) * sizeof(float);

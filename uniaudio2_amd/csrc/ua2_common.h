@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_packed_operand(void* base, int m, int k, i
 // transformers of the Moshi family, llm_modules/transformer.py:211-278) wrap over ring_pages pages.
 __device__ __forceinline__ int ua2_page_slot(const ua2_kv_geom& kv, int pos) {
   const int lp = pos / UA2_PAGE;
-  return kv.ring_pages > 0 ? lp % kv.ring_pages : lp;
+  return kv.ring_pages > 0 ? (lp & (kv.ring_pages - 1)) : lp;   // ring_pages is a power of two (checked by the launchers): no integer division per key
 }
 
 static inline int ua2_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -94,6 +94,7 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     UA2_CHECK(a.row_pos && (a.rope_mode == UA2_ROPE_NONE || (a.rope_cos && a.rope_sin)) && a.q_out && a.kv.k_pool && a.kv.v_pool &&
                   a.kv.page_table,
               "ua2_linear: QKV_ROPE pointer arguments missing");
+    UA2_CHECK(a.kv.ring_pages == 0 || (a.kv.ring_pages & (a.kv.ring_pages - 1)) == 0, "ua2_linear: ring_pages=%d must be a power of two", a.kv.ring_pages);
   }
   if (a.dtype != UA2_BF16 && a.dtype != UA2_F32) {
     ua2_set_error("ua2_linear: bad dtype %d", a.dtype);

@@ -197,6 +197,7 @@ class StreamingTransformer(StreamingModule):
         plan["ring_pages"] = 0
         if ring:
             n_pages = (self.context + self.ring_chunk + UA2_PAGE - 1) // UA2_PAGE + 1
+            n_pages = 1 << (n_pages - 1).bit_length()             # the kernels index the ring with a mask (include/ua2hip.h)
             plan["ring_pages"] = n_pages
         plan["max_pages"] = n_pages
         shape = (max_batch * n_pages, H, UA2_PAGE, hs)
