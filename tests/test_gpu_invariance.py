@@ -113,7 +113,7 @@ def test_large_m_kernel_is_bit_identical_to_the_decode_kernel(dtype, N, K, linea
         for M in (1, 5, 40, 130, 300):
             linear_mode(2)
             ref = run(M, pro, epi, nk)
-            for mode, bmt in ((4, None), (5, 8), (5, 4)):     # skinny form, 128 x 128 tiled form, 64 x 128 tiled form
+            for mode, bmt in ((4, None), (5, 8), (5, 4), (5, 2)):     # skinny form; 128-, 64- and 32-row tiled forms
                 linear_mode(mode, bmt)
                 got = run(M, pro, epi, nk)
                 for r, o, name in zip(ref, got, ("y", "part_max", "part_idx")):
@@ -145,7 +145,7 @@ def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mo
     pt = torch.arange(32, dtype=torch.int32, device=dev).flip(0).contiguous().view(1, 32)
     ws = ops.linear_workspace(dtype, M, C, dev)
     outs = []
-    for mode, bmt in ((2, None), (4, None), (5, 8), (5, 4)):          # decode kernel, skinny, 128 x 128 and 64 x 128 tiled (staged RoPE epilogue in both)
+    for mode, bmt in ((2, None), (4, None), (5, 8), (5, 4), (5, 2)):  # decode kernel, skinny, 128- / 64- / 32-row tiled (staged RoPE epilogue in all)
         linear_mode(mode, bmt)
         kp = torch.zeros(32, nkv, 64, hs, dtype=dtype, device=dev)
         vp = torch.zeros_like(kp)

@@ -503,9 +503,15 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   const char* bmt_env = getenv("UA2_GEMM_BMT");                                                                       // experiment / test hook: 4 or 8 (read per call)
   const int force_bmt = bmt_env ? atoi(bmt_env) : 0;
 
-  const bool small = force_bmt ? force_bmt == 4 : (int64_t)ua2_ceil_div(mtiles, 8) * nblocks < 512;   // 64-row tiles when the 128-row grid cannot give every CU two workgroups (measured on the DiT, M = 1000: 12.0 -> 9.5 ms per step; no change at 2048 rows)
+  // 64-row tiles when the 128-row grid cannot give every CU two workgroups (measured on the DiT, M = 1000: 12.0 -> 9.5 ms per
+  // step; no change at 2048 rows); 32-row tiles when even those leave CUs idle (M = 1000 x N = 1536: 192 workgroups)
+  const int64_t g8 = (int64_t)ua2_ceil_div(mtiles, 8) * nblocks, g4 = (int64_t)ua2_ceil_div(mtiles, 4) * nblocks;
+  const int bmt = force_bmt ? force_bmt : (g8 >= 512 ? 8 : (g4 >= 256 ? 4 : 2));
   const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
-  if (small) {
+  if (bmt == 2) {
+    const int mblocks = ua2_ceil_div(mtiles, 2);
+    hipLaunchKernelGGL((gemm_kernel<DT, EPI, 2>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
+  } else if (bmt == 4) {
     const int mblocks = ua2_ceil_div(mtiles, 4);
     hipLaunchKernelGGL((gemm_kernel<DT, EPI, 4>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
   } else {
