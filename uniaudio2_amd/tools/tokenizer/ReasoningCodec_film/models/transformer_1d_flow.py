@@ -101,13 +101,16 @@ class BasicTransformerBlock(nn.Module):
                        ff2=PackedLinear(self.ff.net[2].weight, self.ff.net[2].bias, dtype),
                        table=self.scale_shift_table.detach().float().contiguous().view(-1), dtype=dtype)
 
-    def run(self, h, ts, kv: DenseKV):
+    def run(self, h, ts, kv: DenseKV, mod=None, mod1=None):
         """h [B*T, D] fp32 rows (in place); ts [6*D] = adaln_single.linear(silu(t_emb)) of this step (one timestep for the
-        whole batch, as solve_euler passes it)."""
+        whole batch, as solve_euler passes it).  mod / mod1: this block's (6, D) slices of `table + ts` and `1 + (table + ts)`
+        when the caller computed them for all blocks in two launches (same operations, same order)."""
         p, D = self._p, self.dim
-        mod = ops.ew_fma(p["table"], c=ts)                                   # table + timestep  -> (6, D)
-        sh_a, sc_a, g_a, sh_m, sc_m, g_m = (mod[i * D:(i + 1) * D] for i in range(6))
-        w_a, w_m = ops.ew_fma(sc_a, beta=1.0), ops.ew_fma(sc_m, beta=1.0)    # 1 + scale
+        if mod is None:
+            mod = ops.ew_fma(p["table"], c=ts)                               # table + timestep  -> (6, D)
+            mod1 = ops.ew_fma(mod, beta=1.0)
+        sh_a, _, g_a, sh_m, _, g_m = (mod[i * D:(i + 1) * D] for i in range(6))
+        w_a, w_m = mod1[D:2 * D], mod1[4 * D:5 * D]                          # 1 + scale
         q = torch.empty(h.shape[0], D, dtype=torch.float32, device=h.device)
         p["qkv"](h, epilogue=EPI_QKV_ROPE, norm=(w_a, sh_a, self.eps), rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq,
                  q_out=q, kv=kv.geom)
@@ -205,6 +208,7 @@ class Transformer1DModel(nn.Module):
         self.proj_in.prepare(dtype); self.proj_out.prepare(dtype); self.adaln_single.prepare(dtype)
         for b in self.transformer_blocks:
             b.prepare(dtype)
+        self._table_all = torch.cat([b._p["table"] for b in self.transformer_blocks]).contiguous()
         D = self.inner_dim
         pos = torch.arange(self.max_pos).unsqueeze(1).float()                 # diffusers SinusoidalPositionalEmbedding (:232)
         div = torch.exp(torch.arange(0, D, 2).float() * (-math.log(10000.0) / D))
@@ -222,8 +226,10 @@ class Transformer1DModel(nn.Module):
         h = self.proj_in.run(x, B, T)
         h = ops.ew_fma(h, c=self._pe[:T])                                     # + pos_embed (:338); the modulo broadcast repeats it per batch element
         ts, e = self.adaln_single.run(emb)
-        for blk in self.transformer_blocks:
-            blk.run(h, ts, self._kv)
+        mod_all = ops.ew_fma(self._table_all, c=ts)                           # every block's table + timestep in one launch (was 3 per block)
+        mod1_all = ops.ew_fma(mod_all, beta=1.0)
+        for l, blk in enumerate(self.transformer_blocks):
+            blk.run(h, ts, self._kv, mod_all[l * 6 * D:(l + 1) * 6 * D], mod1_all[l * 6 * D:(l + 1) * 6 * D])
         mod = ops.ew_fma(self._table, c=e)                                    # (2, D): scale_shift_table + embedded_timestep  :378
         shift, scale = mod[:D], mod[D:]
         hn = ops.layernorm_rows(h, None, None, 1e-6)                          # norm_out :379
