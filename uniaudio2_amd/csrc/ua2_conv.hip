@@ -1,4 +1,7 @@
-// 1-D convolution / transposed convolution of the codec's waveform auto-encoders, exact fp32.
+// 1-D convolution / transposed convolution of the codec's waveform auto-encoders.  Three kernels behind ua2_conv1d:
+//   conv1d_kernel       precision 0: exact fp32 on the f32 matrix pipe (encode side, parity reference)        — first below
+//   conv1d_x3_kernel    precision 1: bf16 x 3 split operands on the bf16 matrix pipe, plain phase-by-phase form
+//   conv1d_x3p_kernel   precision 1: the same arithmetic (bit-identical), software-pipelined — the default of the decode side
 //
 // Replaces (§2.3 K14-K16, K19, K21):
 //   ReasoningCodec_film/models/scalar24k.py  Conv1d :36-74 (causal = left zero-pad d(k-1), else
