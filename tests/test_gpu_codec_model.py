@@ -275,3 +275,44 @@ def test_config1_codec_plumbing_p225(tmp_path):
     assert wav.shape == wav_ref.shape == (1, 1, 96000)
     rms = float(((wav - wav_ref) ** 2).mean().sqrt())
     assert rms < 1e-4 * max(1.0, float((wav_ref ** 2).mean().sqrt())), rms
+
+
+def test_audio2token_skips_discarded_segments_with_identical_tokens():
+    """SURVEY.md §8f rank-2 waste removal on the encode side: reason_tokenizer.py:98-128 encodes every 30-s segment of the
+    self-concatenated clip and then slices the tokens to the clip's own length.  The mirror computes only the segments whose
+    tokens survive, with the FiLM draws of each chunk made for the reference's full batch (AudioDiffusion1D.py:435 draws per
+    batch).  Same seed -> the same tokens as the everything-computed route, with fewer rows through the model."""
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer import ReasoningTokenizer, segment_plan
+    d, meta = _gold()
+    m, _ = _toy_model(meta)
+    c = CFG
+    rows_seen = []
+
+    def ssl_features(audio, spectrograms):
+        """Deterministic stand-in for the frozen encoders: features are a function of the row's own samples only."""
+        B = audio.shape[0]
+        rows_seen.append(B)
+        out = {k: [] for k in ("whisper", "wavlm", "bestrq_acoustic", "bestrq_semantic")}
+        for b in range(B):
+            seed = int(audio[b].double().abs().sum().item() * 1000) % 100000
+            out["whisper"].append(seeded_tensor((c["Cw"], 2 * c["T25"]), seed + 1, std=1.0))
+            out["wavlm"].append(seeded_tensor((c["Cl"], 2 * c["T25"]), seed + 2, std=1.0))
+            out["bestrq_acoustic"].append(seeded_tensor((c["Cb"], c["T25"]), seed + 3, std=1.0))
+            out["bestrq_semantic"].append(seeded_tensor((c["Cb"], c["T25"]), seed + 4, std=1.0))
+        return {k: torch.stack(v).cuda() for k, v in out.items()}
+
+    m.ssl_features = ssl_features
+    tok = ReasoningTokenizer(model=m, device="cuda")
+    wav = seeded_tensor((1, 26000), 77, std=0.1)                       # ~1.08 s: 14 rec / 6 reason tokens kept, one toy segment yields 15 / 6
+    plan = segment_plan(wav.shape[-1])
+    assert plan["n_segments"] == 2
+    results = {}
+    for skip in (True, False):
+        tok.skip_discarded_segments = skip
+        rows_seen.clear()
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        reason, rec = tok.audio2token(wav, 24000)
+        results[skip] = (reason.cpu(), rec.cpu(), sum(rows_seen))
+    assert results[True][2] == 1 and results[False][2] == 2            # rows encoded: 1 instead of 2
+    assert torch.equal(results[True][0], results[False][0]) and torch.equal(results[True][1], results[False][1])
+    assert results[True][1].shape == (1, 8, plan["output_len"]) and results[True][0].shape[-1] == min(plan["output_len_reason"], 6)

@@ -257,8 +257,10 @@ class AudioDiffusion1D(nn.Module):
         return [reason_codes], [codes], [merge]
 
     @torch.inference_mode()
-    def fetch_codes_batch(self, input_audios, spectrograms, additional_feats=None, return_reasoning_text=False):
-        """:493-551.  The frozen SSL encoders are the injected `ssl_features` callable (see the module docstring)."""
+    def fetch_codes_batch(self, input_audios, spectrograms, additional_feats=None, return_reasoning_text=False, film_masks=None):
+        """:493-551.  The frozen SSL encoders are the injected `ssl_features` callable (see the module docstring).  film_masks
+        (3, B) bool: the three FiLM draws of this call made by the caller (ReasoningTokenizer.audio2token draws them for the
+        reference's whole chunk and computes only the rows whose tokens are kept)."""
         if return_reasoning_text:
             raise NotImplementedError("the reasoning-text LLM of AudioThinking is not part of the token path and is not built")
         if self.ssl_features is None:
@@ -266,7 +268,7 @@ class AudioDiffusion1D(nn.Module):
                                       "construct AudioDiffusion1D(ssl_features=...) with a callable that returns their features, or call "
                                       "fetch_codes_from_features")
         f = self.ssl_features(input_audios, spectrograms)
-        return self.fetch_codes_from_features(f["whisper"], f["wavlm"], f["bestrq_acoustic"], f["bestrq_semantic"])
+        return self.fetch_codes_from_features(f["whisper"], f["wavlm"], f["bestrq_acoustic"], f["bestrq_semantic"], film_masks=film_masks)
 
     # ---- decode side -----------------------------------------------------------------------------------------------
     def prepare_latents(self, batch_size, num_frames, dtype, device):

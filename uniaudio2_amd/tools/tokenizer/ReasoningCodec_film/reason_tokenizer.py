@@ -156,6 +156,7 @@ class ReasoningTokenizer:
         self.rec_frame_rate, self.reason_frame_rate, self.sq_codec_hz = 12.5, 5, 25        # :31-33
         self.SQCodec, self.latent_fn, self.model = sq_codec, latent_fn, model
         self.feature_extractor = feature_extractor          # Whisper log-mel front end (:67-72), out of scope: injected or None
+        self.skip_discarded_segments = True                 # audio2token: do not encode segments whose tokens the reference slices away
         self.vq = (vq_phone, vq_semantic, vq_acoustic)
         if model is not None:
             self.vq = (model.vq_pronunciation_semantic, model.vq_structure_semantic, model.vq_acoustic)
@@ -210,13 +211,43 @@ class ReasoningTokenizer:
             audios = torch.cat([audios, audios], -1)
         audios = torch.cat([audios, audios], -1)[:, :plan["total"]]
         audio_input = audios.reshape(1, -1, plan["segment"]).permute(1, 0, 2).reshape(-1, 1, plan["segment"])
+        # Waste removal, outputs identical: the reference encodes every segment of the doubled clip and
+        # then keeps output_len / output_len_reason tokens (:125-128) — for a 10-s clip the whole second 30-s segment is
+        # discarded.  Segments are batch rows (independent of each other), so only the rows whose tokens survive the slice are
+        # computed.  The one cross-row coupling is the RNG: time_film draws torch.rand(B, 1, 1) per call (AudioDiffusion1D.py:435)
+        # — the three draws of a chunk are made here for the reference's full chunk, in its order, and sliced per row.
+        need_rec, need_reason = plan["output_len"], plan["output_len_reason"]
+        have_rec = have_reason = 0
+        per_rec = per_reason = None                               # tokens per segment, known after the first computed row
         reason_list, rec_list = [], []
         for i in range(0, audio_input.shape[0], batch_size):
             chunk = audio_input[i:i + batch_size]
-            mels = self.feature_extractor(chunk[:, 0, :]) if self.feature_extractor is not None else None
-            reasoning_codes, rec_codes, _ = self.model.fetch_codes_batch(chunk, mels, additional_feats=[], return_reasoning_text=return_reasoning_text)
-            reason_list.append(torch.cat(reasoning_codes, 1))
-            rec_list.append(torch.cat(rec_codes, 1))
+            Bc = chunk.shape[0]
+            if self.skip_discarded_segments and have_rec >= need_rec and have_reason >= need_reason:
+                break
+            masks = [(torch.rand(Bc, 1, 1, device=self.device) < 0.2).view(Bc) for _ in range(3)]
+            r = 0
+            while r < Bc:
+                if not self.skip_discarded_segments:
+                    k = Bc
+                elif have_rec >= need_rec and have_reason >= need_reason:
+                    break
+                elif per_rec is None:
+                    k = 1
+                else:
+                    k = max(-(-(need_rec - have_rec) // per_rec), -(-(need_reason - have_reason) // per_reason), 1)
+                k = min(k, Bc - r)
+                rows = chunk[r:r + k]
+                mels = self.feature_extractor(rows[:, 0, :]) if self.feature_extractor is not None else None
+                reasoning_codes, rec_codes, _ = self.model.fetch_codes_batch(rows, mels, additional_feats=[], return_reasoning_text=return_reasoning_text,
+                                                                            film_masks=[m[r:r + k] for m in masks])
+                rc, mc = torch.cat(reasoning_codes, 1), torch.cat(rec_codes, 1)
+                reason_list.append(rc)
+                rec_list.append(mc)
+                per_reason, per_rec = rc.shape[1], mc.shape[1]
+                have_reason += k * per_reason
+                have_rec += k * per_rec
+                r += k
         reason = torch.cat(reason_list, 0).reshape(-1, 8).unsqueeze(0)
         rec = torch.cat(rec_list, 0).reshape(-1, 8).unsqueeze(0)
         return reason[:, :plan["output_len_reason"], :].transpose(1, 2), rec[:, :plan["output_len"], :].transpose(1, 2)
