@@ -213,7 +213,26 @@ def stage2_leg(dev, steps=10):
     e1.record(); torch.cuda.synchronize()
     step_ms = e0.elapsed_time(e1) / 5
     flop = 2.0 * 500 * 32 * 2 * 12 * 1536 ** 2
-    return {"euler_steps": steps, "window_s": 20.0, "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
+    # encode side of the same model (config 2's "codec encode", everything behind the frozen SSL encoders): one 30-s segment
+    # — what a 10-s clip costs since audio2token stopped encoding the segment the reference discards — with synthetic features
+    # of the released shapes (Whisper 1024 x 1500 and WavLM 768 x 1500 at 50 Hz, BEST-RQ 1024 x 750 at 25 Hz)
+    enc = {}
+    try:
+        g = torch.Generator(device="cpu").manual_seed(3)
+        f = [torch.randn(1, c, t, generator=g).to(dev) for c, t in ((1024, 1500), (768, 1500), (1024, 750), (1024, 750))]
+        masks = torch.zeros(3, 1, dtype=torch.bool)
+        model.fetch_codes_from_features(*f, film_masks=masks)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(8):
+            rc, mc, _ = model.fetch_codes_from_features(*f, film_masks=masks)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / 8 * 1e3
+        enc = {"encode_post_ssl_ms_per_30s_segment": round(ms, 2), "encode_post_ssl_clips_per_s": round(1e3 / ms, 1),
+               "reason_tokens": list(rc[0].shape), "semantic_tokens": list(mc[0].shape)}
+    except Exception as e:  # noqa: BLE001 — an information leg must not take the bench line down
+        enc = {"encode_post_ssl_error": repr(e)[:200]}
+    return {**enc, "euler_steps": steps, "window_s": 20.0, "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
             "dit_ms_per_guided_step": round(step_ms, 2), "dit_tflops": round(flop / (step_ms * 1e-3) / 1e12, 1),
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
 
