@@ -125,7 +125,7 @@ def test_large_m_kernel_is_bit_identical_to_the_decode_kernel(dtype, N, K, linea
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("nh,nkv,hs,C", [(24, 8, 128, 3072), (32, 8, 64, 2048)])
+@pytest.mark.parametrize("nh,nkv,hs,C", [(24, 8, 128, 3072), (32, 8, 64, 2048), (6, 6, 64, 384), (5, 5, 64, 320)])
 def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mode):
     """Fused RMSNorm + QKV + RoPE + paged KV-cache append through both kernels: q_out and the cache pages agree
     bit for bit (a 200-token prefill of one sequence)."""
@@ -135,7 +135,10 @@ def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mo
     g = torch.Generator(device="cpu").manual_seed(hs)
     M = 200
     nq = (nh + 2 * nkv) * hs
-    w = ops.pack_linear((torch.randn(nq, C, generator=g) * C ** -0.5).to(dev), dtype, rope_head_size=hs)
+    mha_no_rope = nh == nkv                       # the codec's dense transformers: multi-head, no rotation, q|k|v bias (staged epilogue of its own)
+    from uniaudio2_amd._lib import ROPE_NONE
+    extra = dict(rope_mode=ROPE_NONE, bias=(0.1 * torch.randn(nq, generator=g)).to(dev)) if mha_no_rope else {}
+    w = ops.pack_linear((torch.randn(nq, C, generator=g) * C ** -0.5).to(dev), dtype, **({} if mha_no_rope else dict(rope_head_size=hs)))
     x = torch.randn(M, C, generator=g).to(dev)
     nw = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
     pos = torch.arange(M, dtype=torch.int32, device=dev)
@@ -152,7 +155,7 @@ def test_large_m_qkv_rope_cache_write_identical(dtype, nh, nkv, hs, C, linear_mo
         q = torch.zeros(M, nh * hs, device=dev)
         ops.linear(dtype=dtype, M=M, N=nq, K=C, w0=w, prologue=PRO_NORM, epilogue=EPI_QKV_ROPE, x=x, norm_w=nw,
                    row_pos=pos, row_seq=seq, rope_cos=cos, rope_sin=sin, q_out=q, kv=ops.kv_geom(kp, vp, pt, nh, nkv, hs),
-                   workspace=ws)
+                   workspace=ws, **extra)
         torch.cuda.synchronize()
         outs.append((q, kp, vp))
     for other in outs[1:]:

@@ -308,6 +308,55 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
       }
       return;
     }
+    // No rotation, head_size 64 (the codec's DiT: fused q|k|v with bias): the same staging — a wave's 64 columns are exactly one
+    // head, a lane owns 4 consecutive dims of a row — without the rotation.  The generic path below took 52 us of a launch
+    // whose GEMM is worth 33 (profiles/r2_notes.md §4).  Same operations (sum + bias, one rounding): identical bits.
+    if (a.rope_mode == UA2_ROPE_NONE && a.kv.head_size == 64) {
+      __syncthreads();
+      float* patch = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)wave * (kWM * 16) * 64;
+      const int colq = lane & 15, gq = lane >> 4;
+#pragma unroll
+      for (int mi = 0; mi < kWM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) patch[(mi * 16 + 4 * gq + r) * 64 + ni * 16 + colq] = tot[0][mi][ni][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int hs = 64;
+      const int h = pn * 2 + wn;                         // head of this wave's 64 columns
+      if (h * hs >= a.N) return;                         // wave-uniform: past the last head
+      const bool is_q = h < a.kv.n_head, is_k = !is_q && h < a.kv.n_head + a.kv.n_kv;
+      const int kvh = is_q ? 0 : (is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv);
+      const int d0 = 4 * colq;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (size_t)h * hs + d0);
+      for (int it = 0; it < kWM * 4; ++it) {
+        const int prow = it * 4 + gq;
+        const int m = (pm * kBMT + wm * kWM) * 16 + prow;
+        if (m >= a.M) continue;
+        float4 out = *reinterpret_cast<const float4*>(patch + prow * 64 + d0);
+        if (a.bias) { out.x = __fadd_rn(out.x, b4.x); out.y = __fadd_rn(out.y, b4.y); out.z = __fadd_rn(out.z, b4.z); out.w = __fadd_rn(out.w, b4.w); }
+        if (is_q) {
+          *reinterpret_cast<float4*>(a.q_out + (size_t)m * a.kv.n_head * hs + (size_t)h * hs + d0) = out;
+        } else {
+          const int pos = a.row_pos[m];
+          const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages + ua2_page_slot(a.kv, pos)];
+          const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs + d0;
+          void* pool = is_k ? a.kv.k_pool : a.kv.v_pool;
+          if constexpr (DT == UA2_BF16) {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(out.x) | ((unsigned)f2bf(out.y) << 16);
+            pk.y = (unsigned)f2bf(out.z) | ((unsigned)f2bf(out.w) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(pool) + base) = pk;
+          } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(pool) + base) = out;
+          }
+        }
+      }
+      return;
+    }
     // Other RoPE flavours / head sizes (Moshi family): the generic per-element epilogue, but fed from LDS.  Fed from the
     // accumulator registers, its control flow (shuffles, early exits per row) made the compiler keep `tot` in scratch memory
     // for the WHOLE kernel — 605 scratch instructions, every retire() a round trip: the round-1 QKV launch ran at a third of
