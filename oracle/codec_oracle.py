@@ -159,6 +159,63 @@ def crossfade(segments, wav_window: int, wav_ovlp: int, target_len: int):
     return output[:, 0:target_len]
 
 
+def token2audio_no_reason(rec_codec, inference_codes, decode, duration: int = 20, num_steps: int = 20, latent_dim: int = 136):
+    """reason_tokenizer.py:229-306 around two callables (`inference_codes` = AudioDiffusion1D.inference_codes, `decode` =
+    SQCodec.decode): rec_codec (B, 8, T) -> waveform (B, N) fp32 on the CPU.  PINNED on tests/golden/tokenizer_host.npz, which
+    the reference's own method produced on the same stand-ins (windows, in-context chain, randn draw order, cross-fade, crop).
+    Draws: `first_latent` (B, 500, 136) before anything else (:235), then per later window the (B, 500 - 32, 136) tail of
+    `true_latent` (:282) — both from the CPU generator."""
+    B, _, T = rec_codec.shape
+    plan = window_indices(T, duration)
+    latent_length = int(duration * 25)
+    first_latent = torch.randn(B, latent_length, latent_dim)
+    latents = []
+    for i, idx in enumerate(plan["windows"]):
+        window = rec_codec[:, :, idx]
+        if i == 0:
+            lat = inference_codes([window], None, first_latent, latent_length, 0, additional_feats=[], guidance_scale=1.5,
+                                  num_steps=num_steps, disable_progress=True, scenario="other_seg")
+        else:
+            true = latents[-1][:, -plan["ovlp_frames"]:, :]
+            pad = torch.randn(true.shape[0], latent_length - true.shape[1], true.shape[-1])
+            lat = inference_codes([window], None, torch.cat([true, pad], 1), latent_length, true.shape[1], additional_feats=[],
+                                  guidance_scale=1.5, num_steps=num_steps, disable_progress=True, scenario="other_seg")
+        latents.append(lat)
+    latents = [l.float() for l in latents]
+    segments = [decode(l.transpose(1, 2)).squeeze(0) for l in latents]
+    return crossfade(segments, plan["wav_window"], plan["wav_ovlp"], plan["target_len"])
+
+
+def audio2token(orig_samples, fetch_codes_batch, mel_fn=None, sample_rate: int = 24000, min_duration: int = 30, batch_size: int = 6,
+                rec_frame_rate: float = 12.5, reason_frame_rate: float = 5):
+    """reason_tokenizer.py:86-129 around `fetch_codes_batch` (AudioDiffusion1D.fetch_codes_batch): (1, N) samples at 24 kHz ->
+    (reason (1, 8, T_r), rec (1, 8, T_s)).  PINNED on tests/golden/tokenizer_host.npz.  The clip is self-concatenated until one
+    segment (30 s + 240 samples) fits (:101-102), doubled once more (:105), cut into int_max_len segments (:104-106), encoded
+    batch_size segments at a time (:110-122) — EVERY segment, as the reference does — and the token grid cropped to
+    int(dur * 12.5) + 1 / int(dur * 5) + 1 (:125-128)."""
+    audios = orig_samples if orig_samples.ndim == 2 else orig_samples.squeeze(0)
+    orig_length = audios.shape[-1]
+    min_samples = int(min_duration * sample_rate)
+    output_len = int(orig_length / float(sample_rate) * rec_frame_rate) + 1
+    output_len_reason = int(orig_length / float(sample_rate) * reason_frame_rate) + 1
+    while audios.shape[-1] < min_samples + 240:
+        audios = torch.cat([audios, audios], -1)
+    int_max_len = audios.shape[-1] // min_samples + 1
+    audios = torch.cat([audios, audios], -1)
+    audios = audios[:, :int(int_max_len * (min_samples + 240))]
+    audio_input = audios.reshape(1, -1, min_samples + 240).permute(1, 0, 2).reshape(-1, 1, min_samples + 240)
+    reason_list, rec_list = [], []
+    for i in range(0, audio_input.shape[0], batch_size):
+        chunk = audio_input[i:i + batch_size]
+        mels = mel_fn(chunk[:, 0, :]) if mel_fn is not None else None
+        reasoning_codes, rec_codes, _ = fetch_codes_batch(chunk, mels, additional_feats=[], return_reasoning_text=False)
+        reason_list.append(torch.cat(reasoning_codes, 1))
+        rec_list.append(torch.cat(rec_codes, 1))
+    reason = torch.cat(reason_list, 0).reshape(-1, 8).unsqueeze(0)
+    rec = torch.cat(rec_list, 0).reshape(-1, 8).unsqueeze(0)
+    return reason[:, :output_len_reason, :].transpose(1, 2), rec[:, :output_len, :].transpose(1, 2)
+
+
 # ---- torchaudio.functional.resample (reason_tokenizer.py:383-385) — PARITY UNPINNED: torchaudio is not installed ---------
 
 def resample(waveform, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):

@@ -22,6 +22,11 @@ if leg == "config3":
     print(bench.config3_leg(model, dev))
 elif leg == "batched":
     print(bench.batched_leg(model, dev))
+elif leg == "batched256":
+    print(bench.batched_leg(model, dev, B=256, frames=12, max_seq=128))
+elif leg == "batched_both":
+    print(bench.batched_leg(model, dev))
+    print(bench.batched_leg(model, dev, B=256, frames=12, max_seq=128))
 elif leg == "config5":
     print(bench.config5_leg(model, dev, frames=120))
 else:

@@ -575,10 +575,8 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
 //   tiled : 1.1 us per two-chunk stage when the grid is small (latency-bound), ~700 TFLOP/s bf16 when large.
 // UA2_SKINNY_MAX_ROWS=n overrides (skinny iff M <= n) for experiments.
 bool choose_skinny(const ua2_linear_args& a, int nt) {
-  static const int forced = [] {
-    const char* e = getenv("UA2_SKINNY_MAX_ROWS");
-    return e ? atoi(e) : -1;
-  }();
+  const char* e = getenv("UA2_SKINNY_MAX_ROWS");   // read per call (launches are captured into graphs: not a per-frame cost)
+  const int forced = e ? atoi(e) : -1;
   if (forced >= 0) return a.M <= forced;
   const double bytes = a.dtype == UA2_BF16 ? 2.0 : 4.0, kc = a.dtype == UA2_BF16 ? 32.0 : 16.0;
   const double w_bytes = (double)a.N * a.K * bytes * nt;
@@ -601,7 +599,13 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
   }
   UA2_LAUNCH_CHECK();
   const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
-  if (skinny_ok && (force == 4 || (force != 5 && choose_skinny(a, nt)))) {
+  // The weights-stationary form (ua2_skinny.hip) serves the model's bf16 shapes up to a few hundred rows: measured against
+  // the tiled kernel it wins up to 256 rows everywhere except the 128k-column lm_head (profiles/r3_skinny_sweep.txt).
+  const bool prefer2 = force != 5 && a.dtype == UA2_BF16 && a.M <= 320 && a.N < 32768;
+  const bool old_skinny = skinny_ok && (force == 4 || (force != 5 && choose_skinny(a, nt)));
+  if (prefer2 || old_skinny)
+    if (const int rc = ua2_skinny2_try_launch(a, geo, s); rc <= 0) return rc;
+  if (old_skinny) {
     switch (a.epilogue) {
       case UA2_EPI_STORE: launch_skinny<DT, UA2_EPI_STORE>(a, geo, s); break;
       case UA2_EPI_RESIDUAL: launch_skinny<DT, UA2_EPI_RESIDUAL>(a, geo, s); break;

@@ -14,6 +14,8 @@ int ua2_gemv_rows_per_tile(int dtype, int K);
 // large-M path; returns 1 when not applicable (no workspace, ATTN prologue, few rows)
 // force: 0 = only when M spans more than one row tile; 3 = whenever possible; 4 / 5 = likewise, skinny / tiled form
 int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force);
+// batched-decode form (ua2_skinny.hip): 0 = launched, 1 = shape outside its table (the older skinny kernel serves it)
+int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t s);
 
 // ---- fragments ----------------------------------------------------------------------------
 

@@ -1,0 +1,251 @@
+// Batched-decode form of ua2_linear (a few dozen to a few hundred rows: 64 live sequences per GPU, SURVEY.md §8d
+// config 4) — "weights stationary, operand streaming".
+//
+// Replaces the same reference code as ua2_gemv.hip (lit_model.py:382-511 qkv / proj, :591-595 LLaMAMLP; model_new.py:617-641
+// heads) when 17..~512 rows share a launch.  Contract: bit-identical, row by row, with the decode kernel: K is split over
+// `nw` contiguous chunk ranges exactly as ua2_gemv.hip splits it (one wave per range, an MFMA chain from zero each, partial
+// sums added in range order), so a row's bits are those of the B = 1 run whatever this kernel's tile parameters are.
+//
+// What changed against round 2's skinny kernel (ua2_gemm.hip, kept for fp32 and for shapes outside the table below), and why
+// (profiles/r3_notes.md):
+//   * the old kernel walked a wave's range in rounds of 4 chunks — weights AND operand fragments requested, then waited
+//     for, then multiplied — so every round exposed a full memory round trip (K = 8192: four of them), and at 64 rows the
+//     operand is 4 KiB per 1 KiB of weights: the launches cost 6-12 us more than the B = 1 GEMV on the same weights;
+//   * here a wave requests ALL the weight fragments of its range up front (non-temporal 1 KiB bursts straight to
+//     registers, exactly the decode kernel's pattern: the whole matrix is in flight at once) and keeps them — the weights
+//     are stationary; the packed operand fragments (L2-resident, written by the producer in fragment order) stream
+//     through a small register ring `LA` chunks ahead of the MFMAs;
+//   * a workgroup may take several PASSES of MT row tiles with the same resident weights (B = 256: the weights cross HBM
+//     and L2 once per 16 x MT x passes rows instead of once per 64), the ring running across the pass boundary;
+//   * CT column tiles per wave share each operand fragment (halves the L2 -> CU operand traffic where N is large enough
+//     that halving the grid still fills the chip).
+// Bound: HBM on the weights (the operand comes from L2: 64 rows x K x 2 B per workgroup — at 56 B/clk/CU that is 2.5 us at
+// K = 3072 and 6.8 us at K = 8192 per workgroup, in the shadow of the weight stream).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "ua2_common.h"
+#include "ua2_linear_common.h"
+
+namespace {
+
+constexpr int kRsrcFlags = 0x00020000;   // raw buffer, dword data format (gfx9 family)
+
+template <int EPI, int CT, int MT, int CH, int NWV, int LA>
+__global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int passes) {
+  constexpr int DT = UA2_BF16;
+  constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;   // weight matrices
+  constexpr int NS = NM * CT;                           // weight streams per wave: stream s = matrix s / CT, column tile s % CT
+  static_assert(CH % LA == 0 && LA <= CH, "the operand ring must tile a range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);          // [NWV][NS][MT][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int nchunks = NWV * CH;                     // checked by the launcher: K / KC == NWV * CH
+  const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
+  const int c0 = wave * CH;
+
+  // Addressing: buffer loads — a scalar resource + a scalar offset (tile, chunk) + ONE per-lane 32-bit offset, so a load
+  // costs no 64-bit vector address arithmetic and no address registers (with flat global loads the compiler kept a 64-bit
+  // VGPR pair per stream and spilled operand fragments at 16 waves per workgroup).
+  const unsigned voff = (unsigned)(c0 * 64 + lane) * 16u;
+  __amdgpu_buffer_rsrc_t wr[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int nt = min((int)blockIdx.x * CT + s % CT, ntiles - 1);
+    const char* base = reinterpret_cast<const char*>((s / CT) ? a.w1 : a.w0) + (size_t)nt * nchunks * 1024;
+    wr[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, nchunks * 1024, kRsrcFlags);
+  }
+  // the operand: [mtiles][nchunks] fragments of 1 KiB (< 4 GiB: the launcher checks)
+  const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(apack), 0, (unsigned)mtiles * (unsigned)(nchunks * 1024), kRsrcFlags);
+  const int mt_first = blockIdx.y * passes * MT;
+  // byte offset of row tile mt's fragments; clamped: a tile past M is read (valid memory) and dropped
+  auto aoff = [&](int mt) { return (unsigned)min(mt, mtiles - 1) * (unsigned)(nchunks * 1024); };
+  auto lda = [&](unsigned tile_off, int chunk) { return __builtin_amdgcn_raw_buffer_load_b128(ar, voff, tile_off + (unsigned)chunk * 1024u, 0); };
+
+  auto ldw = [&](int s, int chunk) { return __builtin_amdgcn_raw_buffer_load_b128(wr[s], voff, chunk * 1024, 2); };   // aux 2 = nt: streamed once
+
+  // Issue order: a wave's loads retire in order, so the first operand chunks (L2 hits, needed first) go out BEFORE the weight
+  // burst (HBM).  (A "rolling window" form — weights and operand of a chunk travelling together through a ring, consumed in
+  // issue order — was measured and lost 5-20 %: it caps the weight bytes in flight per wave at the ring depth,
+  // profiles/r3_skinny_sweep.txt.)
+  u32x4 af[LA][MT], wf[NS][CH];
+  {
+    unsigned o[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) o[mi] = aoff(mt_first + mi);
+#pragma unroll
+    for (int u = 0; u < LA; ++u)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[u][mi] = lda(o[mi], u);
+  }
+  __builtin_amdgcn_sched_barrier(0);                    // the machine scheduler may not hoist the weight burst above these
+#pragma unroll
+  for (int u = 0; u < CH; ++u)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wf[s][u] = ldw(s, u);
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int row = tid >> 4, col = tid & 15;
+  const int srcl = (((row >> 2) << 4) + col) * 4 + (row & 3);
+  for (int pass = 0;;) {                                 // the first pass is unconditional (the launcher never starts a workgroup past M):
+    const int mtp = mt_first + pass * MT;               // a guard in front of it lets the compiler sink the first operand loads below the burst
+    unsigned oc[MT], on[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) { oc[mi] = aoff(mtp + mi); on[mi] = aoff(mtp + MT + mi); }
+    f32x4 acc[NS][MT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[s][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        AFrag<DT> f;
+        f.v = af[u % LA][mi];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) f.mma(wf[s][u], acc[s][mi]);
+      }
+      // refill the slot just consumed: chunk u + LA of this pass, or the first chunks of the next pass (always requested —
+      // a branch around a load costs a full vmcnt(0) somewhere; past the last pass the clamped tile is read and dropped)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+        af[u % LA][mi] = (u + LA < CH) ? lda(oc[mi], u + LA) : lda(on[mi], u + LA - CH);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(&red[(((wave * NS + s) * MT) + mi) * 256 + lane * 4]) = acc[s][mi];
+    ua2_lds_barrier();                                   // LDS-only hand-off: the operand prefetch of the next pass stays in flight
+    if (tid < 256) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int nt = blockIdx.x * CT + ct;
+        if (nt >= ntiles) break;                         // uniform
+        int tile[NM];
+#pragma unroll
+        for (int t = 0; t < NM; ++t) tile[t] = nt;
+        EpiPre pre[MT];                                  // every row tile's epilogue loads before any store
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int m0 = (mtp + mi) * 16;
+          if (m0 >= a.M) break;                          // uniform over the workgroup
+          float v[NM];
+#pragma unroll
+          for (int t = 0; t < NM; ++t) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) sacc += red[(((w * NS + t * CT + ct) * MT) + mi) * 256 + srcl];
+            v[t] = sacc;
+          }
+          linear_epilogue<DT, EPI, NM>(a, v, tile, row, col, pre[mi], m0, min(16, a.M - m0));
+        }
+      }
+    }
+    if (++pass >= passes || mt_first + pass * MT >= mtiles) break;   // uniform
+    ua2_lds_barrier();                                   // `red` is rewritten by the next pass
+  }
+}
+
+// VGPRs a variant needs: resident weights + operand ring + accumulators + addressing / epilogue slack.  Variants over the
+// per-wave budget (512 per SIMD shared by NWV / 4 waves) spill and are not built.
+constexpr int regs_needed(int nm, int ct, int mt, int ch, int la) { return nm * ct * ch * 4 + la * mt * 4 + nm * ct * mt * 4 + 20; }
+
+struct Variant { int ct, mt, la, passes; };
+
+// experiment hook: UA2_SKINNY2="ct,mt,la,passes" (read per call); "off" disables the kernel
+bool env_variant(Variant& v, bool& off) {
+  const char* e = getenv("UA2_SKINNY2");
+  off = false;
+  if (!e) return false;
+  if (e[0] == 'o') { off = true; return false; }
+  return sscanf(e, "%d,%d,%d,%d", &v.ct, &v.mt, &v.la, &v.passes) == 4;
+}
+
+template <int EPI, int CT, int MT, int CH, int NWV, int LA>
+int launch_one(const ua2_linear_args& a, int passes, hipStream_t s) {
+  constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA>;
+  constexpr size_t smem = (size_t)NWV * NM * CT * MT * 1024;
+  if constexpr (smem > 160 * 1024) return 1;
+  ua2_allow_big_lds<kern>();
+  const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
+  const dim3 grid(ua2_ceil_div(ntiles, CT), ua2_ceil_div(mtiles, MT * passes));
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), passes);
+  return 0;
+}
+
+template <int EPI, int CH, int NWV>
+int launch_variant(const ua2_linear_args& a, const Variant& v, hipStream_t s) {
+  constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+#define UA2_SK(CT_, MT_, LA_)                                                                            \
+  if (v.ct == CT_ && v.mt == MT_ && v.la == LA_) {                                                       \
+    if constexpr (CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_) <= 2048 / NWV)                     \
+      return launch_one<EPI, CT_, MT_, CH, NWV, LA_>(a, v.passes, s);                                     \
+    return 1;                                                                                            \
+  }
+  UA2_SK(1, 4, 1) UA2_SK(1, 4, 2) UA2_SK(1, 2, 2)
+  UA2_SK(2, 4, 1) UA2_SK(2, 4, 2) UA2_SK(2, 2, 2)
+#undef UA2_SK
+  return 1;
+}
+
+// Tile parameters from the shape: measured, tools/ubench/skinny_shapes.py (profiles/r3_skinny_sweep.txt).  All variants give
+// the same bits, so this is purely a cost choice.  What the sweep says: the launch is bound by bytes INTO each CU (weights +
+// 64 rows x K of operand per workgroup, ~60-75 GB/s per CU achieved), so (i) two column tiles per wave wherever the weights
+// fit the registers and the grid stays >= ~96 column groups (halves the operand bytes per weight byte); (ii) when there are
+// fewer column groups than CUs, the rows are split over 256 / groups workgroups (the weights cross L2 twice, the operand
+// ingest per CU halves); (iii) otherwise one workgroup walks all rows in passes with its weights resident.
+Variant pick_variant(const ua2_linear_args& a, int waves, int ch, int nm) {
+  const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
+  const int budget = 2048 / waves;
+  Variant v{1, 4, 1, 1};
+  if (ntiles >= 192 && regs_needed(nm, 2, 2, ch, 2) <= budget) v.ct = 2;
+  const int groups = ua2_ceil_div(ntiles, v.ct);
+  const int ysplit = std::max(1, std::min(256 / groups, ua2_ceil_div(mtiles, 2)));
+  const int rows = ua2_ceil_div(mtiles, ysplit);            // row tiles per workgroup
+  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1) <= budget) ? 4 : 2;
+  v.la = (v.mt == 2 && ch % 2 == 0) ? 2 : 1;
+  v.passes = ua2_ceil_div(rows, v.mt);
+  return v;
+}
+
+}  // namespace
+
+// Returns 0 when launched, 1 when this problem is outside the kernel's table (the caller uses the older skinny kernel).
+int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t s) {
+  if (a.dtype != UA2_BF16) return 1;
+  if (a.K % 32) return 1;
+  const int nchunks = a.K / 32;
+  if (nchunks % geo.waves) return 1;
+  const int ch = nchunks / geo.waves;
+  const int nm = a.epilogue == UA2_EPI_SWIGLU ? 2 : 1;
+  Variant v = pick_variant(a, geo.waves, ch, nm);
+  bool off = false;
+  Variant ev;
+  const bool forced = env_variant(ev, off);
+  if (forced) v = ev;
+  if (off) return 1;
+  if (v.passes < 1) v.passes = 1;
+  int rc = 1;
+#define UA2_GEO(EPI_, CH_, NWV_) \
+  if (a.epilogue == EPI_ && ch == CH_ && geo.waves == NWV_) rc = launch_variant<EPI_, CH_, NWV_>(a, v, s);
+  // K = 3072: 12 ranges x 8 chunks (grids <= 320 tiles) or 8 x 12 (large grids: SwiGLU, lm_head)
+  UA2_GEO(UA2_EPI_QKV_ROPE, 8, 12) UA2_GEO(UA2_EPI_RESIDUAL, 8, 12) UA2_GEO(UA2_EPI_STORE, 8, 12)
+  UA2_GEO(UA2_EPI_SWIGLU, 12, 8) UA2_GEO(UA2_EPI_STORE, 12, 8) UA2_GEO(UA2_EPI_QKV_ROPE, 12, 8)
+  // K = 8192: 16 x 16
+  UA2_GEO(UA2_EPI_RESIDUAL, 16, 16)
+  // K = 2048: 16 x 4 (small grids) or 8 x 8 (SwiGLU, audio_head)
+  UA2_GEO(UA2_EPI_QKV_ROPE, 4, 16) UA2_GEO(UA2_EPI_RESIDUAL, 4, 16) UA2_GEO(UA2_EPI_STORE, 4, 16)
+  UA2_GEO(UA2_EPI_SWIGLU, 8, 8) UA2_GEO(UA2_EPI_STORE, 8, 8)
+#undef UA2_GEO
+  UA2_CHECK(!(forced && rc == 1), "UA2_SKINNY2=%d,%d,%d,%d is not built for this geometry (epilogue %d, %d ranges x %d chunks)", v.ct, v.mt,
+            v.la, v.passes, a.epilogue, geo.waves, ch);
+  if (rc == 0) UA2_LAUNCH_CHECK();
+  return rc;
+}

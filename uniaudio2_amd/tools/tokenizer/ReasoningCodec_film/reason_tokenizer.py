@@ -296,12 +296,14 @@ class ReasoningTokenizer:
             if self.latent_fn is not None:
                 lat = self.latent_fn(self.codes_to_condition(window), num_steps).float()
             elif i == 0:                                             # :271-276: random "true" latent, no in-context frames
-                first = torch.randn(B, L, self.model.sq_codec_latent, device=self.device)
+                # drawn from the CPU generator and moved, as the reference does (:235 `torch.randn(...).to(self.device)`): the
+                # device generator is consumed only by prepare_latents, in the reference's order
+                first = torch.randn(B, L, self.model.sq_codec_latent).to(self.device)
                 lat = self.model.inference_codes([window], None, first, L, 0, additional_feats=[], guidance_scale=1.5, num_steps=num_steps,
                                                  scenario="other_seg")
             else:                                                    # :277-284: the previous window's tail as in-context frames
                 true = latents[-1][:, -plan["ovlp_frames"]:, :]
-                pad = torch.randn(B, L - true.shape[1], true.shape[-1], device=self.device)
+                pad = torch.randn(B, L - true.shape[1], true.shape[-1]).to(self.device)       # :282, CPU generator as well
                 lat = self.model.inference_codes([window], None, torch.cat([true, pad], 1), L, true.shape[1], additional_feats=[],
                                                  guidance_scale=1.5, num_steps=num_steps, scenario="other_seg")
             latents.append(lat.float())
