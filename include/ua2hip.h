@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 3
+#define UA2_VERSION 4
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -255,9 +255,13 @@ int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32
  * ResidualVQ calls AudioDiffusion1D.py:388,529,535,544).  x [N,D] fp32 in codebook space (after any
  * project_in), emb [L,C,D] fp32, embT [L,D,C] = the same codebooks k-major (coalesced scan).
  * codes [N,L] int32; quantized [N,D] = sum of the chosen codewords (may be NULL).
- * d2 = sum_k fma(x_k-e_k, x_k-e_k, .), k ascending; lowest index wins ties (= oracle/rvq_oracle.c bit for bit). */
+ * d2 = sum_k fma(x_k-e_k, x_k-e_k, .), k ascending; lowest index wins ties (= oracle/rvq_oracle.c bit for bit).
+ * workspace (optional, >= ua2_rvq_workspace_bytes(N, L) bytes of device scratch): lets a launch with few vectors (one
+ * clip) split each level's codebook over several workgroups per group of 8 vectors (candidates merged by 64-bit atomic
+ * min, lowest index on ties); same codes and sums with or without it. */
 int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C, int32_t D,
-                   int32_t* codes, float* quantized, void* stream);
+                   int32_t* codes, float* quantized, void* workspace, size_t workspace_bytes, void* stream);
+size_t ua2_rvq_workspace_bytes(int64_t N, int32_t L);
 /* Lookup + sum over levels (core_vq.py:378-384; AudioDiffusion1D.py:577-583 get_output_from_indices). */
 int ua2_rvq_decode(const int32_t* codes, const float* emb, int64_t N, int32_t L, int32_t C, int32_t D, float* out,
                    void* stream);

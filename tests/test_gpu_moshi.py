@@ -86,3 +86,11 @@ def test_ring_cache_streams_past_the_linear_capacity():
         assert m._plan["ring_pages"] > 0 and m._plan["k"][0].shape[0] == m._plan["ring_pages"]      # a handful of pages, not T / 64
     got = torch.cat(parts, 1)
     assert got.shape == whole.shape and torch.equal(got, whole)
+    # the ring plan of the finished session must not serve a later whole-sequence call (T = 2500 rows in one launch
+    # would overwrite ring slots that earlier rows still attend to): forward() re-plans a linear cache
+    again = m(x)
+    assert m._plan["ring_pages"] == 0 and torch.equal(again, whole)
+    with pytest.raises(RuntimeError):
+        with m.streaming(1):
+            m(x[:, :10].contiguous())
+        m(x[:, 10:20].contiguous(), offset=10)      # explicit offset against a cache that is now a ring: refused, not silently wrong

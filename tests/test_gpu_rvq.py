@@ -50,3 +50,27 @@ def test_rvq_gpu_bit_exact_at_codec_sizes(L, C, D, N):
     c2, _ = ops.rvq_encode(emb[0, pick].contiguous().cuda(), emb[:1].contiguous().cuda())
     d0 = ((emb[0, pick][:, None, :] - emb[0][None]) ** 2).sum(-1)
     assert (c2.cpu()[:, 0].long() == d0.argmin(-1)).all()
+
+
+def test_rvq_split_codebook_ties_pick_the_lowest_index():
+    """One clip (few vectors) takes the split-codebook kernel: candidates from different workgroups meet in a 64-bit atomic
+    min keyed (distance bits, index).  Duplicate codewords placed in different codebook splits are exactly equidistant: the
+    lowest index must win, as in the oracle (strict '<' in ascending order) and in torch.argmin."""
+    from uniaudio2_amd import ops
+    g = torch.Generator().manual_seed(7)
+    L, C, D, N = 3, 8192, 32, 40
+    emb = torch.randn(L, C, D, generator=g)
+    x = torch.randn(N, D, generator=g)
+    for l in range(L):
+        for a, b in ((17, 5000), (300, 8191), (4095, 4096), (1, 7000)):
+            emb[l, b] = emb[l, a]
+    x[0] = emb[0, 5000]; x[1] = emb[0, 8191]; x[2] = emb[0, 4096]; x[3] = emb[0, 7000]       # distance exactly 0 to both copies
+    codes, q = ops.rvq_encode(x.cuda(), emb.cuda())
+    o_codes, o_q = rvq_oracle.rvq_encode(x.numpy(), emb.numpy())
+    assert codes[:4, 0].tolist() == [17, 300, 4095, 1]
+    np.testing.assert_array_equal(codes.cpu().numpy(), o_codes)
+    np.testing.assert_array_equal(q.cpu().numpy(), o_q)
+    # repeated launches reuse nothing from the previous one (the workspace is re-initialised by the call)
+    for _ in range(3):
+        c2, _ = ops.rvq_encode(x.cuda(), emb.cuda())
+        assert torch.equal(c2, codes)

@@ -26,7 +26,9 @@ from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer import R
 G = np.load(os.path.join(HERE, "golden", "tokenizer_host.npz"))
 
 
-def check_t2a(T, calls, wave):
+def check_t2a(T, calls, wave, exact=True):
+    """exact: the stand-ins ran on the CPU, as in the golden run, so every float matches bit for bit; on cuda the stand-ins' sin /
+    cos differ from the CPU's in the last bits (the host logic under test does not), so the waveform gets a 1e-5 tolerance there."""
     k = f"t2a_{T}_"
     assert len(calls) == G[k + "windows"].shape[0]
     for i, c in enumerate(calls):
@@ -35,11 +37,18 @@ def check_t2a(T, calls, wave):
         ic = c["incontext"]
         np.testing.assert_array_equal(c["true"][0, ic:ic + 3, :5].numpy(), G[k + "noise"][i])          # same draws, same order
         np.testing.assert_array_equal(c["true"][0, -2:, -5:].numpy(), G[k + "noise_tail"][i])
-        np.testing.assert_array_equal(c["true"][0, :2, :5].numpy(), G[k + "ctx_head"][i])             # the in-context chain
+        if exact or ic == 0:
+            np.testing.assert_array_equal(c["true"][0, :2, :5].numpy(), G[k + "ctx_head"][i])         # the in-context chain
+        else:
+            np.testing.assert_allclose(c["true"][0, :2, :5].numpy(), G[k + "ctx_head"][i], atol=1e-5, rtol=0)
     assert wave.dtype == torch.float32 and wave.device.type == "cpu"
     assert tuple(wave.shape) == tuple(G[k + "wave_shape"])
-    np.testing.assert_array_equal(wave[0, ::WAVE_STRIDE].numpy(), G[k + "wave_sub"])
-    np.testing.assert_array_equal(wave_digest(wave), G[k + "wave_digest"])
+    if exact:
+        np.testing.assert_array_equal(wave[0, ::WAVE_STRIDE].numpy(), G[k + "wave_sub"])
+        np.testing.assert_array_equal(wave_digest(wave), G[k + "wave_digest"])
+    else:
+        np.testing.assert_allclose(wave[0, ::WAVE_STRIDE].numpy(), G[k + "wave_sub"], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(wave_digest(wave), G[k + "wave_digest"], rtol=1e-5)
 
 
 @pytest.mark.parametrize("T", T_CASES)
@@ -55,7 +64,7 @@ def product_t2a(T, device):
     tok = ReasoningTokenizer(sq_codec=codec, model=model, device=device)
     torch.manual_seed(SEED)
     wave = tok.token2audio_no_reason(make_codes(T), False, duration=20, guidance_scale=1.5, num_steps=7, disable_progress=True)
-    check_t2a(T, model.calls, wave)
+    check_t2a(T, model.calls, wave, exact=(device == "cpu"))
 
 
 @pytest.mark.parametrize("T", T_CASES)

@@ -98,7 +98,8 @@ _EXPORTS = {
     "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
     "ua2_conv1d": (C.c_int, [C.POINTER(Conv1dArgs), vp]),
     "ua2_avgpool1d": (C.c_int, [vp, vp, i64, i32, i32, vp]),
-    "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
+    "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, C.c_size_t, vp]),
+    "ua2_rvq_workspace_bytes": (C.c_size_t, [i64, i32]),
     "ua2_rvq_decode": (C.c_int, [vp, vp, i64, i32, i32, i32, vp, vp]),
     "ua2_ew_fma": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp]),
     "ua2_ew_act": (C.c_int, [vp, vp, i64, i32, vp]),

@@ -17,6 +17,20 @@
 // read 64 consecutive codewords of one k), reusing every loaded value for the VB vectors; the
 // arg-min is a wavefront shuffle reduction on (distance, index) pairs, then one LDS hop across the
 // four waves.
+//
+// Few vectors (one 10-s clip = 125 vectors): the form above gives 16-125 workgroups, each scanning all 6 MiB of
+// codebooks with 32 serial codeword iterations per lane — latency-bound at 1.5 % of the vector peak (255 us, unchanged over
+// two rounds).  `rvq_encode_split_kernel` splits the CODEBOOK over S workgroups per group of 8 vectors (grid = groups x S
+// ~ 256: one per CU): every workgroup scans C / S codewords of the level for its 8 vectors (each loaded value reused 8
+// times), publishes its (distance, index) candidates with one 64-bit agent-scope atomic min per vector — the key is
+// distance bits << 32 | index, so the minimum is the smallest distance and, among equal distances, the lowest index: the
+// oracle's tie rule — and the S workgroups of a group meet at a counter (arrivals after `s_waitcnt vmcnt(0)`, relaxed
+// polls: the cheap forms of profiles/r2_gridbar.txt) before each of them applies the same residual update.  The per-codeword
+// arithmetic is untouched: bit-exact against oracle/rvq_oracle.c.  The S x groups workgroups are co-resident by
+// construction (<= 512 workgroups of 256 threads), so the spin cannot deadlock; it is bounded anyway (a stuck peer
+// flags an error code instead of hanging the GPU).
+#include <stdlib.h>
+
 #include "ua2_common.h"
 
 namespace {
@@ -98,6 +112,104 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_kernel(const float* __res
     for (int idx = tid; idx < nv * D; idx += kThreads) quantized[n0 * D + idx] = qs[idx];
 }
 
+constexpr int kSplitVB = 8;
+constexpr unsigned long long kKeyInit = ~0ull;          // the workspace is memset to 0xff: keys start at "+inf, no index"
+
+// workspace layout: keys [L][groups * 8] u64, then counters [L][groups] u32 (all bytes 0xff before the launch), then one
+// u32 error flag (0xffffffff = clean)
+template <int kVB>
+__global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float* __restrict__ x, const float* __restrict__ emb,
+                                                                    const float* __restrict__ embT, int64_t N, int L, int C, int D,
+                                                                    int32_t* __restrict__ codes, float* __restrict__ quantized,
+                                                                    unsigned long long* keys, unsigned* counters, unsigned* err) {
+  extern __shared__ float sm[];
+  float* res = sm;                 // [kVB][D]
+  float* qs = res + kVB * D;       // [kVB][D]
+  float* wv = qs + kVB * D;        // [4][kVB] wave minima
+  int* wi = reinterpret_cast<int*>(wv + 4 * kVB);
+  int* best_i = wi + 4 * kVB;      // [kVB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x, S = gridDim.y, cs = blockIdx.y, groups = gridDim.x;
+  const int64_t n0 = (int64_t)grp * kVB;
+  const int nv = (int)min((int64_t)kVB, N - n0);
+  const int c_lo = (int)((int64_t)C * cs / S), c_hi = (int)((int64_t)C * (cs + 1) / S);
+  for (int idx = tid; idx < kVB * D; idx += kThreads) {
+    const int v = idx / D, k = idx - v * D;
+    res[idx] = (v < nv) ? x[(n0 + v) * D + k] : 0.f;
+    qs[idx] = 0.f;
+  }
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    const float* eT = embT + (size_t)l * D * C;
+    float bv[kVB];
+    int bi[kVB];
+#pragma unroll
+    for (int v = 0; v < kVB; ++v) { bv[v] = INFINITY; bi[v] = 0x7fffffff; }
+    for (int c = c_lo + tid; c < c_hi; c += kThreads) {
+      float acc[kVB];
+#pragma unroll
+      for (int v = 0; v < kVB; ++v) acc[v] = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < D; ++k) {
+        const float e = eT[(size_t)k * C + c];
+#pragma unroll
+        for (int v = 0; v < kVB; ++v) {
+          const float d = __fsub_rn(res[v * D + k], e);
+          acc[v] = __fmaf_rn(d, d, acc[v]);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < kVB; ++v)
+        if (acc[v] < bv[v]) { bv[v] = acc[v]; bi[v] = c; }   // c ascends per lane: strict '<' keeps the first
+    }
+#pragma unroll
+    for (int v = 0; v < kVB; ++v) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) argmin_pair(bv[v], bi[v], __shfl_xor(bv[v], o), __shfl_xor(bi[v], o));
+      if (lane == 0) { wv[wave * kVB + v] = bv[v]; wi[wave * kVB + v] = bi[v]; }
+    }
+    __syncthreads();
+    unsigned long long* lkeys = keys + ((size_t)l * groups + grp) * kVB;
+    unsigned* cnt = counters + (size_t)l * groups + grp;
+    if (tid < kVB) {
+      float v0 = wv[tid];
+      int i0 = wi[tid];
+      for (int w = 1; w < 4; ++w) argmin_pair(v0, i0, wv[w * kVB + tid], wi[w * kVB + tid]);
+      // distances are >= +0: their bit patterns order like the floats; NaN (never the minimum in the oracle either) sorts last
+      const unsigned long long key = ((unsigned long long)__float_as_uint(v0) << 32) | (unsigned)i0;
+      if (i0 != 0x7fffffff) __hip_atomic_fetch_min(lkeys + tid, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the candidates are performed before this workgroup arrives
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 0xffffffff + S arrivals = S - 1
+      int spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(S - 1)) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+    if (tid < kVB) {
+      const unsigned long long key = __hip_atomic_load(lkeys + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int i0 = (int)(unsigned)(key & 0xffffffffull);
+      best_i[tid] = (key == kKeyInit) ? 0 : i0;             // all-NaN column: the oracle's `bi = 0`
+      if (cs == 0 && tid < nv) codes[(n0 + tid) * L + l] = best_i[tid];
+    }
+    __syncthreads();
+    const float* eR = emb + (size_t)l * C * D;
+    for (int idx = tid; idx < kVB * D; idx += kThreads) {
+      const int v = idx / D, k = idx - v * D;
+      const float e = eR[(size_t)best_i[v] * D + k];
+      res[idx] = __fsub_rn(res[idx], e);      // residual = residual - quantized   (core_vq.py:372)
+      qs[idx] = __fadd_rn(qs[idx], e);
+    }
+    __syncthreads();
+  }
+  if (quantized && cs == 0)
+    for (int idx = tid; idx < nv * D; idx += kThreads) quantized[n0 * D + idx] = qs[idx];
+}
+
 __global__ void rvq_decode_kernel(const int32_t* __restrict__ codes, const float* __restrict__ emb, int64_t N, int L,
                                   int C, int D, float* __restrict__ out) {
   const int64_t total = N * D;
@@ -112,15 +224,46 @@ __global__ void rvq_decode_kernel(const int32_t* __restrict__ codes, const float
 
 }  // namespace
 
+// groups of 8 vectors, codebook splits (a power of two), for the split form; S == 1: not worth it / not possible
+static void rvq_split_plan(int64_t N, int C, int* groups, int* S) {
+  *groups = (int)((N + kSplitVB - 1) / kSplitVB);
+  int s = 1;
+  while (s < 32 && (int64_t)*groups * (s * 2) <= 384 && C / (s * 2) >= kThreads) s *= 2;
+  *S = (*groups < 128) ? s : 1;
+}
+
+extern "C" size_t ua2_rvq_workspace_bytes(int64_t N, int32_t L) {
+  if (N <= 0 || L <= 0) return 0;
+  const size_t groups = (size_t)((N + kSplitVB - 1) / kSplitVB);
+  return (size_t)L * groups * kSplitVB * 8 + (size_t)L * groups * 4 + 8;
+}
+
 extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C,
-                              int32_t D, int32_t* codes, float* quantized, void* stream) {
+                              int32_t D, int32_t* codes, float* quantized, void* workspace, size_t workspace_bytes, void* stream) {
   UA2_CHECK(x && emb && embT && codes && N > 0 && L > 0 && C > 0 && D > 0 && D <= 1024, "ua2_rvq_encode: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int groups = 0, S = 1;
+  rvq_split_plan(N, C, &groups, &S);
+  static const bool no_split = getenv("UA2_RVQ_NO_SPLIT") != nullptr;      // A/B hook
+  if (S > 1 && workspace && !no_split) {
+    const size_t need = ua2_rvq_workspace_bytes(N, L);
+    UA2_CHECK(workspace_bytes >= need, "ua2_rvq_encode: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    UA2_HIP(hipMemsetAsync(workspace, 0xff, need, s));
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
+    unsigned* counters = reinterpret_cast<unsigned*>(keys + (size_t)L * groups * kSplitVB);
+    unsigned* err = counters + (size_t)L * groups;
+    const size_t smem = (size_t)(2 * kSplitVB * D + 4 * kSplitVB) * sizeof(float) + (size_t)(4 * kSplitVB + kSplitVB) * sizeof(int);
+    UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
+    hipLaunchKernelGGL(rvq_encode_split_kernel<kSplitVB>, dim3(groups, S), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes,
+                       quantized, keys, counters, err);
+    UA2_LAUNCH_CHECK();
+    return 0;
+  }
   int vb = 8;
   while (vb > 1 && (N + vb - 1) / vb < 256) vb = vb == 8 ? 2 : 1;
   const size_t smem = (size_t)(2 * vb * D + 4 * vb) * sizeof(float) + (size_t)(4 * vb + vb) * sizeof(int);
   UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
   const int blocks = (int)((N + vb - 1) / vb);
-  hipStream_t s = (hipStream_t)stream;
   if (vb == 8) hipLaunchKernelGGL(rvq_encode_kernel<8>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
   else if (vb == 2) hipLaunchKernelGGL(rvq_encode_kernel<2>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
   else hipLaunchKernelGGL(rvq_encode_kernel<1>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);

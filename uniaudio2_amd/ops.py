@@ -184,7 +184,8 @@ def rvq_encode(x, emb, embT=None):
         embT = emb.transpose(1, 2).contiguous()
     codes = torch.empty(N, L, dtype=torch.int32, device=x.device)
     q = torch.empty(N, D, dtype=torch.float32, device=x.device)
-    check(lib.ua2_rvq_encode(ptr(x), ptr(emb), ptr(embT), N, L, Cc, D, ptr(codes), ptr(q), stream()), "ua2_rvq_encode")
+    ws = torch.empty(lib.ua2_rvq_workspace_bytes(N, L), dtype=torch.uint8, device=x.device)
+    check(lib.ua2_rvq_encode(ptr(x), ptr(emb), ptr(embT), N, L, Cc, D, ptr(codes), ptr(q), ptr(ws), ws.numel(), stream()), "ua2_rvq_encode")
     return codes, q
 
 

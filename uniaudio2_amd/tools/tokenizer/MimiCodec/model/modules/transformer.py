@@ -252,7 +252,8 @@ class StreamingTransformer(StreamingModule):
             state["offset"] = offset + x.shape[1]
             if self.context:                                  # finite context: ring cache, unbounded session length
                 if self._plan is None or not self._plan["ring_pages"] or self._plan_batch < x.shape[0]:
-                    self.prepare(max_batch=x.shape[0], max_seq_length=self.rope_capacity, ring=True)
+                    self.prepare(max_batch=x.shape[0], max_seq_length=self.rope_capacity, ring=True,
+                                 **(dict(dtype=self._plan["dtype"]) if self._plan is not None else {}))
                 if offset + x.shape[1] > self.rope_capacity and self.rope is not None:
                     raise RuntimeError(f"the RoPE table covers {self.rope_capacity} positions; raise rope_capacity for longer sessions")
                 if x.shape[1] > self.ring_chunk:       # keep (context + positions per launch) inside the ring
@@ -262,9 +263,23 @@ class StreamingTransformer(StreamingModule):
                 if offset + x.shape[1] > self.streaming_capacity:
                     raise RuntimeError(f"streaming past {self.streaming_capacity} positions without a context (an unbounded cache)")
                 if self._plan is None or self._plan_capacity < self.streaming_capacity or self._plan_batch < x.shape[0]:
-                    self.prepare(max_batch=x.shape[0], max_seq_length=self.streaming_capacity)
-        if self._plan is None:
-            self.prepare(max_batch=x.shape[0], max_seq_length=max(UA2_PAGE, offset + x.shape[1]))
+                    self.prepare(max_batch=x.shape[0], max_seq_length=self.streaming_capacity,
+                                 **(dict(dtype=self._plan["dtype"]) if self._plan is not None else {}))
+        if state is None:
+            # Whole-sequence / explicit-offset calls need a LINEAR cache that covers every position of the launch.  A plan left
+            # behind by a streaming session with a finite context is a ring of a few pages: the QKV epilogue writes all T rows
+            # before attention runs, so T > ring span would overwrite slots that earlier rows of the same launch still attend to
+            # (silently wrong output).  Never reuse it here; and never run a linear plan past its capacity or batch.
+            need = max(UA2_PAGE, offset + x.shape[1])
+            stale = self._plan is None or self._plan["ring_pages"] > 0 or self._plan_capacity < need or self._plan_batch < x.shape[0]
+            if stale:
+                if offset > 0:
+                    raise RuntimeError("forward(offset > 0) continues a cache this plan does not hold (ring plan of a streaming session, or "
+                                       f"capacity {self._plan_capacity} < {need}): call prepare(max_batch, max_seq_length) before the first chunk")
+                kw = dict(dtype=self._plan["dtype"]) if self._plan is not None else {}      # keep the numerics contract the caller chose
+                self.prepare(max_batch=x.shape[0], max_seq_length=need, **kw)
+        elif self._plan["ring_pages"] > 0:
+            assert x.shape[1] <= self.ring_chunk, "a ring-cached launch may span at most ring_chunk positions"
         B, T, Cc = x.shape
         dev = x.device
         out = x.float().contiguous().clone()
