@@ -32,6 +32,11 @@ SEM_CARD, REASON_CARD = 8196, 4100          # V_a = 12296 (placeholder sizes; th
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+SCALAR_CFG = dict(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
+                  downsample_kernel_sizes=[4, 8, 8, 10, 6], upsample_factors=[3, 5, 4, 4, 2], upsample_kernel_sizes=[6, 10, 8, 8, 4],
+                  latent_hidden_dim=136, default_kernel_size=7, delay_kernel_size=5, init_channel=32, res_kernel_size=7)   # placeholder widths
+
+
 def model_args():
     from uniaudio2_amd.llm_models.model_new import ModelArgs
     return ModelArgs(llm_name="Llama-3.2-3B", decoder_name="Llama-3.2-300M", llm_pretrained_model="",
@@ -115,7 +120,7 @@ def roofline_leg(model):
             "algorithmic_bytes_per_launch": int(per_launch_bytes)}
 
 
-def codec_leg(dev):
+def codec_leg(dev, cpu=False):
     """Codec side of the metric ("codec RTF"): the in-scope deterministic stage-2 sub-graph on one 20-s
     window — ScalarModel.decode of a (1, 136, 500) latent -> 480 000 samples — and the RVQ search of a
     10-s clip (125 frames x (1+1+6) levels of 8192 x 32).  Channel widths / strides live in the
@@ -124,10 +129,7 @@ def codec_leg(dev):
     from uniaudio2_amd import ops
     from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
     torch.manual_seed(1)
-    sq = ScalarModel(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
-                     downsample_kernel_sizes=[4, 8, 8, 10, 6], upsample_factors=[3, 5, 4, 4, 2],
-                     upsample_kernel_sizes=[6, 10, 8, 8, 4], latent_hidden_dim=136, default_kernel_size=7,
-                     delay_kernel_size=5, init_channel=32, res_kernel_size=7).to(dev).prepare()
+    sq = ScalarModel(**SCALAR_CFG).to(dev).prepare()
     lat = torch.tanh(torch.randn(1, 136, 500, device=dev))
     # algorithmic work of one decode: every ua2_conv1d launch's 2 * B * Cout * Tout * Cin * K flops and its
     # activation + weight bytes (counted by wrapping the op for one call)
@@ -162,13 +164,88 @@ def codec_leg(dev):
     for _ in range(10):
         ops.rvq_encode(x, emb, embT)
     e1.record(); torch.cuda.synchronize()
-    return {"scalar_decode_ms_per_20s_window": round(dec_ms, 3), "scalar_decode_rtf": round(dec_ms / 1e3 / (wav.shape[-1] / 24000.0), 6),
-            # exact-fp32 implicit GEMM on v_mfma_f32_16x16x4_f32: dense f32 MFMA peak = 1/16 of the bf16 one (2.5 PFLOP/s / 16)
-            "scalar_decode_conv_launches": work["launches"], "scalar_decode_gflop": round(work["flop"] / 1e9, 2),
-            "scalar_decode_tflops": round(work["flop"] / (dec_ms * 1e-3) / 1e12, 2),
-            "scalar_decode_frac_f32_mfma_peak": round(work["flop"] / (dec_ms * 1e-3) / (2.5e15 / 16), 4),
-            "scalar_decode_algorithmic_GBps": round(work["bytes"] / (dec_ms * 1e-3) / 1e9, 1),
-            "rvq_encode_us_125x6x8192x32": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "config": "placeholder init_channel=32, hop 960"}
+    rvq_us = e0.elapsed_time(e1) / 10 * 1e3
+    res = {"scalar_decode_ms_per_20s_window": round(dec_ms, 3), "scalar_decode_rtf": round(dec_ms / 1e3 / (wav.shape[-1] / 24000.0), 6),
+           "scalar_decode_conv_launches": work["launches"], "scalar_decode_gflop": round(work["flop"] / 1e9, 2),
+           "scalar_decode_tflops": round(work["flop"] / (dec_ms * 1e-3) / 1e12, 2),
+           # the decode-side kernels split every fp32 operand into bf16 hi + lo and issue THREE bf16 MFMAs per product
+           # (csrc/ua2_conv.hip): against the dense bf16 peak the issued flops are 3x the useful ones
+           "scalar_decode_frac_bf16_mfma_incl_x3": round(3.0 * work["flop"] / (dec_ms * 1e-3) / 2.5e15, 4),
+           # algorithmic bytes (every launch's input + output (+ residual) tensors and weights once, fp32) over the time,
+           # against the 8 TB/s HBM peak: the roofline that bounds this stack (north_star bar: 0.60)
+           "scalar_decode_algorithmic_GBps": round(work["bytes"] / (dec_ms * 1e-3) / 1e9, 1),
+           "scalar_decode_frac_hbm": round(work["bytes"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "rvq_encode_us_125x6x8192x32": round(rvq_us, 1), "config": "placeholder init_channel=32, hop 960"}
+    if cpu:
+        res["cpu_baseline"] = codec_cpu_baseline(sq, lat, x, emb, dec_ms, rvq_us)
+    return res
+
+
+def host_cpu_budget():
+    """What this process may actually use: logical cores, scheduler affinity, cgroup quota (cpu.max) — `os.cpu_count()` alone
+    said 256 on a box where 8 threads were the optimum and 256 threads ran 25x slower."""
+    info = {"logical": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity"] = info["logical"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    info["cgroup_cpus"] = None if quota is None else round(quota, 2)
+    usable = min(info["logical"], info["affinity"])
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.999)))
+    info["usable"] = usable
+    return info
+
+
+def codec_cpu_baseline(sq, lat, x, emb, gpu_dec_ms, gpu_rvq_us):
+    """the codec half of the metric on the host beside the GPU numbers — `ScalarModel.decode` of the same
+    (1, 136, 500) latent through the CPU oracle (oracle/codec_oracle.py, plain PyTorch fp32 convolutions: the reference's own
+    arithmetic) and the RVQ search of the same 125 x 6 x 8192 x 32 problem through the C oracle (one thread, the scalar port)."""
+    import numpy as np
+    from oracle import rvq_oracle
+    from oracle.codec_oracle import ScalarOracle
+    budget = host_cpu_budget()
+    threads = min(budget["usable"], 16)
+    sd = {k: v.detach().to("cpu", torch.float32) for k, v in sq.state_dict().items()}
+    old = torch.get_num_threads()
+    out = {"cores": threads, "kind": "port", "host_cpu_budget": budget}
+    try:
+        torch.set_num_threads(threads)
+        orc = ScalarOracle(sd, SCALAR_CFG)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            w = orc.decode(lat.detach().cpu())
+            dec_s = time.perf_counter() - t0
+        out.update({"scalar_decode_s_per_20s_window": round(dec_s, 3), "scalar_decode_rtf": round(dec_s / (w.shape[-1] / 24000.0), 5),
+                    "gpu_speedup_scalar_decode": round(dec_s * 1e3 / gpu_dec_ms, 1)})
+    except Exception as e:  # noqa: BLE001 — an information leg must not take the bench line down
+        out["scalar_decode_error"] = repr(e)[:200]
+    finally:
+        torch.set_num_threads(old)
+    try:
+        xs, es = np.ascontiguousarray(x.cpu().numpy()), np.ascontiguousarray(emb.cpu().numpy())
+        t0 = time.perf_counter()
+        rvq_oracle.rvq_encode(xs, es)
+        rvq_s = time.perf_counter() - t0
+        out.update({"rvq_encode_ms_125x6x8192x32_1thread": round(rvq_s * 1e3, 1), "gpu_speedup_rvq": round(rvq_s * 1e6 / gpu_rvq_us, 1)})
+    except Exception as e:  # noqa: BLE001
+        out["rvq_error"] = repr(e)[:200]
+    out["sample"] = "one 20-s window (1, 136, 500) latent -> 480 000 samples; one 10-s clip's 125 vectors x 6 levels"
+    return out
 
 
 def stage2_leg(dev, steps=10):
@@ -191,10 +268,7 @@ def stage2_leg(dev, steps=10):
             if n_.endswith("_codebook.embed"):
                 b_.normal_(0, 0.5)
     model = model.to(dev).prepare()
-    sq = ScalarModel(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
-                     downsample_kernel_sizes=[4, 8, 8, 10, 6], upsample_factors=[3, 5, 4, 4, 2],
-                     upsample_kernel_sizes=[6, 10, 8, 8, 4], latent_hidden_dim=136, default_kernel_size=7,
-                     delay_kernel_size=5, init_channel=32, res_kernel_size=7).to(dev).prepare()
+    sq = ScalarModel(**SCALAR_CFG).to(dev).prepare()
     tok = ReasoningTokenizer(sq_codec=sq, model=model, device=dev)
     codes = torch.randint(0, 8192, (8, 250))
     tok.detokenize_no_reason(codes, steps=2)                       # warm: packs, graph capture
@@ -288,7 +362,8 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
     tk, mk = tokens.cpu(), mask.cpu()
     L = tk.size(1)
     pos = torch.arange(0, L).unsqueeze(0)
-    ncores = os.cpu_count() or 1
+    budget = host_cpu_budget()
+    ncores = budget["usable"]                      # affinity / cgroup-limited, not os.cpu_count()
 
     def run(threads, frames, prefill=True):
         """-> (prefill seconds or None, per-frame seconds list, (frames, 9) ids)"""
@@ -313,7 +388,7 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
     old = torch.get_num_threads()
     try:
         # Tall: pick the thread count by one frame each (no prefill cost: the cache content does not change the timing)
-        cands = sorted({t for t in (8, 16, 32, 64, ncores // 2, ncores) if 1 <= t <= ncores})
+        cands = sorted({t for t in (2, 4, 8, 16, 32, 64, ncores // 2, ncores) if 1 <= t <= ncores})
         o.reset_caches()
         sweep = {}
         for t in cands:
@@ -331,8 +406,10 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
     f_all, f_1 = statistics.median(per_all), statistics.median(per_1)
     whole = 8 * FRAMES / (pre_all + FRAMES * f_all)
     return {"value": round(whole, 2), "unit": "audio tokens/s", "cores": best, "kind": "port",
-            "sample": f"fp32 oracle, B=1: {L - 1}-row prefill + {frames_all} greedy frames at Tall={best} threads (of {ncores} "
-                      f"logical cores; sweep {{{', '.join(f'{t}: {v * 1e3:.0f} ms/frame' for t, v in sweep.items())}}}), "
+            "host_cpu_budget": budget,
+            "sample": f"fp32 oracle, B=1: {L - 1}-row prefill + {frames_all} greedy frames at Tall={best} threads (host budget: "
+                      f"{budget['logical']} logical cores, affinity {budget['affinity']}, cgroup cpu.max {budget['cgroup_cpus']} -> {ncores} usable; "
+                      f"sweep {{{', '.join(f'{t}: {v * 1e3:.0f} ms/frame' for t, v in sweep.items())}}}), "
                       f"{frames_t1} frames at T1; value = 8*{FRAMES} tokens / (prefill + {FRAMES} x median frame)",
             "tall": {"threads": best, "prefill_s": round(pre_all, 3), "ms_per_frame_median": round(f_all * 1e3, 1),
                      "decode_audio_tokens_per_s": round(8 / f_all, 2)},
@@ -501,6 +578,14 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms_frame = e0.elapsed_time(e1) / 64
+    # per-frame latency distribution (p50 / p99): 200 frames launched one by one, an event pair around each
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(101)]
+    utterance(model, tokens, mask, frames=2)
+    evs[0].record()
+    model.generate_frames(100, 1, 0, reason_eos=-1, reason_card=REASON_CARD, frame_events=evs[1:])
+    torch.cuda.synchronize()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(100))
+    p50, p99 = per[49], per[98]
 
     audio_tokens = 8 * FRAMES * a.steps * world
     res = {"metric": "audio tokens/sec (TTS greedy)", "value": round(audio_tokens / dt, 1), "unit": "audio tokens/s",
@@ -510,7 +595,8 @@ def main():
                                   f"{PROMPT_LEN}-token prompt + {FRAMES} frames x (8 audio + 1 text) tokens; "
                                   "Llama-3.2-3B backbone + 3L/2L experts + 4L local decoder x8, V_a=12296, random init",
                       "parallelism": f"dp{world} (one utterance per GPU, RCCL all-gather of token tensors)"},
-           "decode_ms_per_frame": round(ms_frame, 3), "decode_frames_per_s": round(1e3 / ms_frame, 1)}
+           "decode_ms_per_frame": round(ms_frame, 3), "decode_frames_per_s": round(1e3 / ms_frame, 1),
+           "decode_ms_per_frame_p50": round(p50, 3), "decode_ms_per_frame_p99": round(p99, 3)}
     solo = rank == 0 and world == 1
     if solo and not a.no_roofline:
         res["roofline"] = roofline_leg(model)
@@ -525,7 +611,7 @@ def main():
                                "codec's ResidualVQ is restated from vector_quantize_pytorch==1.27.15's published algorithm and is "
                                "parity-UNPINNED against the package itself (absent here)")
     if solo and not a.no_legs:
-        res["codec"] = codec_leg(dev)
+        res["codec"] = codec_leg(dev, cpu=not a.no_cpu_baseline)
         res["codec"]["stage2_codes_to_wav"] = stage2_leg(dev)
         res["config5_ttm_500_frames"] = config5_leg(model, dev)
         res["batched_decode"] = batched_leg(model, dev)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_kernel(const float* __res
       float acc[kVB];
 #pragma unroll
       for (int v = 0; v < kVB; ++v) acc[v] = 0.f;
-#pragma unroll 8
+#pragma unroll 32
       for (int k = 0; k < D; ++k) {
         const float e = eT[(size_t)k * C + c];
 #pragma unroll
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_kernel(const float* __res
 constexpr int kSplitVB = 8;
 constexpr unsigned long long kKeyInit = ~0ull;          // the workspace is memset to 0xff: keys start at "+inf, no index"
 
-// workspace layout: keys [L][groups * 8] u64, then counters [L][groups] u32 (all bytes 0xff before the launch), then one
-// u32 error flag (0xffffffff = clean)
+// workspace layout: keys [L][groups][32][8] u64 (this kernel uses [l][grp][0][v] as the group's atomic-min cells; the
+// one-codeword-per-thread kernel below uses a slot per split), then counters [L][groups] u32, then one u32 error flag
+// (0xffffffff = clean); all bytes 0xff before the launch
 template <int kVB>
 __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                     const float* __restrict__ embT, int64_t N, int L, int C, int D,
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float*
       float acc[kVB];
 #pragma unroll
       for (int v = 0; v < kVB; ++v) acc[v] = 0.f;
-#pragma unroll 8
+#pragma unroll 32
       for (int k = 0; k < D; ++k) {
         const float e = eT[(size_t)k * C + c];
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float*
       if (lane == 0) { wv[wave * kVB + v] = bv[v]; wi[wave * kVB + v] = bi[v]; }
     }
     __syncthreads();
-    unsigned long long* lkeys = keys + ((size_t)l * groups + grp) * kVB;
+    unsigned long long* lkeys = keys + (((size_t)l * groups + grp) * 32) * kVB;
     unsigned* cnt = counters + (size_t)l * groups + grp;
     if (tid < kVB) {
       float v0 = wv[tid];
@@ -210,6 +211,113 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float*
     for (int idx = tid; idx < nv * D; idx += kThreads) quantized[n0 * D + idx] = qs[idx];
 }
 
+// One codeword per thread (S = C / 256 splits): the thread's codeword lives in registers, and the NEXT level's codeword is
+// requested while this level's candidates travel through the atomics — the codebook loads do not depend on the residual,
+// only the arithmetic does.  What the generic split kernel above spends per level is not the scan (0.9 us of VALU) but the
+// dependent load batches in front of it (k walked 8 loads at a time: four memory round trips per codeword): 25-30 us per
+// level, measured (profiles/r3_notes.md).
+template <int kVB, int kD>
+__global__ __launch_bounds__(kThreads, (kD <= 32 ? 4 : 2)) void rvq_encode_split1_kernel(const float* __restrict__ x, const float* __restrict__ emb,
+                                                                     const float* __restrict__ embT, int64_t N, int L, int C,
+                                                                     int32_t* __restrict__ codes, float* __restrict__ quantized,
+                                                                     unsigned long long* keys, unsigned* counters, unsigned* err) {
+  __shared__ float res[kVB * kD], qs[kVB * kD], dist[kVB * kThreads];
+  __shared__ int best_i[kVB];
+  __shared__ unsigned long long skeys[kThreads];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x, S = gridDim.y, cs = blockIdx.y, groups = gridDim.x;
+  const int64_t n0 = (int64_t)grp * kVB;
+  const int nv = (int)min((int64_t)kVB, N - n0);
+  const int c = cs * kThreads + tid;                       // this thread's codeword (C == S * 256)
+  float e_cur[kD], e_next[kD];
+#pragma unroll
+  for (int k = 0; k < kD; ++k) e_cur[k] = embT[(size_t)k * C + c];      // level 0, all k in flight at once
+  for (int idx = tid; idx < kVB * kD; idx += kThreads) {
+    const int v = idx / kD, k = idx - v * kD;
+    res[idx] = (v < nv) ? x[(n0 + v) * kD + k] : 0.f;
+    qs[idx] = 0.f;
+  }
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    // Distances vector by vector into LDS (not unrolled: fully unrolled the compiler keeps all kVB x kD residual values in
+    // registers — 256 VGPRs, one workgroup per CU, and the co-residency the exchange relies on is gone; the residual row is a
+    // broadcast LDS read).  The arg-min then runs two vectors per wave with the shuffle chains of the two interleaved — done
+    // per vector inside the loop above it was 8 x 6 dependent ds_bpermute pairs, ~2.4 us per level.
+#pragma unroll 1
+    for (int v = 0; v < kVB; ++v) {
+      float a0 = 0.f;
+#pragma unroll
+      for (int k = 0; k < kD; ++k) {
+        const float d = __fsub_rn(res[v * kD + k], e_cur[k]);
+        a0 = __fmaf_rn(d, d, a0);
+      }
+      dist[v * kThreads + tid] = a0;
+    }
+    __syncthreads();
+    // Exchange inside the group: every workgroup publishes its kVB candidates as 64-bit keys (distance bits << 32 | index: a
+    // smaller key is a smaller distance and, at equal distance, the lower index — the oracle's tie rule; NaN bit patterns sort
+    // last, as a NaN never wins there) with write-through stores into its own slots, and every workgroup reads all S x kVB
+    // slots — one per thread — polling until the slot differs from the 0xff.. the workspace was memset to.  A valid key never
+    // equals it (index < 2^31).  Two memory round trips per level (store -> visible, poll) instead of the five of an
+    // atomic-min + arrival-counter + key read-back chain (measured 14.6 us per level that way).
+    unsigned long long* lkeys = keys + (((size_t)l * groups + grp) * S) * kVB;        // [S][kVB]
+    {
+      static_assert(kVB == 8, "two vectors per wave, four waves");
+      unsigned long long k2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* dv = dist + (2 * wave + h) * kThreads;
+        unsigned long long best = kKeyInit;
+#pragma unroll
+        for (int j = 0; j < kThreads / 64; ++j) {
+          const int t = lane + 64 * j;
+          best = min(best, ((unsigned long long)__float_as_uint(dv[t]) << 32) | (unsigned)(cs * kThreads + t));
+        }
+        k2[h] = best;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) k2[h] = min(k2[h], (unsigned long long)__shfl_xor((long long)k2[h], o));
+      }
+      if (lane < 2) __hip_atomic_store(lkeys + (size_t)cs * kVB + 2 * wave + lane, lane ? k2[1] : k2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the next level's codeword goes out now: its round trip runs under the exchange and the residual update below
+    const float* eT = embT + (size_t)min(l + 1, L - 1) * kD * C;
+#pragma unroll
+    for (int k = 0; k < kD; ++k) e_next[k] = eT[(size_t)k * C + c];
+    unsigned long long mine = kKeyInit;
+    if (tid < S * kVB) {
+      int spins = 0;
+      while ((mine = __hip_atomic_load(lkeys + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kKeyInit) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    skeys[tid] = mine;
+    __syncthreads();
+    if (tid < kVB) {
+      unsigned long long best = kKeyInit;
+      for (int sp = 0; sp < S; ++sp) best = min(best, skeys[sp * kVB + tid]);
+      best_i[tid] = (best == kKeyInit) ? 0 : (int)(unsigned)(best & 0xffffffffull);
+      if (cs == 0 && tid < nv) codes[(n0 + tid) * L + l] = best_i[tid];
+    }
+    __syncthreads();
+    const float* eR = emb + (size_t)l * C * kD;
+    for (int idx = tid; idx < kVB * kD; idx += kThreads) {
+      const int v = idx / kD, k = idx - v * kD;
+      const float e = eR[(size_t)best_i[v] * kD + k];
+      res[idx] = __fsub_rn(res[idx], e);      // residual = residual - quantized   (core_vq.py:372)
+      qs[idx] = __fadd_rn(qs[idx], e);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kD; ++k) e_cur[k] = e_next[k];
+  }
+  if (quantized && cs == 0)
+    for (int idx = tid; idx < nv * kD; idx += kThreads) quantized[n0 * kD + idx] = qs[idx];
+}
+
 __global__ void rvq_decode_kernel(const int32_t* __restrict__ codes, const float* __restrict__ emb, int64_t N, int L,
                                   int C, int D, float* __restrict__ out) {
   const int64_t total = N * D;
@@ -235,7 +343,7 @@ static void rvq_split_plan(int64_t N, int C, int* groups, int* S) {
 extern "C" size_t ua2_rvq_workspace_bytes(int64_t N, int32_t L) {
   if (N <= 0 || L <= 0) return 0;
   const size_t groups = (size_t)((N + kSplitVB - 1) / kSplitVB);
-  return (size_t)L * groups * kSplitVB * 8 + (size_t)L * groups * 4 + 8;
+  return (size_t)L * groups * 32 * kSplitVB * 8 + (size_t)L * groups * 4 + 8;     // keys [L][groups][<= 32 splits][8], counters, error flag
 }
 
 extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C,
@@ -250,10 +358,34 @@ extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* emb
     UA2_CHECK(workspace_bytes >= need, "ua2_rvq_encode: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
     UA2_HIP(hipMemsetAsync(workspace, 0xff, need, s));
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
-    unsigned* counters = reinterpret_cast<unsigned*>(keys + (size_t)L * groups * kSplitVB);
+    unsigned* counters = reinterpret_cast<unsigned*>(keys + (size_t)L * groups * 32 * kSplitVB);
     unsigned* err = counters + (size_t)L * groups;
+    const int s1 = C / kThreads;                            // one codeword per thread
+    // every workgroup of the grid must be resident at once (they wait for each other): cap the grid by what the device holds
+    static int cus = 0, occ32 = 0, occ64 = 0;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      UA2_HIP(hipGetDevice(&dev));
+      UA2_HIP(hipGetDeviceProperties(&prop, dev));
+      UA2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ32, rvq_encode_split1_kernel<kSplitVB, 32>, kThreads, 0));
+      UA2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ64, rvq_encode_split1_kernel<kSplitVB, 64>, kThreads, 0));
+      cus = prop.multiProcessorCount;
+    }
+    const int64_t room1 = (int64_t)cus * (D == 32 ? occ32 : occ64) / 2;      // half of the device: other streams may hold the rest
+    if ((D == 32 || D == 64) && C % kThreads == 0 && s1 * kSplitVB <= kThreads && (int64_t)groups * s1 <= room1) {
+      if (D == 32) hipLaunchKernelGGL((rvq_encode_split1_kernel<kSplitVB, 32>), dim3(groups, s1), dim3(kThreads), 0, s, x, emb, embT, N, L, C,
+                                      codes, quantized, keys, counters, err);
+      else hipLaunchKernelGGL((rvq_encode_split1_kernel<kSplitVB, 64>), dim3(groups, s1), dim3(kThreads), 0, s, x, emb, embT, N, L, C, codes,
+                              quantized, keys, counters, err);
+      UA2_LAUNCH_CHECK();
+      return 0;
+    }
     const size_t smem = (size_t)(2 * kSplitVB * D + 4 * kSplitVB) * sizeof(float) + (size_t)(4 * kSplitVB + kSplitVB) * sizeof(int);
     UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
+    int occg = 0;
+    UA2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occg, rvq_encode_split_kernel<kSplitVB>, kThreads, smem));
+    while (S > 1 && (int64_t)groups * S > (int64_t)cus * occg / 2) S /= 2;
     hipLaunchKernelGGL(rvq_encode_split_kernel<kSplitVB>, dim3(groups, S), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes,
                        quantized, keys, counters, err);
     UA2_LAUNCH_CHECK();

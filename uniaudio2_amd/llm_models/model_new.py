@@ -274,7 +274,7 @@ class Model_stage3(nn.Module):
     # ---- MI355X-native fast path ---------------------------------------------------------------
     @torch.inference_mode()
     def generate_frames(self, n_frames: int, batch: int, mode: int, reason_eos: int = -1, reason_card: int = 0,
-                        max_pos: Optional[int] = None, use_graph: bool = True) -> torch.Tensor:
+                        max_pos: Optional[int] = None, use_graph: bool = True, frame_events=None) -> torch.Tensor:
         """Runs `n_frames` frames back to back from the state left by the previous frame (first
         call: after `begin_decode`).  mode 0 = audio feedback (evaluation/tts_task.py:259-280),
         1 = text feedback (evaluation/asr_task.py:668-682; the depth decoder is skipped there — its samples are
@@ -294,9 +294,11 @@ class Model_stage3(nn.Module):
             self._check_positions(self._pos_hi + n_frames - 1)
         self._pos_hi += n_frames
         s = ops.stream()
-        for _ in range(n_frames):
+        for i in range(n_frames):
             check(lib.ua2_stage3_frame(self._h, batch, mode, reason_eos, reason_card, int(use_graph), s),
                   "ua2_stage3_frame")
+            if frame_events is not None:           # measurement hook: one event after every frame (bench.py p50 / p99)
+                frame_events[i].record()
         return st["frame_log"][start:start + n_frames, :batch]
 
     # ---- ragged batches / continuous batching (the reference has neither: SURVEY.md A.17, §8e) ------
