@@ -344,6 +344,65 @@ def batched_leg(model, dev, B=64, frames=24, max_seq=2048):
     return res
 
 
+def config4_leg(model, dev, world, rank, per_rank=64, seed=0):
+    """BASELINE.json config 4 / SURVEY.md §8d: batched TTS, 64 ragged prompts PER GPU (512 over 8 GPUs), prompt lengths
+    uniform[24, 48], frames to generate uniform[60, 300] (deterministic stop), sharded longest-first round-robin over the ranks
+    (uniaudio2_amd/parallel.py), each rank decoding its shard as ONE continuous batch (sequences retire the frame they finish)
+    and the shard ending in the path's only collective — the fixed-shape RCCL all-gather of the token tensors — INSIDE the
+    timed region.  Weak scaling: the per-GPU work is fixed (the global prompt list grows with the world size).  Timed like the
+    headline: barrier + synchronize on both sides, max over ranks; the first pass (graph captures for every live-batch size
+    the retirement schedule visits) is untimed."""
+    import numpy as np
+    from uniaudio2_amd import parallel
+    n_total = per_rank * world
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(24, 49, size=n_total)
+    nfr = rs.randint(60, 301, size=n_total)
+    items = []
+    for i in range(n_total):
+        g = torch.Generator().manual_seed(4000 + i)
+        t = torch.zeros(int(lens[i]), 9, dtype=torch.long)
+        t[:, -1] = torch.randint(0, 128000, (int(lens[i]),), generator=g)
+        m = torch.zeros(int(lens[i]), 9, dtype=torch.bool)
+        m[:, -1] = True
+        items.append((t.to(dev), m.to(dev), int(nfr[i])))
+    model.setup_caches(per_rank, dtype=torch.bfloat16, max_seq_length=512, max_rows=4096, log_frames=320)
+
+    def generate_batch(chunk):
+        ids = model.generate_ragged([(t, m) for t, m, _ in chunk], [n for _, _, n in chunk], mode=0, reason_eos=-1, reason_card=REASON_CARD)
+        out = []
+        for o in ids:                                        # (T, 9) int32 -> the (reason (8, T_r), semantic (8, T_s)) contract
+            a = o[:, 1:].t().contiguous()
+            k = min(a.shape[1], 50)
+            out.append((a[:, :k], a[:, k:]))
+        return out
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dt = 0.0
+    for rep in range(2):
+        fence()
+        t0 = time.perf_counter()
+        res = parallel.run_sharded_batched(items, nfr.tolist(), generate_batch, per_rank)
+        fence()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ok = sum(1 for v in res.values() if not isinstance(v, parallel.Failed))
+    frames = int(nfr.sum())
+    return {"prompts_total": n_total, "prompts_per_gpu": per_rank, "n_gpus": world, "frames_total": frames, "gathered_ok": ok,
+            "seconds": round(dt, 4), "audio_tokens_per_s": round(8 * frames / dt, 1),
+            "audio_tokens_per_s_per_gpu": round(8 * frames / dt / world, 1), "max_frames_of_a_sequence": int(nfr.max()),
+            "scaling": "weak", "exchange": "one fixed-shape int32 all-gather of the token tensors per shard, inside the timed region"}
+
+
 def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
     """the CPU oracle (fp32 port of the reference algorithm as shipped: full-2048 masked prefill,
     repeat_interleave GQA, lm_head + 8-step local decoder every frame) on this host's cores, same weights, same prompt,
@@ -610,6 +669,9 @@ def main():
         res["parity_notes"] = ("bf16 ids are asserted teacher-forced against the bf16 oracle (tests/test_gpu_fullsize.py); the live "
                                "codec's ResidualVQ is restated from vector_quantize_pytorch==1.27.15's published algorithm and is "
                                "parity-UNPINNED against the package itself (absent here)")
+    if not a.no_legs and (world > 1 or solo):
+        # the named multi-GPU config (BASELINE.json configs[3]): every rank takes part (collective inside)
+        res["config4_batched_tts"] = config4_leg(model, dev, world, rank)
     if solo and not a.no_legs:
         res["codec"] = codec_leg(dev, cpu=not a.no_cpu_baseline)
         res["codec"]["stage2_codes_to_wav"] = stage2_leg(dev)

@@ -293,10 +293,16 @@ def test_model_topk_sampling_runs_and_is_reproducible(golden, sd):
     # (the seed lives in device memory, counters[2..3]); same seed + same draw index -> same stream
     runs = []
     for seed in (888, 889, 888):
-        m.set_sampling(20, 0.9, seed=seed)
-        m._st["counters"][1] = 0
+        m.set_sampling(20, 0.9, seed=seed)          # a new key rewinds the device's draw index (no host poke needed)
         runs.append(product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"])
     assert torch.equal(runs[0], runs[2]) and not torch.equal(runs[0], runs[1])
+    # sharding independence: "utterance A" (key 888) gives the same samples whether its rank generated another
+    # utterance of any length before it or not
+    m.set_sampling(20, 0.9, seed=4242)
+    product_decode_loop(m, tokens, mask, 7, "audio", fast=True)
+    m.set_sampling(20, 0.9, seed=888)
+    after_other = product_decode_loop(m, tokens, mask, 12, "audio", fast=True)["samples"]
+    assert torch.equal(after_other, runs[0])
     m.reset_caches()
 
 

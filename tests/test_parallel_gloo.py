@@ -3,6 +3,7 @@ utterance exactly once and the all-gather returns every rank the full, correctly
 import os
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -87,20 +88,35 @@ def _worker_failing(rank, world, port, n, ret):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from uniaudio2_amd.parallel import Failed, run_sharded
+    from uniaudio2_amd.parallel import Failed, GenerationFailed, run_sharded
 
     def gen(i):
         if i == 2:
-            raise RuntimeError("no semantic frames were produced")      # what PhaseSplitter.result raises
+            raise GenerationFailed("no semantic frames were produced")      # what PhaseSplitter.result raises
+        if i == 3:                                                          # over-long result: a failed slot, not a raise between collectives
+            return torch.zeros(8, 501, dtype=torch.int32), torch.zeros(8, 3, dtype=torch.int32)
         return fake_generate(i)
 
     out = run_sharded(list(range(n)), [1] * n, gen)
-    ok = sorted(out) == list(range(n)) and isinstance(out[2], Failed)
+    ok = sorted(out) == list(range(n)) and isinstance(out[2], Failed) and isinstance(out[3], Failed)
+    # the reason survives the gather on EVERY rank, whichever rank the utterance ran on
+    ok = ok and "no semantic frames" in out[2].message and "MAX_FRAMES" in out[3].message
     for i in range(n):
-        if i != 2:
+        if i not in (2, 3):
             ok = ok and torch.equal(out[i][0], fake_generate(i)[0])
     ret[rank] = ok
     dist.destroy_process_group()
+
+
+def test_device_errors_are_not_swallowed_as_failed_utterances():
+    """A RuntimeError that is not the generation logic's own (HIP fault, OOM, ua2_* status) propagates."""
+    from uniaudio2_amd.parallel import run_sharded
+
+    def gen(i):
+        raise RuntimeError("HIP error: an illegal memory access was encountered")
+
+    with pytest.raises(RuntimeError):
+        run_sharded([0, 1], [1, 1], gen)
 
 
 def test_failed_utterance_travels_as_sentinel_world2():

@@ -247,7 +247,10 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   return 0;
 }
 
-__global__ void set_seed_kernel(int32_t* c, uint32_t lo, uint32_t hi) { c[2] = (int32_t)lo; c[3] = (int32_t)hi; }
+// (re-)seeding also rewinds the draw index (counters[1]): an utterance's samples are then a function of its own key and its
+// own frame count, whatever was generated before it on this rank (per-utterance keys alone did not make the
+// samples independent of the sharding — the index kept counting across utterances)
+__global__ void set_seed_kernel(int32_t* c, uint32_t lo, uint32_t hi) { c[1] = 0; c[2] = (int32_t)lo; c[3] = (int32_t)hi; }
 
 // The seed lives in device memory (counters[2..3]) and the samplers read it there, so a captured frame graph
 // serves every seed: re-seeding between utterances is one 8-byte store on the caller's stream, never a re-capture.

@@ -55,8 +55,9 @@ class PhaseSplitter:
 
     def result(self):
         if len(self.pre_reason) < 2 or len(self.pre_sem) < 2:
-            raise RuntimeError("stack expects a non-empty TensorList: the model produced no reason/semantic frames "
-                               "(same failure as the reference's torch.stack at tts_task.py:283-284)")
+            from ..parallel import GenerationFailed
+            raise GenerationFailed("stack expects a non-empty TensorList: the model produced no reason/semantic frames "
+                                   "(same failure as the reference's torch.stack at tts_task.py:283-284)")
         de_reason = torch.stack(self.pre_reason[1:]).permute(1, 2, 0).squeeze(0)      # (8, T_r)
         de_sem = torch.stack(self.pre_sem[1:]).permute(1, 2, 0).squeeze(0)
         return de_reason, de_sem

@@ -258,6 +258,7 @@ class Model_stage3(nn.Module):
             seed = self.sampling_seed if self.sampling_seed is not None else torch.initial_seed()
         key = (int(topk), float(temperature), int(seed) & (2 ** 64 - 1))
         if getattr(self, "_sampling", None) != key:
+            # a new key rewinds the draw index on the device; the same key keeps counting (like a global generator)
             check(lib.ua2_stage3_set_sampling(self._h, key[0], key[1], key[2], ops.stream()), "ua2_stage3_set_sampling")
             self._sampling = key
 

@@ -239,14 +239,17 @@ def run_generation_stage1(args):
     extra = (lambda i: {"caption": ids[i]}) if _generation_method_name(task) == "generate_instruct_tts" else (lambda i: {})   # :520-521
 
     def one(i):
-        # the sampler's key folds in the global utterance index: ranks (and utterances) draw from independent
-        # streams, and an utterance's samples do not depend on how the work was sharded
+        # the sampler's key folds in the global utterance index and a new key rewinds the device's draw index
+        # (ua2_stage3_set_sampling), so with one utterance at a time an utterance's samples depend only on (seed, index):
+        # not on the world size, nor on what its rank generated before it (tests/test_gpu_lm.py)
         model.sampling_seed = parallel.utterance_seed(args.seed, i)
         return gen_fn(task_prompt=task_prompt, task_name=task, text_token=ids[i], temperature=args.temperature,
                       topk=args.topk, cfg_scale=args.cfg_scale, **extra(i))
 
     if args.batch_size > 1 and hasattr(generator, "generate_tts_batch") and _generation_method_name(task) == "generate_tts":
         def many(idx):
+            # batched chunks are keyed by their first utterance and draw per (row, frame): samples here DO depend on the
+            # chunk composition, i.e. on --batch_size and the world size (greedy decoding, topk = 1, does not)
             model.sampling_seed = parallel.utterance_seed(args.seed, idx[0])
             return generator.generate_tts_batch(task_prompt=task_prompt, task_name=task, text_tokens=[ids[i] for i in idx],
                                                 temperature=args.temperature, topk=args.topk, cfg_scale=args.cfg_scale)

@@ -15,6 +15,16 @@ import torch.distributed as dist
 MAX_FRAMES = 500          # evaluation/tts_task.py:222
 
 
+MSG_BYTES = 96           # a failed utterance's reason travels with the gather (truncated UTF-8)
+
+
+class GenerationFailed(RuntimeError):
+    """(A RuntimeError, as the reference's own torch.stack failure is.)  An utterance-level failure of the generation LOGIC (e.g. PhaseSplitter.result: the model produced no frames of a phase —
+    the reference's torch.stack error, evaluation/tts_task.py:283-284).  Only this is turned into a `Failed` slot by the
+    sharded runners: device / library errors (HIP faults, out of memory, ua2_* status codes) are NOT utterance-level — after a
+    sticky device fault every later utterance would "fail" too — and propagate."""
+
+
 class Failed:
     """Result slot of an utterance whose generation raised on its rank.  It travels through the all-gather as the
     sentinel T_r = T_s = -1 (a rank that raised BEFORE the collective would leave the others waiting in it forever)."""
@@ -45,15 +55,21 @@ def pack_local(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_local_ma
     """results: global index -> (reason (8,T_r), semantic (8,T_s)) int32.  Fixed-shape buffers for the all-gather."""
     tok = torch.zeros(n_local_max, 2, n_cb, MAX_FRAMES, dtype=torch.int32, device=device)
     meta = torch.full((n_local_max, 3), -1, dtype=torch.int32, device=device)      # (global index, T_r, T_s)
+    msg = torch.zeros(n_local_max, MSG_BYTES, dtype=torch.uint8, device=device)
     for slot, (gi, res) in enumerate(sorted(results.items(), key=lambda kv: kv[0])):
+        if not isinstance(res, Failed) and max(res[0].shape[1], res[1].shape[1]) > MAX_FRAMES:
+            # never raise between the ranks' collectives (the peers would wait forever): an over-long result is a failed slot
+            res = Failed(f"result longer than MAX_FRAMES={MAX_FRAMES}: T_r={res[0].shape[1]} T_s={res[1].shape[1]}")
         if isinstance(res, Failed):
             meta[slot] = torch.tensor([gi, -1, -1], dtype=torch.int32)
+            raw = res.message.encode("utf-8", "replace")[:MSG_BYTES]
+            msg[slot, :len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
             continue
         r, s = res
         tok[slot, 0, :, :r.shape[1]] = r.to(device=device, dtype=torch.int32)
         tok[slot, 1, :, :s.shape[1]] = s.to(device=device, dtype=torch.int32)
         meta[slot] = torch.tensor([gi, r.shape[1], s.shape[1]], dtype=torch.int32)
-    return tok, meta
+    return tok, meta, msg
 
 
 def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_total: int, device=None):
@@ -64,17 +80,24 @@ def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_tota
     n_local_max = (n_total + world - 1) // world
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    tok, meta = pack_local(results, n_local_max, device)
+    tok, meta, msg = pack_local(results, n_local_max, device)
     toks = [torch.empty_like(tok) for _ in range(world)]
     metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(toks, tok)          # the path's only collective
+    msgs = [torch.empty_like(msg) for _ in range(world)]
+    dist.all_gather(toks, tok)          # the path's only collective (+ its two small side-cars)
     dist.all_gather(metas, meta)
+    dist.all_gather(msgs, msg)
     out = {}
-    for t, m in zip(toks, metas):
+    for t, m, g in zip(toks, metas, msgs):
+        m = m.cpu()
         for slot in range(n_local_max):
             gi, tr, ts = (int(v) for v in m[slot])
             if gi >= 0:
-                out[gi] = Failed() if tr < 0 else (t[slot, 0, :, :tr].clone(), t[slot, 1, :, :ts].clone())
+                if tr < 0:
+                    raw = bytes(g[slot].cpu().tolist()).rstrip(b"\0")
+                    out[gi] = Failed(raw.decode("utf-8", "replace") or "generation failed on its rank")
+                else:
+                    out[gi] = (t[slot, 0, :, :tr].clone(), t[slot, 1, :, :ts].clone())
     return out
 
 
@@ -86,7 +109,7 @@ def run_sharded(items: Sequence, lengths: Sequence[int], generate_fn) -> Dict[in
     for i in shard_indices(lengths, world, rank):
         try:
             local[i] = generate_fn(items[i])
-        except (RuntimeError, ValueError) as e:          # e.g. PhaseSplitter.result: no frames of a phase were produced
+        except GenerationFailed as e:                    # e.g. PhaseSplitter.result: no frames of a phase were produced
             local[i] = Failed(f"{type(e).__name__}: {e}")
     return gather_results(local, len(items))
 
@@ -103,7 +126,7 @@ def run_sharded_batched(items: Sequence, lengths: Sequence[int], generate_batch_
         try:
             for i, res in zip(chunk, generate_batch_fn([items[i] for i in chunk])):
                 local[i] = res
-        except (RuntimeError, ValueError) as e:
+        except GenerationFailed as e:
             for i in chunk:
                 local.setdefault(i, Failed(f"{type(e).__name__}: {e}"))
     return gather_results(local, len(items))

@@ -188,6 +188,13 @@ class ReasoningTokenizer:
         model = AudioDiffusion1D(num_channels=ta.get("num_channels"), unet_model_config_path=ta["transformer_diffusion_config"], **dims)
         mine = model.state_dict()
         model.load_state_dict({k: v for k, v in sd.items() if k in mine}, strict=False)       # SSL / LLM keys of the checkpoint are not ours
+        if sd:
+            # strict=False hides name mismatches: a parameter of THIS module tree that the checkpoint does not name would silently
+            # keep its random initialisation and stage 2 would write garbage waveforms without an error
+            missing = sorted(set(mine) - set(sd))
+            if missing:
+                raise RuntimeError(f"{model_path}: {len(missing)} parameter(s) of the codec model are not in the checkpoint "
+                                   f"(first: {missing[:5]}) — a key-name mismatch between this module tree and the released one")
         self.model = model.to(self.device)
         self.model.sq_codec_latent = sq_cfg["latent_hidden_dim"]
         self.model.prepare()
