@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 4
+#define UA2_VERSION 5
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -36,9 +36,17 @@ enum ua2_prologue {
   UA2_PRO_CAST = 0, /* x as is                                   (lit_model.py:511,595; model_new.py:617,631) */
   UA2_PRO_NORM = 1, /* RMSNorm(x)*w, fp32 math                    (lit_model.py:883-890 before :424 / :591)    */
   /* 2: reserved (round 1's merge of per-page attention partials; ua2_attn now writes the normalised row itself) */
-  UA2_PRO_LOCAL_ATTN = 3 /* M == 1 only: the operand row IS the short-context attention of ua2_attn_local, computed
+  UA2_PRO_LOCAL_ATTN = 3, /* M == 1 only: the operand row IS the short-context attention of ua2_attn_local, computed
                        in the kernel (x = q [1, n_head*head_size], kv, row_pos, row_seq as for ua2_attn_local;
                        K == n_head*head_size).  Bit-identical to ua2_attn_local followed by UA2_PRO_CAST. */
+  UA2_PRO_SCALED = 4  /* RMSNorm folded around the GEMM (UA2_BF16 only; the frame executor's form of lit_model.py:883-890
+                       + :424 / :591):   y = rstd[m] * ( RNE_bf16(x (.) w) W^T ),   rstd = rsqrt(mean(x^2) + eps).
+                       The operand RNE_bf16(x (.) w) is handed over by the PRODUCER of x (x_h: row-major bf16, launches of
+                       one row tile; x_packed: fragment order, many-row launches) together with per-16-column sums of
+                       squares of the fp32 x (x_ssq) — see y_norm_w below — so that no launch stands between the
+                       producer and this GEMM, whatever the row count; the row scale is applied to the fp32 sums in
+                       the epilogue.  Mathematically RMSNorm(x) W^T; numerically the bf16 rounding happens before
+                       the row scale instead of after it (same relative error).  K % 16 == 0. */
 };
 
 /* What happens to the GEMM result (the ops the reference runs right after the Linear). */
@@ -156,6 +164,19 @@ typedef struct ua2_linear_args {
                              WITHOUT rope_head_size (rope_mode INTERLEAVED / NONE), where column n is source row n */
   const float* bias1;     /* SWIGLU: bias of w1 */
   int32_t act_kind;       /* enum ua2_act_kind */
+  /* Scaled-norm hand-over (UA2_BF16).  Producer side — UA2_EPI_RESIDUAL / UA2_EPI_STORE with y_norm_w != NULL: besides
+     y the launch writes, for the UA2_PRO_SCALED consumer that follows, RNE_bf16(y[m][n] * y_norm_w[n]) into y_h (row-major
+     [M, ldh] bf16) and / or y_packed (fragment order, N % 32 == 0), and y_ssq[m][n / 16] = the sum of y[m][n]^2 over the
+     16-column tile, added in a fixed butterfly order (xor 1, 2, 4, 8) — the same tree in every kernel, so a row's
+     statistic does not depend on the row count.  N % 16 == 0.
+     Consumer side — UA2_PRO_SCALED: x_h (M <= the decode kernel's row tile) or x_packed, and x_ssq [M, K / 16]; eps as
+     for UA2_PRO_NORM.  rstd[m] = rsqrt(sum_j x_ssq[m][j] / K + eps), j summed as 16 interleaved chains + butterfly. */
+  const float* y_norm_w;
+  void* y_h;
+  int32_t ldh;            /* row stride (elements) of y_h / x_h */
+  float* y_ssq;
+  const void* x_h;
+  const float* x_ssq;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
@@ -209,19 +230,31 @@ int ua2_attn(const ua2_attn_args* a, void* stream);
  * of ua2_attn_args ([R, n_head*head_size] fp32 out); exact-operation softmax in position order. */
 int ua2_attn_local(const ua2_attn_args* a, void* stream);
 
+/* Producer half of the scaled-norm hand-over (see ua2_linear_args.y_norm_w) for the row-wise kernels that feed a GPT's first
+ * layer: besides its fp32 output `o` [M, C] the kernel writes RNE_bf16(o * norm_w) into h (row-major, stride ldh) and / or
+ * packed (fragment order), and ssq [M, C / 16] (the same butterfly tree as the linear epilogues).  UA2_BF16; C % 32 == 0. */
+typedef struct ua2_handover {
+  const float* norm_w;   /* [C] weight of the RMSNorm the consumer folds */
+  void* h;               /* [M, ldh] bf16, or NULL */
+  int32_t ldh;
+  void* packed;          /* [ceil(M/16)][C/32][64 lanes][16 B], or NULL */
+  float* ssq;            /* [M, C / 16] */
+} ua2_handover;
+
 /* Frame embedding (model_new.py:594-600, 604, 665-673): for each row,
- * audio_sum = sum_i mask[i] * audio_emb[tok[i] + i*V_a]  (i = 0..n_cb-1, in order), text = wte[tok[n_cb]]. */
+ * audio_sum = sum_i mask[i] * audio_emb[tok[i] + i*V_a]  (i = 0..n_cb-1, in order), text = wte[tok[n_cb]].
+ * ho (optional): hand-over of audio_sum to the understanding expert's first layer. */
 int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, int32_t va,
                     const int32_t* tokens /* [M, n_cb+1] */, const uint8_t* mask /* [M, n_cb+1] */,
                     const void* audio_emb, const void* wte, float* audio_sum /* [M,C] */, float* text /* [M,C] */,
-                    void* stream);
+                    const ua2_handover* ho, void* stream);
 
 /* Final RMSNorm of a GPT + the step-mask blends (lit_model.py:164; model_new.py:607,610,613):
  *   n = RMSNorm(x)*w ; out1 = n*fa + other*fb ; out2 = n (optional)
  * fa = mask[m, col_a] if col_a >= 0 else 1 ; fb = mask[m, col_b] if other else 0. */
 int ua2_rmsnorm_blend(int32_t M, int32_t C, const float* x, const float* w, float eps,
                       const float* other, const uint8_t* mask, int32_t mask_ld, int32_t col_a, int32_t col_b,
-                      float* out1, float* out2, void* stream);
+                      float* out1, float* out2, const ua2_handover* ho /* optional: hand-over of out1 */, void* stream);
 
 /* Greedy sampling tail (model_new.py:146-187 with topk=1; lowest index wins ties) fused with
  * the next-step embedding gather (model_new.py:640,662-663):

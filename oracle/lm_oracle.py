@@ -17,6 +17,12 @@ Two arithmetic contracts are restated:
                to bf16 when written to the cache, everything else (residual stream, norms,
                RoPE, softmax, logits) and all accumulation in fp32.  This is NOT
                `model.to(bfloat16)` of the reference (which also rounds every activation).
+               RMSNorm + Linear pairs (norm_1 -> qkv, norm_2 -> fc_1 / fc_2, the depth decoder's
+               ln_f -> audio_head) are evaluated in the product's "scaled" form (round 3,
+               include/ua2hip.h UA2_PRO_SCALED):  rstd * ( RNE_bf16(x * w) W^T )  with
+               rstd = rsqrt(mean(x^2) + eps) in fp32 — the same function as
+               RNE_bf16((x * rstd) * w) W^T of lit_model.py:883-890 + the Linear, with the bf16
+               rounding taken before the row scale instead of after it.
 """
 import math
 from dataclasses import dataclass, field
@@ -82,6 +88,18 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def norm_linear(x, w, eps, mats, mode):
+    """RMSNorm(x) followed by one or more Linear layers (lit_model.py:883-890 + :424 / :591-592).  fp32: as the reference
+    evaluates it.  bf16: the product's scaled form (module docstring)."""
+    if mode != "bf16":
+        xn = rmsnorm(x, w, eps)
+        return [F.linear(xn, m) for m in mats]
+    x = x.float()
+    rstd = torch.rsqrt(torch.mean(x * x, dim=-1, keepdim=True) + eps)
+    a = _bf16(x * w.float())
+    return [F.linear(a, m) * rstd for m in mats]
+
+
 class GPTOracle:
     """llm_models/lit_model.py:22-275 GPT with embeddings in / hidden out (:180), linear KV cache (:814-860)."""
 
@@ -113,8 +131,9 @@ class GPTOracle:
         for t in self.k + self.v:
             t.zero_()
 
-    def forward(self, x, input_pos, maxp1=None):
-        """x (B, T, C) fp32; input_pos (B, T) long (per-sequence positions).  lit_model.py:83-180."""
+    def forward(self, x, input_pos, maxp1=None, final_norm=True):
+        """x (B, T, C) fp32; input_pos (B, T) long (per-sequence positions).  lit_model.py:83-180.
+        final_norm=False returns the stream BEFORE ln_f (the caller folds ln_f into the Linear that follows)."""
         s = self.s
         B, T, C = x.shape
         cos, sin = self.cos[input_pos], self.sin[input_pos]             # (B, T, hs)   :129-130
@@ -124,8 +143,7 @@ class GPTOracle:
         nh, ng, hs = s.n_head, s.n_query_groups, s.head_size
         bidx = torch.arange(B).unsqueeze(1).expand(B, T)
         for li, W in enumerate(self.layers):                            # Block.forward :337-349
-            xn = rmsnorm(x, W["norm_1"], s.norm_eps)
-            qkv = F.linear(self.qa(xn), W["qkv"])                       # :424
+            qkv, = norm_linear(x, W["norm_1"], s.norm_eps, [W["qkv"]], self.mode)     # :341, :424
             q, k, v = qkv.split((nh * hs, ng * hs, ng * hs), dim=-1)    # :431
             q = q.view(B, T, nh, hs).transpose(1, 2)
             k = k.view(B, T, ng, hs).transpose(1, 2)
@@ -142,11 +160,10 @@ class GPTOracle:
                                                scale=1.0 / math.sqrt(hs))       # :529-531
             y = y.transpose(1, 2).reshape(B, T, nh * hs)
             x = F.linear(self.qa(y), W["proj"]) + x                     # :511, :345
-            xn = rmsnorm(x, W["norm_2"], s.norm_eps)
-            a = self.qa(xn)
-            h = F.silu(F.linear(a, W["fc_1"])) * F.linear(a, W["fc_2"]) # LLaMAMLP :591-595
+            g1, g2 = norm_linear(x, W["norm_2"], s.norm_eps, [W["fc_1"], W["fc_2"]], self.mode)
+            h = F.silu(g1) * g2                                         # LLaMAMLP :591-595
             x = F.linear(self.qa(h), W["mlp_proj"]) + x
-        return rmsnorm(x, self.ln_f, s.norm_eps)                        # :164
+        return rmsnorm(x, self.ln_f, s.norm_eps) if final_norm else x   # :164
 
 
 class Stage3Oracle:
@@ -226,8 +243,9 @@ class Stage3Oracle:
         alog = []
         for i in range(self.ncb):                                      # :630-641
             d_in = F.linear(self.qa(curr_h), self.projection)
-            d_h = self.decoder.forward(d_in, torch.full((B, 1), i, dtype=torch.long), None)
-            lg = mix(torch.mm(self.qa(d_h[:, -1, :]), self.audio_head[i]))   # :632
+            d_x = self.decoder.forward(d_in, torch.full((B, 1), i, dtype=torch.long), None, final_norm=False)
+            lg, = norm_linear(d_x[:, -1, :], self.decoder.ln_f, self.decoder.s.norm_eps, [self.audio_head[i].t()], self.mode)   # ln_f :164 + :632
+            lg = mix(lg)
             alog.append(lg)
             lg2 = lg.clone()
             if forbid_prefix > 0:

@@ -207,3 +207,88 @@ def test_local_attention_and_its_fusion_into_the_o_projection(dtype, nh, nkv, hs
                    row_seq=torch.tensor([r], dtype=torch.int32, device=dev), kv=geom)
         torch.cuda.synchronize()
         assert torch.equal(a, b), (r, (a - b).abs().max().item())
+
+
+def _unpack_operand(pk, M, K):
+    """[ceil(M/16)][K/32][64 lanes][8] bf16 fragment order -> [M, K] (element (m, k): chunk k // 32, lane (k % 32) // 8 * 16 + m % 16)."""
+    t = pk.view(-1, K // 32, 4, 16, 8)                   # [mt][chunk][g][m & 15][e]
+    return t.permute(0, 3, 1, 2, 4).reshape(-1, K)[:M]
+
+
+def test_scaled_norm_handover_is_kernel_and_row_count_invariant(linear_mode):
+    """Round 3's RMSNorm hand-over (include/ua2hip.h UA2_PRO_SCALED / y_norm_w): the producer's three outputs (fp32 y,
+    RNE_bf16(y * w_next) in row-major or fragment order, per-16-column sums of squares) and the consumer's result
+    rstd * (operand W^T) are bit-identical whichever kernel the row count selects (decode kernel with the row-major
+    hand-over; skinny / tiled kernels with the packed one) and whatever rows share the launch; and they are the function the
+    contract states, against a plain torch evaluation."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_CAST, lib
+    PRO_SCALED = 4
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    C, N2, I = 3072, 2048, 8192
+    Mmax = 70
+    w_o = ops.pack_linear((torch.randn(C, C, generator=g) * C ** -0.5).to(dev), dt)          # the producer: a residual projection
+    W2 = (torch.randn(N2, C, generator=g) * C ** -0.5).to(dev)
+    w_c = ops.pack_linear(W2, dt)                                                              # consumers: STORE and SWIGLU
+    Wg, Wu = (torch.randn(I, C, generator=g) * C ** -0.5).to(dev), (torch.randn(I, C, generator=g) * C ** -0.5).to(dev)
+    w_g, w_u = ops.pack_linear(Wg, dt), ops.pack_linear(Wu, dt)
+    nw = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev)
+    x = torch.randn(Mmax, C, generator=g).to(dev)
+    res = (3.0 * torch.randn(Mmax, C, generator=g)).to(dev)
+
+    def produce(rows, mode, packed):
+        M = rows.stop - rows.start
+        linear_mode(mode)
+        y = torch.empty(M, C, device=dev)
+        ssq = torch.zeros(M, C // 16, device=dev)
+        kw = dict(dtype=dt, M=M, N=C, K=C, w0=w_o, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x[rows].contiguous(), y=y,
+                  resid=res[rows].contiguous(), y_norm_w=nw, y_ssq=ssq, workspace=ops.linear_workspace(dt, M, C, dev))
+        if packed:
+            pk = torch.zeros((M + 15) // 16 * 16 * C, dtype=dt, device=dev)
+            ops.linear(**kw, y_packed=pk)
+            h = _unpack_operand(pk, M, C)
+        else:
+            h = torch.zeros(M, C, dtype=dt, device=dev)
+            ops.linear(**kw, y_h=h)
+            pk = None
+        torch.cuda.synchronize()
+        return y, ssq, h, pk
+
+    def consume(M, mode, h, pk, ssq, swiglu):
+        linear_mode(mode)
+        N = I if swiglu else N2
+        out = torch.empty(M, N, device=dev)
+        kw = dict(dtype=dt, M=M, N=N, K=C, w0=w_g if swiglu else w_c, w1=w_u if swiglu else None, prologue=PRO_SCALED,
+                  epilogue=EPI_SWIGLU if swiglu else EPI_STORE, y=out, x_ssq=ssq, eps=1e-5)
+        if pk is not None:
+            ops.linear(**kw, x_packed=pk)
+        else:
+            ops.linear(**kw, x_h=h.contiguous())
+        torch.cuda.synchronize()
+        return out
+
+    # single-row reference runs through the decode kernel and the row-major hand-over
+    singles = [produce(slice(r, r + 1), 2, False) for r in range(Mmax)]
+    y1 = torch.cat([s[0] for s in singles]); q1 = torch.cat([s[1] for s in singles]); h1 = torch.cat([s[2] for s in singles])
+    c1 = torch.cat([consume(1, 2, singles[r][2], None, singles[r][1], False) for r in range(Mmax)])
+    g1 = torch.cat([consume(1, 2, singles[r][2], None, singles[r][1], True) for r in range(0, Mmax, 9)])
+    # the contract, in plain torch (fp32 accumulate; bf16 inputs): y = resid + bf16(x) Wo^T is checked by the other tests; here
+    # the hand-over of THAT y and the scaled consumer
+    assert torch.equal(h1, (y1 * nw).to(dt))
+    torch.testing.assert_close(q1, (y1.double() ** 2).view(Mmax, C // 16, 16).sum(-1).float(), rtol=2e-6, atol=0)
+    rstd = torch.rsqrt((y1.double() ** 2).mean(-1, keepdim=True) + 1e-5)
+    want = (rstd * (h1.double() @ W2.to(dt).double().t())).float()
+    torch.testing.assert_close(c1, want, rtol=0, atol=2e-3)
+    hg = h1[::9].double()
+    want_g = (torch.nn.functional.silu(rstd[::9] * (hg @ Wg.to(dt).double().t())) * (rstd[::9] * (hg @ Wu.to(dt).double().t()))).float()
+    torch.testing.assert_close(g1, want_g, rtol=0, atol=4e-3)
+    for M in (2, 16, 17, 40, 70):
+        for mode, packed in ((2, False), (4, True), (5, True)) if M <= 16 else ((4, True), (5, True)):
+            y, ssq, h, pk = produce(slice(0, M), mode, packed)
+            assert torch.equal(y, y1[:M]) and torch.equal(ssq, q1[:M]) and torch.equal(h, h1[:M]), (M, mode)
+            c = consume(M, mode, h, pk, ssq, False)
+            assert torch.equal(c, c1[:M]), (M, mode, (c - c1[:M]).abs().max().item())
+    y, ssq, h, pk = produce(slice(0, 64), 4, True)
+    gm = consume(64, 4, h, pk, ssq, True)
+    assert torch.equal(gm[::9], g1[:8])

@@ -40,7 +40,8 @@ class LinearArgs(C.Structure):
                 ("rope_cos", vp), ("rope_sin", vp), ("q_out", vp), ("kv", KvGeom),
                 ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32),
                 ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp),
-                ("bias", vp), ("bias1", vp), ("act_kind", i32)]
+                ("bias", vp), ("bias1", vp), ("act_kind", i32),
+                ("y_norm_w", vp), ("y_h", vp), ("ldh", i32), ("y_ssq", vp), ("x_h", vp), ("x_ssq", vp)]
 
 
 class AttnArgs(C.Structure):
@@ -93,8 +94,8 @@ _EXPORTS = {
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
     "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "ua2_attn_local": (C.c_int, [C.POINTER(AttnArgs), vp]),
-    "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
-    "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "ua2_embed_frame": (C.c_int, [C.c_int, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
     "ua2_conv1d": (C.c_int, [C.POINTER(Conv1dArgs), vp]),
     "ua2_avgpool1d": (C.c_int, [vp, vp, i64, i32, i32, vp]),

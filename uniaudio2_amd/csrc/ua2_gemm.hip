@@ -272,9 +272,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
       for (int it = 0; it < kWM * 4; ++it) {
         const int prow = it * 4 + gq;
         const int m = (pm * kBMT + wm * kWM) * 16 + prow;
-        if (m >= a.M) continue;
-        const float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
-        const float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
+        if (m >= a.M) continue;                          // uniform over the row's 16 lanes
+        float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
+        float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
+        if (a.prologue == UA2_PRO_SCALED) {              // the row scale first, as linear_epilogue does
+          const float rs = scaled_rstd(a, m, j);
+          own.x = __fmul_rn(own.x, rs); own.y = __fmul_rn(own.y, rs); own.z = __fmul_rn(own.z, rs); own.w = __fmul_rn(own.w, rs);
+          oth.x = __fmul_rn(oth.x, rs); oth.y = __fmul_rn(oth.y, rs); oth.z = __fmul_rn(oth.z, rs); oth.w = __fmul_rn(oth.w, rs);
+        }
         const int pos = a.row_pos[m];
         float4 out = own;
         if (rot) {
@@ -638,7 +643,7 @@ extern "C" size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K) {
 }
 
 int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force) {
-  if (a.prologue != UA2_PRO_CAST && a.prologue != UA2_PRO_NORM) return 1;
+  if (a.prologue != UA2_PRO_CAST && a.prologue != UA2_PRO_NORM && !(a.prologue == UA2_PRO_SCALED && a.x_packed)) return 1;
   if (!a.x_packed && (!a.workspace || a.workspace_bytes < ua2_linear_workspace_bytes(a.dtype, a.M, a.K))) return 1;
   const int rt = ua2_gemv_rows_per_tile(a.dtype, a.K);
   if (rt < 1) return 1;                          // the decode kernel cannot take this K at all: nothing to be identical with

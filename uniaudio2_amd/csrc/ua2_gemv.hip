@@ -87,7 +87,13 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   // the epilogue needs goes out BEFORE the weight burst (it then completes in one L2 round trip
   // while the weights are still streaming), never behind it.
   constexpr int XPT = 2;  // float4 per thread kept in registers on the single-row fast path
-  const bool one = (PRO != UA2_PRO_LOCAL_ATTN) && (rows == 1) && (a.K <= XPT * 4 * nthreads);
+  const bool one = (PRO != UA2_PRO_LOCAL_ATTN) && (PRO != UA2_PRO_SCALED) && (rows == 1) && (a.K <= XPT * 4 * nthreads);
+  // UA2_PRO_SCALED: the operand row(s) arrive already rounded (RNE_bf16(x (.) w), written by the producer of x): a 16-byte
+  // copy into the LDS tile — no statistics, no conversion, one barrier.  The first row's piece goes out before the weights.
+  u32x4 xh0 = u32x4{0u, 0u, 0u, 0u};
+  if constexpr (PRO == UA2_PRO_SCALED) {
+    if (tid * 8 < a.K) xh0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.x_h) + (size_t)m0 * a.ldh + tid * 8);
+  }
   float4 xv[XPT], nv[XPT], nb[XPT];
   const bool ln = (PRO == UA2_PRO_NORM) && a.norm_kind == UA2_NORM_LAYERNORM;
   if (one) {
@@ -142,6 +148,16 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   };
   if constexpr (PRO == UA2_PRO_LOCAL_ATTN) {
     // operand row already in LDS
+  } else if constexpr (PRO == UA2_PRO_SCALED) {
+    static_assert(DT == UA2_BF16 || PRO != UA2_PRO_SCALED, "scaled hand-over is a bf16 contract");
+    const int kpad = nchunks * KC;                               // K % 32 == 0 (checked by the launcher): kpad == K
+    for (int r0 = 0; r0 < rows; ++r0) {
+      const unsigned short* xr = reinterpret_cast<const unsigned short*>(a.x_h) + (size_t)(m0 + r0) * a.ldh;
+      for (int k = tid * 8; k < kpad; k += nthreads * 8) {
+        const u32x4 v = (r0 == 0 && k == tid * 8) ? xh0 : *reinterpret_cast<const u32x4*>(xr + k);
+        *reinterpret_cast<u32x4*>(a_lds + ((size_t)r0 * a_stride + k) * BYTES) = v;
+      }
+    }
   } else if (one) {
     NormStat st{0.f, 1.f};
     if constexpr (PRO == UA2_PRO_NORM) {
@@ -389,6 +405,12 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
     if (a.epilogue == UA2_EPI_QKV_ROPE) return launch_cpw<DT, UA2_PRO_CAST, UA2_EPI_QKV_ROPE>(a, s);
   } else if (a.prologue == UA2_PRO_LOCAL_ATTN) {
     if (a.epilogue == UA2_EPI_RESIDUAL) return launch_cpw<DT, UA2_PRO_LOCAL_ATTN, UA2_EPI_RESIDUAL>(a, s);
+  } else if (a.prologue == UA2_PRO_SCALED) {
+    if constexpr (DT == UA2_BF16) {
+      if (a.epilogue == UA2_EPI_QKV_ROPE) return launch_cpw<DT, UA2_PRO_SCALED, UA2_EPI_QKV_ROPE>(a, s);
+      if (a.epilogue == UA2_EPI_SWIGLU) return launch_cpw<DT, UA2_PRO_SCALED, UA2_EPI_SWIGLU>(a, s);
+      if (a.epilogue == UA2_EPI_STORE) return launch_cpw<DT, UA2_PRO_SCALED, UA2_EPI_STORE>(a, s);
+    }
   }
   return 1;  // combination not specialised here: the caller falls back to the general kernel
 }

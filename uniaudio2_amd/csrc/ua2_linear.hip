@@ -61,10 +61,28 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     UA2_CHECK(rc <= 0, "ua2_linear: LOCAL_ATTN problem outside the decode kernel's range");
     return rc;
   }
+  if (a.y_norm_w) {   // producer half of the scaled-norm hand-over
+    UA2_CHECK(a.dtype == UA2_BF16 && (a.epilogue == UA2_EPI_RESIDUAL || a.epilogue == UA2_EPI_STORE) && a.N % 32 == 0 && a.y_ssq &&
+                  (a.y_h || a.y_packed) && (!a.y_h || a.ldh % 8 == 0),
+              "ua2_linear: y_norm_w hand-over needs UA2_BF16, a RESIDUAL / STORE epilogue, N %% 32 == 0, y_ssq and y_h (ldh %% 8 == 0) or y_packed");
+  }
+  if (a.prologue == UA2_PRO_SCALED) {
+    UA2_CHECK(a.dtype == UA2_BF16 && a.K % 32 == 0 && a.x_ssq && (a.x_h || a.x_packed) && (!a.x_h || a.ldh % 8 == 0),
+              "ua2_linear: UA2_PRO_SCALED needs UA2_BF16, K %% 32 == 0, x_ssq and x_h (ldh %% 8 == 0) or x_packed");
+    UA2_CHECK(a.epilogue == UA2_EPI_QKV_ROPE || a.epilogue == UA2_EPI_SWIGLU || a.epilogue == UA2_EPI_STORE,
+              "ua2_linear: UA2_PRO_SCALED serves the QKV_ROPE, SWIGLU and STORE epilogues");
+  }
   if (a.x_packed) {   // operand handed over in fragment order by its producer: only the many-row kernels read it
-    UA2_CHECK(a.prologue == UA2_PRO_CAST && g_force_general != 2, "ua2_linear: x_packed needs PRO_CAST and the many-row kernels");
-    const int rc = ua2_gemm_try_launch(a, s, 3);
+    UA2_CHECK((a.prologue == UA2_PRO_CAST || a.prologue == UA2_PRO_SCALED) && g_force_general != 2,
+              "ua2_linear: x_packed needs PRO_CAST / PRO_SCALED and the many-row kernels");
+    const int rc = ua2_gemm_try_launch(a, s, g_force_general >= 4 ? g_force_general : 3);
     UA2_CHECK(rc <= 0, "ua2_linear: x_packed launch not applicable");
+    return rc;
+  }
+  if (a.prologue == UA2_PRO_SCALED) {   // row-major hand-over: one row tile, the decode kernel
+    UA2_CHECK(a.M <= ua2_gemv_rows_per_tile(a.dtype, a.K), "ua2_linear: x_h serves launches of one row tile (M=%d): hand over x_packed", a.M);
+    const int rc = ua2_gemv_try_launch(a, s);
+    UA2_CHECK(rc <= 0, "ua2_linear: UA2_PRO_SCALED launch outside the decode kernel's range");
     return rc;
   }
   UA2_CHECK(a.prologue == UA2_PRO_CAST || a.prologue == UA2_PRO_NORM, "ua2_linear: bad prologue %d", a.prologue);
@@ -83,7 +101,7 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     UA2_CHECK(a.w1 != nullptr && (a.y != nullptr || a.y_packed != nullptr), "ua2_linear: SWIGLU needs w1 and y or y_packed");
     UA2_CHECK(!a.y_packed || a.N % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_linear: y_packed needs N %% chunk == 0");
   } else if (a.epilogue != UA2_EPI_GELU) {
-    UA2_CHECK(!a.y_packed, "ua2_linear: y_packed is a SWIGLU / GELU output");
+    UA2_CHECK(!a.y_packed || a.y_norm_w, "ua2_linear: y_packed is a SWIGLU / GELU output (or, with y_norm_w, a RESIDUAL / STORE hand-over)");
   }
   if (a.epilogue == UA2_EPI_RESIDUAL) UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
   if (a.epilogue == UA2_EPI_STORE) UA2_CHECK(a.y != nullptr || a.part_max != nullptr, "ua2_linear: STORE needs y or part_max");

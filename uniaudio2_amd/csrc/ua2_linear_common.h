@@ -97,8 +97,36 @@ __device__ __forceinline__ float norm_apply(const ua2_linear_args& a, float x, f
 struct EpiPre {
   float resid = 0.f, cs = 0.f, sn = 0.f;
   float bias = 0.f, bias1 = 0.f;
+  float rstd = 1.f, nw = 1.f;        // UA2_PRO_SCALED: the row's scale; y_norm_w hand-over: the following norm's weight of this column
   int pos = 0, page = 0, forbid = 0;
 };
+
+// ---- scaled-norm hand-over (UA2_PRO_SCALED, include/ua2hip.h) -----------------------------------------------------
+// The one summation tree every producer uses for a row's sum of squares over a 16-column tile (lanes of one 16-lane
+// group hold the 16 columns): butterfly xor 1, 2, 4, 8.  fp add is commutative, so every lane of the group ends with
+// the same bits, and a producer that holds several columns per thread (ua2_misc.hip) reproduces the tree in registers.
+__device__ __forceinline__ float ssq_tile16(float v) {
+  float s = __fmul_rn(v, v);
+  s = __fadd_rn(s, __shfl_xor(s, 1));
+  s = __fadd_rn(s, __shfl_xor(s, 2));
+  s = __fadd_rn(s, __shfl_xor(s, 4));
+  s = __fadd_rn(s, __shfl_xor(s, 8));
+  return s;
+}
+// Row scale of a UA2_PRO_SCALED launch from the producer's partials: lane c of the row's 16-lane group adds partials
+// c, c + 16, ... in ascending order, the 16 chains meet in the same butterfly.  Call with all 16 lanes of the group
+// (rows past M read row M - 1: valid memory, result unused).
+__device__ __forceinline__ float scaled_rstd(const ua2_linear_args& a, int mr, int col) {
+  const int nparts = a.K >> 4;
+  const float* p = a.x_ssq + (size_t)min(mr, a.M - 1) * nparts;
+  float s = 0.f;
+  for (int j = col; j < nparts; j += 16) s = __fadd_rn(s, p[j]);
+  s = __fadd_rn(s, __shfl_xor(s, 1));
+  s = __fadd_rn(s, __shfl_xor(s, 2));
+  s = __fadd_rn(s, __shfl_xor(s, 4));
+  s = __fadd_rn(s, __shfl_xor(s, 8));
+  return 1.0f / sqrtf(s / (float)a.K + a.eps);            // torch.rsqrt(mean(x*x) + eps), as norm_stat
+}
 
 // table row of the paged KV cache for matrix row mr: row_seq == NULL means "row r is sequence r"
 __device__ __forceinline__ int kv_table_row(const ua2_linear_args& a, int mr) { return a.row_seq ? a.row_seq[mr] : mr; }
@@ -107,6 +135,7 @@ __device__ __forceinline__ int kv_table_row(const ua2_linear_args& a, int mr) { 
 template <int DT, int EPI>
 __device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
   const int mr = m0 + row;
+  if (a.prologue == UA2_PRO_SCALED) p.rstd = scaled_rstd(a, mr, col);     // 16-lane shuffles: before any early exit
   if (mr >= a.M) return;
   const int n = tile0 * 16 + col;
   if constexpr (EPI == UA2_EPI_STORE) {
@@ -122,6 +151,8 @@ __device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, in
 // only needed by the epilogue)
 template <int DT, int EPI>
 __device__ __forceinline__ void epilogue_prefetch_b(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
+  if constexpr (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL)
+    if (a.y_norm_w && tile0 * 16 + col < a.N) p.nw = a.y_norm_w[tile0 * 16 + col];    // per output column: here, where the tile is always the real one
   if (a.bias) {                                    // nn.Linear bias: per output column, any epilogue
     const int n = tile0 * 16 + col;
     if (n < a.N) {
@@ -149,6 +180,19 @@ __device__ __forceinline__ void epilogue_prefetch(const ua2_linear_args& a, int 
   epilogue_prefetch_b<DT, EPI>(a, tile0, row, col, p, m0);
 }
 
+// Producer half of the hand-over: `out` = this thread's fp32 result (row mr, column n).  16-lane shuffles: every lane of the
+// row group calls it (columns >= N and rows >= M contribute zeros / store nothing).
+template <int DT>
+__device__ __forceinline__ void handover_emit(const ua2_linear_args& a, float out, float nw, int mr, int n, int tile, int col, bool rvalid) {
+  const bool live = rvalid && n < a.N;
+  const float s = ssq_tile16(live ? out : 0.f);
+  if (!live) return;
+  if (a.y_ssq && col == 0) a.y_ssq[(size_t)mr * ((a.N + 15) >> 4) + tile] = s;
+  const float h = __fmul_rn(out, nw);
+  if (a.y_h) store_elem<DT>(a.y_h, (size_t)mr * a.ldh + n, h);
+  if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, h);
+}
+
 // NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.
 template <int DT, int EPI, int NT>
 __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&vin)[NT], const int (&tile)[NT],
@@ -158,6 +202,10 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
   float v[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) v[t] = vin[t];
+  if (a.prologue == UA2_PRO_SCALED) {              // y = rstd * (bf16(x (.) w) W^T): one rounding on the fp32 sum
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = __fmul_rn(v[t], p.rstd);
+  }
   if (a.bias) {                                    // absent (every Linear of the LM): the sums pass through untouched
     v[0] = __fadd_rn(v[0], p.bias);
     if constexpr (NT == 2) v[1] = __fadd_rn(v[1], p.bias1);
@@ -166,6 +214,7 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
   if constexpr (EPI == UA2_EPI_STORE) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N && a.y) a.y[(size_t)mr * a.ldy + n] = v[0];
+    if (a.y_norm_w) handover_emit<DT>(a, v[0], p.nw, mr, n, tile[0], col, rvalid);
     if (a.part_max) {
       float bv = (n < a.N && n >= p.forbid) ? v[0] : -INFINITY;
       int bi = n;
@@ -183,7 +232,9 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
     }
   } else if constexpr (EPI == UA2_EPI_RESIDUAL) {
     const int n = tile[0] * 16 + col;
-    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = __fadd_rn(a.out_scale ? __fmul_rn(a.out_scale[n], v[0]) : v[0], p.resid);
+    const float out = __fadd_rn(a.out_scale ? __fmul_rn(a.out_scale[min(n, a.N - 1)], v[0]) : v[0], p.resid);
+    if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = out;
+    if (a.y_norm_w) handover_emit<DT>(a, out, p.nw, mr, n, tile[0], col, rvalid);
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {

@@ -32,6 +32,47 @@ extern "C" size_t ua2_struct_size(int which) {
 
 namespace {
 
+// ---- producer half of the scaled-norm hand-over for row-wise kernels (include/ua2hip.h ua2_handover) ----------------
+// The sum of squares of a 16-column tile must be added in the tree the linear epilogues use (ua2_linear_common.h
+// ssq_tile16: butterfly xor 1, 2, 4, 8 over 16 lanes holding one column each).  A thread holding 8 (4) consecutive columns
+// does the first three (two) levels in registers — same operands, same pairing — and the rest by exchanging with its
+// neighbour thread(s); fp add is commutative, so the bits are those of the 16-lane butterfly.
+__device__ __forceinline__ void handover_emit8(const ua2_handover& ho, const float (&v)[8], int m, int c, int C) {
+  const float q0 = __fmul_rn(v[0], v[0]), q1 = __fmul_rn(v[1], v[1]), q2 = __fmul_rn(v[2], v[2]), q3 = __fmul_rn(v[3], v[3]);
+  const float q4 = __fmul_rn(v[4], v[4]), q5 = __fmul_rn(v[5], v[5]), q6 = __fmul_rn(v[6], v[6]), q7 = __fmul_rn(v[7], v[7]);
+  const float b0 = __fadd_rn(__fadd_rn(q0, q1), __fadd_rn(q2, q3)), b1 = __fadd_rn(__fadd_rn(q4, q5), __fadd_rn(q6, q7));
+  float s = __fadd_rn(b0, b1);
+  s = __fadd_rn(s, __shfl_xor(s, 1));                       // the other half of the tile lives in the neighbour thread
+  if (((c >> 3) & 1) == 0) ho.ssq[(size_t)m * (C >> 4) + (c >> 4)] = s;
+  const float4 w0 = *reinterpret_cast<const float4*>(ho.norm_w + c), w1 = *reinterpret_cast<const float4*>(ho.norm_w + c + 4);
+  u32x4 pk;
+  pk[0] = (unsigned)f2bf(__fmul_rn(v[0], w0.x)) | ((unsigned)f2bf(__fmul_rn(v[1], w0.y)) << 16);
+  pk[1] = (unsigned)f2bf(__fmul_rn(v[2], w0.z)) | ((unsigned)f2bf(__fmul_rn(v[3], w0.w)) << 16);
+  pk[2] = (unsigned)f2bf(__fmul_rn(v[4], w1.x)) | ((unsigned)f2bf(__fmul_rn(v[5], w1.y)) << 16);
+  pk[3] = (unsigned)f2bf(__fmul_rn(v[6], w1.z)) | ((unsigned)f2bf(__fmul_rn(v[7], w1.w)) << 16);
+  if (ho.h) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(ho.h) + (size_t)m * ho.ldh + c) = pk;
+  if (ho.packed) {   // 8 consecutive k of one chunk = the 16 bytes of lane (k % 32) / 8 * 16 + (m & 15)
+    const size_t slot = (((size_t)(m >> 4) * (C >> 5) + (c >> 5)) * 64 + ((c & 31) >> 3) * 16 + (m & 15));
+    reinterpret_cast<u32x4*>(ho.packed)[slot] = pk;
+  }
+}
+__device__ __forceinline__ void handover_emit4(const ua2_handover& ho, const float4& v, int m, int c, int C) {
+  const float q0 = __fmul_rn(v.x, v.x), q1 = __fmul_rn(v.y, v.y), q2 = __fmul_rn(v.z, v.z), q3 = __fmul_rn(v.w, v.w);
+  float s = __fadd_rn(__fadd_rn(q0, q1), __fadd_rn(q2, q3));
+  s = __fadd_rn(s, __shfl_xor(s, 1));                       // columns c ^ 4
+  s = __fadd_rn(s, __shfl_xor(s, 2));                       // columns c ^ 8
+  if ((c & 15) == 0) ho.ssq[(size_t)m * (C >> 4) + (c >> 4)] = s;
+  const float4 w = *reinterpret_cast<const float4*>(ho.norm_w + c);
+  uint2 pk;
+  pk.x = (unsigned)f2bf(__fmul_rn(v.x, w.x)) | ((unsigned)f2bf(__fmul_rn(v.y, w.y)) << 16);
+  pk.y = (unsigned)f2bf(__fmul_rn(v.z, w.z)) | ((unsigned)f2bf(__fmul_rn(v.w, w.w)) << 16);
+  if (ho.h) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(ho.h) + (size_t)m * ho.ldh + c) = pk;
+  if (ho.packed) {
+    const size_t slot = (((size_t)(m >> 4) * (C >> 5) + (c >> 5)) * 64 + ((c & 31) >> 3) * 16 + (m & 15));
+    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ho.packed) + slot * 16 + (c & 7) * 2) = pk;
+  }
+}
+
 // model_new.py:594-600 (_embed_audio_tokens + masked sum over the 8 streams), :604 (wte)
 // One workgroup per row; a thread owns 8 consecutive channels (16 B of a bf16 table row, 32 B of an fp32
 // one).  The token ids are read once, then all ncb + 1 table rows are requested before the first is summed:
@@ -40,7 +81,7 @@ template <int DT, int NCB>
 __global__ __launch_bounds__(512) void embed_frame_kernel(int C, int ncb, int va, const int32_t* __restrict__ tokens,
                                                           const uint8_t* __restrict__ mask, const void* __restrict__ audio_emb,
                                                           const void* __restrict__ wte, float* __restrict__ audio_sum,
-                                                          float* __restrict__ text) {
+                                                          float* __restrict__ text, const ua2_handover ho) {
   const int m = blockIdx.x;
   const int32_t* tk = tokens + (size_t)m * (ncb + 1);
   const uint8_t* mk = mask + (size_t)m * (ncb + 1);
@@ -83,6 +124,9 @@ __global__ __launch_bounds__(512) void embed_frame_kernel(int C, int ncb, int va
     *reinterpret_cast<float4*>(as + 4) = make_float4(s[4], s[5], s[6], s[7]);
     *reinterpret_cast<float4*>(tx) = make_float4(e[NCB][0], e[NCB][1], e[NCB][2], e[NCB][3]);
     *reinterpret_cast<float4*>(tx + 4) = make_float4(e[NCB][4], e[NCB][5], e[NCB][6], e[NCB][7]);
+    if constexpr (DT == UA2_BF16) {
+      if (ho.norm_w) handover_emit8(ho, s, m, c, C);     // the understanding expert's first layer reads audio_sum (C % 16 == 0: pairs of threads)
+    }
   }
 }
 
@@ -112,7 +156,8 @@ __global__ void embed_frame_any_kernel(int C, int ncb, int va, const int32_t* __
 // chain over its float4s in ascending order, xor-shuffle tree, four wave partials left to right.
 __global__ __launch_bounds__(256) void rmsnorm_blend_kernel(int C, const float* __restrict__ x, const float* __restrict__ w, float eps,
                                                             const float* __restrict__ other, const uint8_t* __restrict__ mask, int mask_ld,
-                                                            int col_a, int col_b, float* __restrict__ out1, float* __restrict__ out2) {
+                                                            int col_a, int col_b, float* __restrict__ out1, float* __restrict__ out2,
+                                                            const ua2_handover ho) {
   constexpr int KEEP = 4;
   __shared__ float part[4];
   const int m = blockIdx.x;
@@ -148,6 +193,7 @@ __global__ __launch_bounds__(256) void rmsnorm_blend_kernel(int C, const float* 
     }
     *reinterpret_cast<float4*>(out1 + (size_t)m * C + c) = o1;
     if (out2) *reinterpret_cast<float4*>(out2 + (size_t)m * C + c) = n;
+    if (ho.norm_w) handover_emit4(ho, o1, m, c, C);       // out1 enters the next GPT's first layer (C % 16 == 0: whole groups of 4 threads)
   }
 }
 
@@ -225,15 +271,21 @@ __global__ __launch_bounds__(256) void cfg_mix_kernel(float* __restrict__ logits
 
 extern "C" int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, int32_t va, const int32_t* tokens,
                                const uint8_t* mask, const void* audio_emb, const void* wte, float* audio_sum,
-                               float* text, void* stream) {
+                               float* text, const ua2_handover* hop, void* stream) {
   UA2_CHECK(M > 0 && C > 0 && tokens && mask && audio_emb && wte && audio_sum && text, "ua2_embed_frame: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const bool fast = n_cb == 8 && C % 8 == 0;
+  ua2_handover ho{};
+  if (hop && hop->norm_w) {
+    UA2_CHECK(dtype == UA2_BF16 && fast && C % 32 == 0 && hop->ssq && (hop->h || hop->packed) && (!hop->h || hop->ldh % 8 == 0),
+              "ua2_embed_frame: hand-over needs UA2_BF16, n_cb == 8, C %% 32 == 0, ssq and h (ldh %% 8 == 0) or packed");
+    ho = *hop;
+  }
   const int nthr = std::min(512, std::max(64, (C / 8 + 63) / 64 * 64));
   if (dtype == UA2_BF16 && fast)
-    hipLaunchKernelGGL((embed_frame_kernel<UA2_BF16, 8>), dim3(M), dim3(nthr), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+    hipLaunchKernelGGL((embed_frame_kernel<UA2_BF16, 8>), dim3(M), dim3(nthr), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text, ho);
   else if (dtype == UA2_F32 && fast)
-    hipLaunchKernelGGL((embed_frame_kernel<UA2_F32, 8>), dim3(M), dim3(nthr), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
+    hipLaunchKernelGGL((embed_frame_kernel<UA2_F32, 8>), dim3(M), dim3(nthr), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text, ho);
   else if (dtype == UA2_BF16)
     hipLaunchKernelGGL((embed_frame_any_kernel<UA2_BF16>), dim3(M), dim3(256), 0, s, C, n_cb, va, tokens, mask, audio_emb, wte, audio_sum, text);
   else if (dtype == UA2_F32)
@@ -248,11 +300,17 @@ extern "C" int ua2_embed_frame(int dtype, int32_t M, int32_t C, int32_t n_cb, in
 
 extern "C" int ua2_rmsnorm_blend(int32_t M, int32_t C, const float* x, const float* w, float eps, const float* other,
                                  const uint8_t* mask, int32_t mask_ld, int32_t col_a, int32_t col_b, float* out1,
-                                 float* out2, void* stream) {
+                                 float* out2, const ua2_handover* hop, void* stream) {
   UA2_CHECK(M > 0 && C > 0 && C % 4 == 0 && x && w && out1, "ua2_rmsnorm_blend: bad arguments (C must be a multiple of 4)");
   UA2_CHECK((col_a < 0 && !other) || mask, "ua2_rmsnorm_blend: mask needed");
+  ua2_handover ho{};
+  if (hop && hop->norm_w) {
+    UA2_CHECK(C % 32 == 0 && hop->ssq && (hop->h || hop->packed) && (!hop->h || hop->ldh % 8 == 0),
+              "ua2_rmsnorm_blend: hand-over needs C %% 32 == 0, ssq and h (ldh %% 8 == 0) or packed");
+    ho = *hop;
+  }
   hipLaunchKernelGGL(rmsnorm_blend_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, C, x, w, eps, other, mask,
-                     mask_ld, col_a, col_b, out1, out2);
+                     mask_ld, col_a, col_b, out1, out2, ho);
   UA2_LAUNCH_CHECK();
   return 0;
 }

@@ -29,6 +29,12 @@ struct ua2_stage3 {
   void* gemm_ws;               // operand scratch of the large-M linear kernel (max_rows x widest K)
   size_t gemm_ws_bytes;
   void* act_ws;                // packed SwiGLU output handed straight to the down-projection (max_rows x widest intermediate)
+  // scaled-norm hand-over of the residual stream (UA2_PRO_SCALED, bf16): every producer of x also writes RNE_bf16(x (.) w_next)
+  // for the RMSNorm + Linear that follows (row-major for launches of one row tile, fragment order otherwise) and the
+  // per-16-column sums of squares — no prep launch and no in-kernel statistics between a residual update and its consumer
+  void *xh, *xpk;
+  float* ssq;
+  bool scaled = false;
   int32_t npart_t, npart_a;
   int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
   float temperature = 1.f;
@@ -50,7 +56,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -73,6 +79,10 @@ Carve carve(const ua2_stage3_desc& d) {
   c.gemm_ws_floats = ua2_linear_workspace_bytes(d.dtype, (int64_t)R, (int64_t)std::max(std::max(C, Cd), std::max(qmax, actmax))) / sizeof(float);
   c.gemm_ws = take(c.gemm_ws_floats);
   c.act_ws = take(ua2_linear_workspace_bytes(d.dtype, (int64_t)R, (int64_t)actmax) / sizeof(float));
+  const size_t Cw = std::max(C, Cd);
+  c.xh = take(R * Cw / 2);                                       // bf16 rows
+  c.xpk = take(ua2_linear_workspace_bytes(UA2_BF16, (int64_t)R, (int64_t)Cw) / sizeof(float));
+  c.ssq = take(R * (Cw / 16 + 1));
   c.total = off;
   return c;
 }
@@ -85,10 +95,35 @@ void fresh_args(const ua2_stage3* h, ua2_linear_args& a) {
 }
 
 // local = the depth decoder: positions < kLocalCtx, short-context attention (fused into the O-projection when R == 1)
+// hand-over helpers: which form the consumer of a C-wide row reads (row-major: its launch is one row tile of the decode kernel)
+struct Handover {
+  ua2_stage3* h; int R, C; bool rows_h;
+  Handover(ua2_stage3* h_, int R_, int C_) : h(h_), R(R_), C(C_), rows_h(R_ <= ua2_gemv_rows_per_tile(h_->d.dtype, C_)) {}
+  void consume(ua2_linear_args& a) const {
+    a.prologue = UA2_PRO_SCALED; a.x_ssq = h->ssq; a.x = nullptr; a.norm_w = nullptr;
+    if (rows_h) { a.x_h = h->xh; a.ldh = C; } else { a.x_packed = h->xpk; }
+  }
+  void produce(ua2_linear_args& a, const float* norm_w_next) const {
+    if (!norm_w_next) return;
+    a.y_norm_w = norm_w_next; a.y_ssq = h->ssq;
+    if (rows_h) { a.y_h = h->xh; a.ldh = C; } else { a.y_packed = h->xpk; }
+  }
+  ua2_handover rowwise(const float* norm_w_next) const {
+    ua2_handover ho{};
+    ho.norm_w = norm_w_next; ho.ssq = h->ssq;
+    if (rows_h) { ho.h = h->xh; ho.ldh = C; } else { ho.packed = h->xpk; }
+    return ho;
+  }
+};
+
+// final_norm_w: weight of the RMSNorm + Linear that consumes this GPT's OUTPUT through UA2_PRO_SCALED (the depth decoder's
+// ln_f in front of audio_head), or NULL (the trunk GPTs end in ua2_rmsnorm_blend, which reads the fp32 stream).
+// With h->scaled the caller has already handed over x for layer 0 (embed_frame / rmsnorm_blend / the projection's epilogue).
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
-            const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false) {
+            const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false, const float* final_norm_w = nullptr) {
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
+  const Handover ho(h, R, C);
   for (int l = 0; l < g.n_layer; ++l) {
     ua2_kv_geom kv{};                      // ring_pages = 0: the LM's caches are linear
     kv.k_pool = h->pools[gi][0][l]; kv.v_pool = h->pools[gi][1][l]; kv.page_table = g.page_table;
@@ -100,6 +135,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = nqkv; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][0][l]; a.eps = g.eps;
     a.w0 = h->ptrs[gi][0][l]; a.row_pos = row_pos; a.row_seq = row_seq; a.rope_cos = g.rope_cos;
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
+    if (h->scaled) ho.consume(a);
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     static const bool no_fuse = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
@@ -127,6 +163,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (fuse_attn) { a.row_pos = row_pos; a.row_seq = row_seq; a.kv = kv; }
     if (pack_o && !fuse_attn) a.x_packed = h->gemm_ws;
+    if (h->scaled) ho.produce(a, h->norms[gi][1][l]);              // x after attention -> norm_2 + fc_1 / fc_2
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -134,6 +171,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = g.inter; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][1][l]; a.eps = g.eps;
     a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.ldy = g.inter;
     if (pack_act) a.y_packed = h->act_ws; else a.y = h->act;
+    if (h->scaled) ho.consume(a);
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -141,6 +179,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = C; a.K = g.inter; a.x = h->act; a.ldx = g.inter; a.w0 = h->ptrs[gi][4][l];
     a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (pack_act) a.x_packed = h->act_ws;
+    if (h->scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
     if (int rc = ua2_linear_launch(a, s)) return rc;
   }
   return 0;
@@ -212,6 +251,9 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->pmax_a = b + c.pmax_a; h->pidx_a = (int32_t*)(b + c.pidx_a);
   h->gemm_ws = b + c.gemm_ws; h->gemm_ws_bytes = c.gemm_ws_floats * sizeof(float);
   h->act_ws = b + c.act_ws;
+  h->xh = b + c.xh; h->xpk = b + c.xpk; h->ssq = b + c.ssq;
+  // the scaled contract is the bf16 executor's (fp32 keeps the reference's operation order); A/B hook: UA2_NO_SCALED=1
+  h->scaled = d->dtype == UA2_BF16 && getenv("UA2_NO_SCALED") == nullptr && d->backbone.n_embd % 32 == 0 && d->decoder.n_embd % 32 == 0;
   h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
   *out = h;
   return 0;
@@ -233,17 +275,20 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   ua2_stage3_desc d = h->d;
   if (identity) d.row_seq = nullptr;
   const int C = d.backbone.n_embd, w = d.n_cb + 1;
-  if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, s)) return rc;
+  const Handover ho(h, R, C);
+  ua2_handover e0{}, e1{}, e2{};
+  if (h->scaled) { e0 = ho.rowwise(h->norms[0][0][0]); e1 = ho.rowwise(h->norms[1][0][0]); e2 = ho.rowwise(h->norms[2][0][0]); }
+  if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, &e0, s)) return rc;
   const bool grouped = !identity;   // prefill chunks (ua2_stage3_trunk) may carry row groups; decode frames never do
   if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
   // backbone_input = h_audio*audio_step + text_embeds*text_step   (model_new.py:607)
-  if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, s)) return rc;
+  if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, &e1, s)) return rc;
   if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
   // h = ln_f(x); generation_input = h*audio_step                   (model_new.py:609-610)
-  if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, s)) return rc;
+  if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, &e2, s)) return rc;
   if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
   // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
-  if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, s)) return rc;
+  if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, nullptr, s)) return rc;
   return 0;
 }
 
@@ -334,13 +379,17 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
+    const Handover hod(h, R, Cd);
+    if (h->scaled) hod.produce(a, h->norms[3][0][0]);
     if (int rc = ua2_linear_launch(a, s)) return rc;
-    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8)) return rc;
+    if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8, false,
+                         h->scaled ? d.decoder.ln_f : nullptr)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
     a.w0 = h->audio_head[i]; a.y = h->audio_logits + (size_t)i * d.va; a.ldy = d.n_cb * d.va;
     a.part_max = h->pmax_a; a.part_idx = h->pidx_a; a.forbid = d.forbid;
+    if (h->scaled) hod.consume(a);
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (cfg)   // model_new.py:634-637
       if (int rc = ua2_cfg_mix(h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->cfg_scale, d.forbid, h->pmax_a,

@@ -61,7 +61,7 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
            w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
            forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True,
            norm_b=None, norm_kind=0, out_scale=None, rope_mode=0, workspace=None, bias=None, bias1=None, act_kind=0,
-           y_packed=None, x_packed=None):
+           y_packed=None, x_packed=None, y_norm_w=None, y_h=None, ldh=0, y_ssq=None, x_h=None, x_ssq=None):
     a = LinearArgs()
     a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
     a.M, a.N, a.K = M, N, K
@@ -76,6 +76,8 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
     a.norm_b, a.norm_kind, a.out_scale, a.rope_mode = ptr(norm_b), norm_kind, ptr(out_scale), rope_mode
     a.bias, a.bias1, a.act_kind = ptr(bias), ptr(bias1), act_kind
     a.y_packed, a.x_packed = ptr(y_packed), ptr(x_packed)
+    a.y_norm_w, a.y_h, a.y_ssq, a.x_h, a.x_ssq = ptr(y_norm_w), ptr(y_h), ptr(y_ssq), ptr(x_h), ptr(x_ssq)
+    a.ldh = ldh or (y_h.shape[-1] if y_h is not None else (x_h.shape[-1] if x_h is not None else 0))
     if workspace is not None:
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     if kv is not None:
@@ -155,7 +157,7 @@ def embed_frame(dtype, tokens, mask, audio_emb, wte, va):
     a = torch.empty(M, Cc, dtype=torch.float32, device=tokens.device)
     t = torch.empty_like(a)
     check(lib.ua2_embed_frame(dtype_code(dtype), M, Cc, w - 1, va, ptr(tokens), ptr(mask), ptr(audio_emb), ptr(wte),
-                              ptr(a), ptr(t), stream()), "ua2_embed_frame")
+                              ptr(a), ptr(t), None, stream()), "ua2_embed_frame")
     return a, t
 
 
@@ -164,7 +166,7 @@ def rmsnorm_blend(x, w, eps, other=None, mask=None, col_a=-1, col_b=-1, want_n=F
     o1 = torch.empty_like(x)
     o2 = torch.empty_like(x) if want_n else None
     check(lib.ua2_rmsnorm_blend(M, Cc, ptr(x), ptr(w), eps, ptr(other), ptr(mask),
-                                mask.shape[1] if mask is not None else 0, col_a, col_b, ptr(o1), ptr(o2), stream()),
+                                mask.shape[1] if mask is not None else 0, col_a, col_b, ptr(o1), ptr(o2), None, stream()),
           "ua2_rmsnorm_blend")
     return (o1, o2) if want_n else o1
 
