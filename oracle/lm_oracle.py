@@ -88,12 +88,16 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def norm_linear(x, w, eps, mats, mode):
+def norm_linear(x, w, eps, mats, mode, scaled=True):
     """RMSNorm(x) followed by one or more Linear layers (lit_model.py:883-890 + :424 / :591-592).  fp32: as the reference
-    evaluates it.  bf16: the product's scaled form (module docstring)."""
+    evaluates it.  bf16: the product's scaled form (module docstring) on decode frames; `scaled=False` = the form its prefill
+    passes keep (and plans for more than 64 sequences): the normalised row rounded to bf16, RNE_bf16((x * rstd) * w) W^T."""
     if mode != "bf16":
         xn = rmsnorm(x, w, eps)
         return [F.linear(xn, m) for m in mats]
+    if not scaled:
+        a = _bf16(rmsnorm(x, w, eps))
+        return [F.linear(a, m) for m in mats]
     x = x.float()
     rstd = torch.rsqrt(torch.mean(x * x, dim=-1, keepdim=True) + eps)
     a = _bf16(x * w.float())
@@ -131,7 +135,7 @@ class GPTOracle:
         for t in self.k + self.v:
             t.zero_()
 
-    def forward(self, x, input_pos, maxp1=None, final_norm=True):
+    def forward(self, x, input_pos, maxp1=None, final_norm=True, scaled=True):
         """x (B, T, C) fp32; input_pos (B, T) long (per-sequence positions).  lit_model.py:83-180.
         final_norm=False returns the stream BEFORE ln_f (the caller folds ln_f into the Linear that follows)."""
         s = self.s
@@ -143,7 +147,7 @@ class GPTOracle:
         nh, ng, hs = s.n_head, s.n_query_groups, s.head_size
         bidx = torch.arange(B).unsqueeze(1).expand(B, T)
         for li, W in enumerate(self.layers):                            # Block.forward :337-349
-            qkv, = norm_linear(x, W["norm_1"], s.norm_eps, [W["qkv"]], self.mode)     # :341, :424
+            qkv, = norm_linear(x, W["norm_1"], s.norm_eps, [W["qkv"]], self.mode, scaled)     # :341, :424
             q, k, v = qkv.split((nh * hs, ng * hs, ng * hs), dim=-1)    # :431
             q = q.view(B, T, nh, hs).transpose(1, 2)
             k = k.view(B, T, ng, hs).transpose(1, 2)
@@ -160,7 +164,7 @@ class GPTOracle:
                                                scale=1.0 / math.sqrt(hs))       # :529-531
             y = y.transpose(1, 2).reshape(B, T, nh * hs)
             x = F.linear(self.qa(y), W["proj"]) + x                     # :511, :345
-            g1, g2 = norm_linear(x, W["norm_2"], s.norm_eps, [W["fc_1"], W["fc_2"]], self.mode)
+            g1, g2 = norm_linear(x, W["norm_2"], s.norm_eps, [W["fc_1"], W["fc_2"]], self.mode, scaled)
             h = F.silu(g1) * g2                                         # LLaMAMLP :591-595
             x = F.linear(self.qa(h), W["mlp_proj"]) + x
         return rmsnorm(x, self.ln_f, s.norm_eps) if final_norm else x   # :164
@@ -202,16 +206,16 @@ class Stage3Oracle:
         off = self.va * torch.arange(self.ncb)
         return self.audio_embeddings[(tokens[:, :, :-1] + off)]
 
-    def _trunk(self, tokens, mask, input_pos, maxp1):
+    def _trunk(self, tokens, mask, input_pos, maxp1, scaled=True):
         """Shared by forward_prefix (:471-497) and generate_frame (:594-613).
         tokens (B,S,9) long; mask (B,S,9) bool; input_pos (B,S)."""
         a_step = mask[:, :, 0].unsqueeze(-1).float()
         t_step = mask[:, :, -1].unsqueeze(-1).float()
         a_in = (self._embed_audio_tokens(tokens) * mask[:, :, :-1].unsqueeze(-1).float()).sum(dim=2)
-        h_a = self.und.forward(a_in, input_pos, maxp1)
+        h_a = self.und.forward(a_in, input_pos, maxp1, scaled=scaled)
         text = self.wte[tokens[:, :, -1]]
-        h = self.backbone.forward(h_a * a_step + text * t_step, input_pos, maxp1)
-        h_g = self.gen.forward(h * a_step, input_pos, maxp1)
+        h = self.backbone.forward(h_a * a_step + text * t_step, input_pos, maxp1, scaled=scaled)
+        h_g = self.gen.forward(h * a_step, input_pos, maxp1, scaled=scaled)
         return h_g * a_step + h * t_step
 
     @torch.inference_mode()
@@ -219,7 +223,7 @@ class Stage3Oracle:
         """model_new.py:456-507.  tokens (B,S,9); tokens_mask (B,S+1,9) as the caller passes it
         (evaluation/tts_task.py:244); input_pos (B,S).  No input_pos_maxp1 => attends all slots
         under the mask.  The discarded lm_head / local-decoder work (:498-506) is not restated."""
-        return self._trunk(tokens, tokens_mask[:, :-1], input_pos, None)
+        return self._trunk(tokens, tokens_mask[:, :-1], input_pos, None, scaled=False)     # the product's prefill passes keep the unscaled form
 
     @torch.inference_mode()
     def generate_frame(self, tokens, tokens_mask, input_pos, input_pos_maxp1=None, forbid_prefix=0, cfg_scale=1.0):

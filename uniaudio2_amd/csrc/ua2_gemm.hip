@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "ua2_common.h"
 #include "ua2_linear_common.h"
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
 constexpr int kKS = 2;      // chunks per LDS stage
 constexpr int kGroupM = 8;  // row-blocks per L2 patch
 
-template <int DT, int EPI, int kBMT>
+template <int DT, int EPI, int kBMT, bool HO>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
                                                       const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
         float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
         float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
         if (a.prologue == UA2_PRO_SCALED) {              // the row scale first, as linear_epilogue does
-          const float rs = scaled_rstd(a, m, j);
+          const float rs = scaled_rstd_row(a, m, j);      // the row's 16 lanes together (the ring holds the patches: no LDS to spare)
           own.x = __fmul_rn(own.x, rs); own.y = __fmul_rn(own.y, rs); own.z = __fmul_rn(own.z, rs); own.w = __fmul_rn(own.w, rs);
           oth.x = __fmul_rn(oth.x, rs); oth.y = __fmul_rn(oth.y, rs); oth.z = __fmul_rn(oth.z, rs); oth.w = __fmul_rn(oth.w, rs);
         }
@@ -392,12 +393,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
         for (int t = 0; t < NT; ++t) tile[t] = nt;
         EpiPre pre[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) epilogue_prefetch<DT, EPI>(a, nt, 4 * gg + r, colg, pre[r], m0);
+        for (int r = 0; r < 4; ++r) {
+          epilogue_prefetch<DT, EPI>(a, nt, 4 * gg + r, colg, pre[r], m0);
+          if (a.prologue == UA2_PRO_SCALED) pre[r].rstd = scaled_rstd_row(a, m0 + 4 * gg + r, colg);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v[NT];
           v[0] = patch[((mi * WN + ni) * 4 + r) * 64 + lane];
-          linear_epilogue<DT, EPI, NT>(a, v, tile, 4 * gg + r, colg, pre[r], m0, rows);
+          linear_epilogue<DT, EPI, NT, HO>(a, v, tile, 4 * gg + r, colg, pre[r], m0, rows);
         }
       }
     }
@@ -419,6 +423,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
 #pragma unroll
       for (int r = 0; r < 4; ++r) epilogue_prefetch_a<DT, EPI>(a, 0, 4 * g + r, col, row_pre[r], m0);
     }
+    float row_rstd[4] = {1.f, 1.f, 1.f, 1.f};                          // UA2_PRO_SCALED: once per row tile, the row's 16 lanes together
+    if (a.prologue == UA2_PRO_SCALED) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row_rstd[r] = scaled_rstd_row(a, m0 + 4 * g + r, col);
+    }
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
       const int nt = pn * BNT + wn * WN + ni;
@@ -433,13 +442,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
         if constexpr (EPI != UA2_EPI_QKV_ROPE && EPI != UA2_EPI_STORE) epilogue_prefetch_a<DT, EPI>(a, nt, 4 * g + r, col, pre[r], m0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) epilogue_prefetch_b<DT, EPI>(a, nt, 4 * g + r, col, pre[r], m0);
+      for (int r = 0; r < 4; ++r) {
+        epilogue_prefetch_b<DT, EPI>(a, nt, 4 * g + r, col, pre[r], m0);
+        pre[r].rstd = row_rstd[r];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = tot[t][mi][ni][r];
-        linear_epilogue<DT, EPI, NT>(a, v, tile, 4 * g + r, col, pre[r], m0, rows);
+        linear_epilogue<DT, EPI, NT, HO>(a, v, tile, 4 * g + r, col, pre[r], m0, rows);
       }
     }
   }
@@ -462,9 +474,11 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const ua2_linear_args a, c
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);               // [nw][NT][MT][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  float* rstd_l = red + (size_t)nw * NT * MT * 256;          // [MT * 16] row scales (UA2_PRO_SCALED)
   const int nchunks = (a.K + KC - 1) / KC;
   const int mtiles = (a.M + 15) / 16;
   const int nt = blockIdx.x, mt0 = blockIdx.y * MT;
+  if (a.prologue == UA2_PRO_SCALED) scaled_rstd_rows(a, mt0 * 16, min(MT * 16, a.M - mt0 * 16), rstd_l, tid, blockDim.x);
   const u32x4* wp[NT];
   wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)nt * nchunks * 64 + lane;
   if constexpr (NT == 2) wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)nt * nchunks * 64 + lane;
@@ -518,6 +532,10 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const ua2_linear_args a, c
   for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mt0 + mi) * 16);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mt0 + mi) * 16);
+  if (a.prologue == UA2_PRO_SCALED) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) pre[mi].rstd = rstd_l[mi * 16 + row];
+  }
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int m0 = (mt0 + mi) * 16;
@@ -538,7 +556,7 @@ void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t 
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr auto kern = skinny_kernel<DT, EPI, 4>;
   ua2_allow_big_lds<kern>();
-  const size_t smem = (size_t)geo.waves * NT * kSkinnyMT * 256 * sizeof(float);
+  const size_t smem = (size_t)geo.waves * NT * kSkinnyMT * 256 * sizeof(float) + kSkinnyMT * 16 * sizeof(float);
   const dim3 grid(ua2_ceil_div(a.N, 16), ua2_ceil_div(ua2_ceil_div(a.M, 16), kSkinnyMT));
   hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace));
 }
@@ -562,16 +580,21 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   const int64_t g8 = (int64_t)ua2_ceil_div(mtiles, 8) * nblocks, g4 = (int64_t)ua2_ceil_div(mtiles, 4) * nblocks;
   const int bmt = force_bmt ? force_bmt : (g8 >= 512 ? 8 : (g4 >= 256 ? 4 : 2));
   const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
-  if (bmt == 2) {
-    const int mblocks = ua2_ceil_div(mtiles, 2);
-    hipLaunchKernelGGL((gemm_kernel<DT, EPI, 2>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
-  } else if (bmt == 4) {
-    const int mblocks = ua2_ceil_div(mtiles, 4);
-    hipLaunchKernelGGL((gemm_kernel<DT, EPI, 4>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
-  } else {
-    const int mblocks = ua2_ceil_div(mtiles, 8);
-    hipLaunchKernelGGL((gemm_kernel<DT, EPI, 8>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
-  }
+  constexpr bool kCanHo = (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL);
+  const bool ho = kCanHo && a.y_norm_w != nullptr;
+  auto go = [&](auto bmt_c, auto ho_c) {
+    constexpr int B = decltype(bmt_c)::value;
+    constexpr bool H = decltype(ho_c)::value;
+    const int mblocks = ua2_ceil_div(mtiles, B);
+    hipLaunchKernelGGL((gemm_kernel<DT, EPI, B, H>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
+  };
+  auto pick = [&](auto bmt_c) {
+    if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}); return; } }
+    go(bmt_c, std::false_type{});
+  };
+  if (bmt == 2) pick(std::integral_constant<int, 2>{});
+  else if (bmt == 4) pick(std::integral_constant<int, 4>{});
+  else pick(std::integral_constant<int, 8>{});
 }
 
 // Which of the two forms is faster — both give the same bits, so this is purely a cost model, fitted on

@@ -115,6 +115,10 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   }
   EpiPre pre;
   if (tid < 256) epilogue_prefetch_a<DT, EPI>(a, tile[0], tid >> 4, tid & 15, pre, m0);
+  float ssqv[16];                                        // UA2_PRO_SCALED: the row's sum-of-squares partials, requested before the burst
+  if constexpr (PRO == UA2_PRO_SCALED) {
+    if (tid < 256) scaled_ssq_request(a, m0 + min(tid >> 4, rows - 1), tid & 15, ssqv);
+  }
 
   u32x4 wf[NT][CPW];
   auto burst = [&]() {
@@ -235,6 +239,9 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
         put(r0, k, t);
       }
     }
+  }
+  if constexpr (PRO == UA2_PRO_SCALED) {
+    if (tid < 256) pre.rstd = scaled_rstd_reduce(a, tid & 15, ssqv);     // requested before the burst: landed long ago
   }
   __syncthreads();
 

@@ -67,8 +67,8 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
               "ua2_linear: y_norm_w hand-over needs UA2_BF16, a RESIDUAL / STORE epilogue, N %% 32 == 0, y_ssq and y_h (ldh %% 8 == 0) or y_packed");
   }
   if (a.prologue == UA2_PRO_SCALED) {
-    UA2_CHECK(a.dtype == UA2_BF16 && a.K % 32 == 0 && a.x_ssq && (a.x_h || a.x_packed) && (!a.x_h || a.ldh % 8 == 0),
-              "ua2_linear: UA2_PRO_SCALED needs UA2_BF16, K %% 32 == 0, x_ssq and x_h (ldh %% 8 == 0) or x_packed");
+    UA2_CHECK(a.dtype == UA2_BF16 && a.K % 32 == 0 && a.K <= 4096 && a.x_ssq && (a.x_h || a.x_packed) && (!a.x_h || a.ldh % 8 == 0),
+              "ua2_linear: UA2_PRO_SCALED needs UA2_BF16, K %% 32 == 0, K <= 4096, x_ssq and x_h (ldh %% 8 == 0) or x_packed");
     UA2_CHECK(a.epilogue == UA2_EPI_QKV_ROPE || a.epilogue == UA2_EPI_SWIGLU || a.epilogue == UA2_EPI_STORE,
               "ua2_linear: UA2_PRO_SCALED serves the QKV_ROPE, SWIGLU and STORE epilogues");
   }

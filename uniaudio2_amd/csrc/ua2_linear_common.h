@@ -113,19 +113,47 @@ __device__ __forceinline__ float ssq_tile16(float v) {
   s = __fadd_rn(s, __shfl_xor(s, 8));
   return s;
 }
-// Row scale of a UA2_PRO_SCALED launch from the producer's partials: lane c of the row's 16-lane group adds partials
-// c, c + 16, ... in ascending order, the 16 chains meet in the same butterfly.  Call with all 16 lanes of the group
-// (rows past M read row M - 1: valid memory, result unused).
-__device__ __forceinline__ float scaled_rstd(const ua2_linear_args& a, int mr, int col) {
+// Row scale of a UA2_PRO_SCALED launch from the producer's partials, in two halves so that a kernel can REQUEST the partials
+// before its weight burst (tiny L2 hits: they retire first) and REDUCE them after issuing it — a wave's loads retire in
+// order, so partials requested behind the burst make the reduction wait for the last weight fragment, and the MFMA loop
+// that follows then starts on a drained pipeline instead of on the first fragment (+4-6 us per launch, measured).
+// One order for every kernel: lane c of the row's 16-lane group adds partials c, c + 16, ... ascending, the 16 chains meet
+// in the butterfly xor 1, 2, 4, 8 — a row's scale does not depend on the row count or the kernel.  K <= 4096.
+// NPL = partials per lane the caller holds (>= ceil(K / 256); 16 covers every K): fewer registers where K is a compile-time fact
+template <int NPL>
+__device__ __forceinline__ void scaled_ssq_request(const ua2_linear_args& a, int mr, int c, float (&v)[NPL]) {
   const int nparts = a.K >> 4;
-  const float* p = a.x_ssq + (size_t)min(mr, a.M - 1) * nparts;
+  const float* p = a.x_ssq + (size_t)min(max(mr, 0), a.M - 1) * nparts;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) v[i] = p[min(c + 16 * i, nparts - 1)];   // clamped, not predicated: a load under a lane predicate ends in a wait per load
+}
+template <int NPL>
+__device__ __forceinline__ float scaled_rstd_reduce(const ua2_linear_args& a, int c, const float (&v)[NPL]) {
+  const int nparts = a.K >> 4;
   float s = 0.f;
-  for (int j = col; j < nparts; j += 16) s = __fadd_rn(s, p[j]);
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) s = __fadd_rn(s, (c + 16 * i < nparts) ? v[i] : 0.f);   // + 0.f past the end: exact (and the same bits whatever NPL >= the need)
   s = __fadd_rn(s, __shfl_xor(s, 1));
   s = __fadd_rn(s, __shfl_xor(s, 2));
   s = __fadd_rn(s, __shfl_xor(s, 4));
   s = __fadd_rn(s, __shfl_xor(s, 8));
   return 1.0f / sqrtf(s / (float)a.K + a.eps);            // torch.rsqrt(mean(x*x) + eps), as norm_stat
+}
+// both halves at once, for rows [m_first, m_first + nrows) into rstd_lds (kernels without a burst to hide behind)
+__device__ __forceinline__ void scaled_rstd_rows(const ua2_linear_args& a, int m_first, int nrows, float* rstd_lds, int tid, int nthreads) {
+  for (int r = tid >> 4; r < nrows; r += nthreads >> 4) {
+    float v[16];
+    scaled_ssq_request(a, m_first + r, tid & 15, v);
+    const float rs = scaled_rstd_reduce(a, tid & 15, v);
+    if ((tid & 15) == 0) rstd_lds[r] = rs;
+  }
+}
+
+// The same statistic for ONE row by the 16 lanes of its group (the tiled kernel's epilogue: no LDS to spare there).
+__device__ __forceinline__ float scaled_rstd_row(const ua2_linear_args& a, int mr, int c) {
+  float v[16];
+  scaled_ssq_request(a, mr, c, v);
+  return scaled_rstd_reduce(a, c, v);
 }
 
 // table row of the paged KV cache for matrix row mr: row_seq == NULL means "row r is sequence r"
@@ -135,7 +163,6 @@ __device__ __forceinline__ int kv_table_row(const ua2_linear_args& a, int mr) { 
 template <int DT, int EPI>
 __device__ __forceinline__ void epilogue_prefetch_a(const ua2_linear_args& a, int tile0, int row, int col, EpiPre& p, int m0) {
   const int mr = m0 + row;
-  if (a.prologue == UA2_PRO_SCALED) p.rstd = scaled_rstd(a, mr, col);     // 16-lane shuffles: before any early exit
   if (mr >= a.M) return;
   const int n = tile0 * 16 + col;
   if constexpr (EPI == UA2_EPI_STORE) {
@@ -194,7 +221,11 @@ __device__ __forceinline__ void handover_emit(const ua2_linear_args& a, float ou
 }
 
 // NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.
-template <int DT, int EPI, int NT>
+// HO = false compiles the hand-over emission out: the tiled kernel's STORE / RESIDUAL instantiations sit at the register
+// limit (chain + total accumulators), and with the emission's shuffles in their epilogue the allocator moved the totals
+// into scratch for the whole kernel (272 B/lane, the lm_head launch 222 -> 510 us) — the launcher picks the HO = true
+// instantiation only for launches that hand over.
+template <int DT, int EPI, int NT, bool HO = true>
 __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const float (&vin)[NT], const int (&tile)[NT],
                                                 int row, int col, const EpiPre& p, int m0, int rows) {
   const int mr = m0 + row;
@@ -214,7 +245,7 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
   if constexpr (EPI == UA2_EPI_STORE) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N && a.y) a.y[(size_t)mr * a.ldy + n] = v[0];
-    if (a.y_norm_w) handover_emit<DT>(a, v[0], p.nw, mr, n, tile[0], col, rvalid);
+    if constexpr (HO) if (a.y_norm_w) handover_emit<DT>(a, v[0], p.nw, mr, n, tile[0], col, rvalid);
     if (a.part_max) {
       float bv = (n < a.N && n >= p.forbid) ? v[0] : -INFINITY;
       int bi = n;
@@ -234,7 +265,7 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
     const int n = tile[0] * 16 + col;
     const float out = __fadd_rn(a.out_scale ? __fmul_rn(a.out_scale[min(n, a.N - 1)], v[0]) : v[0], p.resid);
     if (rvalid && n < a.N) a.y[(size_t)mr * a.ldy + n] = out;
-    if (a.y_norm_w) handover_emit<DT>(a, out, p.nw, mr, n, tile[0], col, rvalid);
+    if constexpr (HO) if (a.y_norm_w) handover_emit<DT>(a, out, p.nw, mr, n, tile[0], col, rvalid);
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {

@@ -32,7 +32,9 @@ namespace {
 
 constexpr int kRsrcFlags = 0x00020000;   // raw buffer, dword data format (gfx9 family)
 
-template <int EPI, int CT, int MT, int CH, int NWV, int LA>
+// SC: the launch is a UA2_PRO_SCALED consumer (row scales from the producer's partials) — a template flag, not a runtime
+// test: the partials' registers must not exist in the other instantiations (as a runtime branch they spilled all of them)
+template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC>
 __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int passes) {
   constexpr int DT = UA2_BF16;
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;   // weight matrices
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
   static_assert(CH % LA == 0 && LA <= CH, "the operand ring must tile a range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);          // [NWV][NS][MT][256]
+  float* rstd_l = red + NWV * NS * MT * 256;            // [MT * passes * 16] row scales (UA2_PRO_SCALED)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nchunks = NWV * CH;                     // checked by the launcher: K / KC == NWV * CH
   const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
@@ -65,6 +68,25 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 
   auto ldw = [&](int s, int chunk) { return __builtin_amdgcn_raw_buffer_load_b128(wr[s], voff, chunk * 1024, 2); };   // aux 2 = nt: streamed once
 
+  // UA2_PRO_SCALED: sum-of-squares partials of the pass's rows — a 16-lane group per row, SW sweeps over the MT * 16 rows —
+  // requested at the head of the pass (pass 0: before the weight burst), reduced after its chunk loop, into rstd_l
+  constexpr int SW = SC ? (MT * 16 + NWV * 4 - 1) / (NWV * 4) : 1;
+  constexpr int NPL = SC ? (nchunks + 7) / 8 : 1;         // K / 16 partials per row over 16 lanes
+  float ssqv[SW][NPL];
+  auto ssq_request = [&](int pass) {
+#pragma unroll
+    for (int w = 0; w < SW; ++w) scaled_ssq_request(a, (mt_first + pass * MT) * 16 + w * NWV * 4 + (tid >> 4), tid & 15, ssqv[w]);
+  };
+  auto ssq_reduce = [&](int pass) {
+#pragma unroll
+    for (int w = 0; w < SW; ++w) {
+      const int r = w * NWV * 4 + (tid >> 4);
+      const float rs = scaled_rstd_reduce(a, tid & 15, ssqv[w]);
+      if ((tid & 15) == 0 && r < MT * 16) rstd_l[pass * MT * 16 + r] = rs;
+    }
+  };
+  if constexpr (SC) ssq_request(0);
+
   // Issue order: a wave's loads retire in order, so the first operand chunks (L2 hits, needed first) go out BEFORE the weight
   // burst (HBM).  (A "rolling window" form — weights and operand of a chunk travelling together through a ring, consumed in
   // issue order — was measured and lost 5-20 %: it caps the weight bytes in flight per wave at the ring depth,
@@ -85,6 +107,10 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 #pragma unroll
     for (int s = 0; s < NS; ++s) wf[s][u] = ldw(s, u);
   __builtin_amdgcn_sched_barrier(0);
+  // the partials were requested first (they retire first, ~an L2 round trip): reduced here, while the weights stream, so
+  // that their registers are dead before the chunk loop (kept across it, the allocator starved the loop's operand ring of
+  // lookahead: vmcnt(1) instead of vmcnt(3) per refill, +3 us per pass)
+  if constexpr (SC) ssq_reduce(0);
 
   const int row = tid >> 4, col = tid & 15;
   const int srcl = (((row >> 2) << 4) + col) * 4 + (row & 3);
@@ -118,6 +144,8 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(&red[(((wave * NS + s) * MT) + mi) * 256 + lane * 4]) = acc[s][mi];
     ua2_lds_barrier();                                   // LDS-only hand-off: the operand prefetch of the next pass stays in flight
+    const bool more_passes = pass + 1 < passes && mt_first + (pass + 1) * MT < mtiles;    // uniform
+    if constexpr (SC) { if (more_passes) ssq_request(pass + 1); }                         // lands under the epilogue below
     if (tid < 256) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -131,6 +159,10 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
         for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+        if constexpr (SC) {
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) pre[mi].rstd = rstd_l[min((mtp - mt_first + mi) * 16 + row, passes * MT * 16 - 1)];
+        }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
           const int m0 = (mtp + mi) * 16;
@@ -147,14 +179,19 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
         }
       }
     }
-    if (++pass >= passes || mt_first + pass * MT >= mtiles) break;   // uniform
+    if (!more_passes) break;
+    ++pass;
+    if constexpr (SC) ssq_reduce(pass);
     ua2_lds_barrier();                                   // `red` is rewritten by the next pass
   }
 }
 
 // VGPRs a variant needs: resident weights + operand ring + accumulators + addressing / epilogue slack.  Variants over the
 // per-wave budget (512 per SIMD shared by NWV / 4 waves) spill and are not built.
-constexpr int regs_needed(int nm, int ct, int mt, int ch, int la) { return nm * ct * ch * 4 + la * mt * 4 + nm * ct * mt * 4 + 20; }
+constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false) {
+  const int sw = (mt * 16 + nwv * 4 - 1) / (nwv * 4), npl = (nwv * ch + 7) / 8;      // the scaled consumer's sum-of-squares partials
+  return nm * ct * ch * 4 + la * mt * 4 + nm * ct * mt * 4 + 20 + (sc ? sw * npl + 40 : 0);
+}
 
 struct Variant { int ct, mt, la, passes; };
 
@@ -167,12 +204,13 @@ bool env_variant(Variant& v, bool& off) {
   return sscanf(e, "%d,%d,%d,%d", &v.ct, &v.mt, &v.la, &v.passes) == 4;
 }
 
-template <int EPI, int CT, int MT, int CH, int NWV, int LA>
+template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC>
 int launch_one(const ua2_linear_args& a, int passes, hipStream_t s) {
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
-  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA>;
-  constexpr size_t smem = (size_t)NWV * NM * CT * MT * 1024;
-  if constexpr (smem > 160 * 1024) return 1;
+  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA, SC>;
+  constexpr size_t red_bytes = (size_t)NWV * NM * CT * MT * 1024;
+  if constexpr (red_bytes > 156 * 1024) return 1;
+  const size_t smem = red_bytes + (size_t)passes * MT * 16 * sizeof(float);
   ua2_allow_big_lds<kern>();
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
   const dim3 grid(ua2_ceil_div(ntiles, CT), ua2_ceil_div(mtiles, MT * passes));
@@ -185,8 +223,12 @@ int launch_variant(const ua2_linear_args& a, const Variant& v, hipStream_t s) {
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
 #define UA2_SK(CT_, MT_, LA_)                                                                            \
   if (v.ct == CT_ && v.mt == MT_ && v.la == LA_) {                                                       \
+    if constexpr (EPI != UA2_EPI_RESIDUAL && CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_, NWV, true) <= 2048 / NWV) { \
+      if (a.prologue == UA2_PRO_SCALED) return launch_one<EPI, CT_, MT_, CH, NWV, LA_, true>(a, v.passes, s);             \
+    }                                                                                                    \
+    if (a.prologue == UA2_PRO_SCALED) return 1;                                                          \
     if constexpr (CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_) <= 2048 / NWV)                     \
-      return launch_one<EPI, CT_, MT_, CH, NWV, LA_>(a, v.passes, s);                                     \
+      return launch_one<EPI, CT_, MT_, CH, NWV, LA_, false>(a, v.passes, s);                              \
     return 1;                                                                                            \
   }
   UA2_SK(1, 4, 1) UA2_SK(1, 4, 2) UA2_SK(1, 2, 2)
@@ -204,12 +246,13 @@ int launch_variant(const ua2_linear_args& a, const Variant& v, hipStream_t s) {
 Variant pick_variant(const ua2_linear_args& a, int waves, int ch, int nm) {
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
   const int budget = 2048 / waves;
+  const bool sc = a.prologue == UA2_PRO_SCALED;
   Variant v{1, 4, 1, 1};
-  if (ntiles >= 192 && regs_needed(nm, 2, 2, ch, 2) <= budget) v.ct = 2;
+  if (ntiles >= 192 && regs_needed(nm, 2, 2, ch, 2, waves, sc) <= budget) v.ct = 2;
   const int groups = ua2_ceil_div(ntiles, v.ct);
   const int ysplit = std::max(1, std::min(256 / groups, ua2_ceil_div(mtiles, 2)));
   const int rows = ua2_ceil_div(mtiles, ysplit);            // row tiles per workgroup
-  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1) <= budget) ? 4 : 2;
+  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1, waves, sc) <= budget) ? 4 : 2;
   v.la = (v.mt == 2 && ch % 2 == 0) ? 2 : 1;
   v.passes = ua2_ceil_div(rows, v.mt);
   return v;

@@ -120,7 +120,8 @@ struct Handover {
 // ln_f in front of audio_head), or NULL (the trunk GPTs end in ua2_rmsnorm_blend, which reads the fp32 stream).
 // With h->scaled the caller has already handed over x for layer 0 (embed_frame / rmsnorm_blend / the projection's epilogue).
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
-            const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false, const float* final_norm_w = nullptr) {
+            const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false, const float* final_norm_w = nullptr,
+            bool scaled = false) {
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   const Handover ho(h, R, C);
@@ -135,7 +136,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = nqkv; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][0][l]; a.eps = g.eps;
     a.w0 = h->ptrs[gi][0][l]; a.row_pos = row_pos; a.row_seq = row_seq; a.rope_cos = g.rope_cos;
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
-    if (h->scaled) ho.consume(a);
+    if (scaled) ho.consume(a);
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     static const bool no_fuse = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
@@ -163,7 +164,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.w0 = h->ptrs[gi][1][l]; a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (fuse_attn) { a.row_pos = row_pos; a.row_seq = row_seq; a.kv = kv; }
     if (pack_o && !fuse_attn) a.x_packed = h->gemm_ws;
-    if (h->scaled) ho.produce(a, h->norms[gi][1][l]);              // x after attention -> norm_2 + fc_1 / fc_2
+    if (scaled) ho.produce(a, h->norms[gi][1][l]);              // x after attention -> norm_2 + fc_1 / fc_2
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -171,7 +172,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = g.inter; a.K = C; a.x = x; a.ldx = C; a.norm_w = h->norms[gi][1][l]; a.eps = g.eps;
     a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.ldy = g.inter;
     if (pack_act) a.y_packed = h->act_ws; else a.y = h->act;
-    if (h->scaled) ho.consume(a);
+    if (scaled) ho.consume(a);
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -179,7 +180,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.M = R; a.N = C; a.K = g.inter; a.x = h->act; a.ldx = g.inter; a.w0 = h->ptrs[gi][4][l];
     a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (pack_act) a.x_packed = h->act_ws;
-    if (h->scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
+    if (scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
     if (int rc = ua2_linear_launch(a, s)) return rc;
   }
   return 0;
@@ -253,7 +254,12 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->act_ws = b + c.act_ws;
   h->xh = b + c.xh; h->xpk = b + c.xpk; h->ssq = b + c.ssq;
   // the scaled contract is the bf16 executor's (fp32 keeps the reference's operation order); A/B hook: UA2_NO_SCALED=1
-  h->scaled = d->dtype == UA2_BF16 && getenv("UA2_NO_SCALED") == nullptr && d->backbone.n_embd % 32 == 0 && d->decoder.n_embd % 32 == 0;
+  // Plans for more than 64 live sequences keep the prep form as well: at 256 rows the consumers' per-pass row-scale work and
+  // the producers' fragment-order stores cost more than the 140 prep launches they replace (12.6 vs 13.7 ms per frame).  The
+  // choice is made once per plan, so every row count served by one plan computes the same function (rows of a 64-sequence
+  // batch are bit-identical to their B = 1 runs under the same plan).
+  h->scaled = d->dtype == UA2_BF16 && getenv("UA2_NO_SCALED") == nullptr && d->backbone.n_embd % 32 == 0 && d->decoder.n_embd % 32 == 0 &&
+              d->max_batch <= 64;
   h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
   *out = h;
   return 0;
@@ -275,18 +281,23 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   ua2_stage3_desc d = h->d;
   if (identity) d.row_seq = nullptr;
   const int C = d.backbone.n_embd, w = d.n_cb + 1;
+  // Decode frames run the scaled hand-over; PREFILL chunks (row groups set: the MFMA flash attention path) keep the
+  // prep + RMSNorm-prologue form: prefill rows already differ from decode rows by bf16-level summation order,
+  // and there the hand-over's epilogue costs more than the prep launches it saves (the tiled kernel's RESIDUAL epilogue
+  // with the emission spills its accumulators: 8192-row prefill 82 -> 131 ms, profiles/r3_notes.md)
+  const bool grouped = !identity;   // prefill chunks (ua2_stage3_trunk) may carry row groups; decode frames never do
+  const bool scaled = h->scaled && !(grouped && h->n_groups > 0);
   const Handover ho(h, R, C);
   ua2_handover e0{}, e1{}, e2{};
-  if (h->scaled) { e0 = ho.rowwise(h->norms[0][0][0]); e1 = ho.rowwise(h->norms[1][0][0]); e2 = ho.rowwise(h->norms[2][0][0]); }
+  if (scaled) { e0 = ho.rowwise(h->norms[0][0][0]); e1 = ho.rowwise(h->norms[1][0][0]); e2 = ho.rowwise(h->norms[2][0][0]); }
   if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, &e0, s)) return rc;
-  const bool grouped = !identity;   // prefill chunks (ua2_stage3_trunk) may carry row groups; decode frames never do
-  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
+  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
   // backbone_input = h_audio*audio_step + text_embeds*text_step   (model_new.py:607)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, &e1, s)) return rc;
-  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
+  if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
   // h = ln_f(x); generation_input = h*audio_step                   (model_new.py:609-610)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, &e2, s)) return rc;
-  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s, false, grouped)) return rc;
+  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
   // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, nullptr, s)) return rc;
   return 0;
@@ -383,7 +394,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
     if (h->scaled) hod.produce(a, h->norms[3][0][0]);
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8, false,
-                         h->scaled ? d.decoder.ln_f : nullptr)) return rc;
+                         h->scaled ? d.decoder.ln_f : nullptr, h->scaled)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
