@@ -154,6 +154,7 @@ def test_batch_rows_equal_single_runs_ragged(golden, sd, dtype):
         n = L - 1
         model._load_rows(t[0, :-1].to(dev), mk[0, :-1].to(dev), torch.arange(n, device=dev),
                          torch.full((n,), b, device=dev))
+        model._set_groups(torch.arange(n), torch.full((n,), b))        # a prefill chunk, as forward_prefix issues it
         from uniaudio2_amd import ops
         from uniaudio2_amd._lib import check, lib
         check(lib.ua2_stage3_trunk(model._h, n, ops.stream()), "trunk")

@@ -286,7 +286,7 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   // and there the hand-over's epilogue costs more than the prep launches it saves (the tiled kernel's RESIDUAL epilogue
   // with the emission spills its accumulators: 8192-row prefill 82 -> 131 ms, profiles/r3_notes.md)
   const bool grouped = !identity;   // prefill chunks (ua2_stage3_trunk) may carry row groups; decode frames never do
-  const bool scaled = h->scaled && !(grouped && h->n_groups > 0);
+  const bool scaled = h->scaled && !(grouped && (h->n_groups > 0 || R > h->d.max_batch));   // ua2_stage3_trunk with row groups, or with more rows than sequences: a prefill chunk
   const Handover ho(h, R, C);
   ua2_handover e0{}, e1{}, e2{};
   if (scaled) { e0 = ho.rowwise(h->norms[0][0][0]); e1 = ho.rowwise(h->norms[1][0][0]); e2 = ho.rowwise(h->norms[2][0][0]); }
