@@ -143,6 +143,16 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(&red[(((wave * NS + s) * MT) + mi) * 256 + lane * 4]) = acc[s][mi];
+    // the first column tile's epilogue loads (residual values; position -> RoPE table entry / page id) go out BEFORE the barrier:
+    // issued behind it they were a dependent L2 round trip or two in front of every store of the launch
+    EpiPre pre0[MT];
+    if (tid < 256) {
+      const int nt0 = min((int)blockIdx.x * CT, ntiles - 1);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt0, row, col, pre0[mi], (mtp + mi) * 16);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt0, row, col, pre0[mi], (mtp + mi) * 16);
+    }
     ua2_lds_barrier();                                   // LDS-only hand-off: the operand prefetch of the next pass stays in flight
     const bool more_passes = pass + 1 < passes && mt_first + (pass + 1) * MT < mtiles;    // uniform
     if constexpr (SC) { if (more_passes) ssq_request(pass + 1); }                         // lands under the epilogue below
@@ -155,10 +165,15 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 #pragma unroll
         for (int t = 0; t < NM; ++t) tile[t] = nt;
         EpiPre pre[MT];                                  // every row tile's epilogue loads before any store
+        if (ct == 0) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+          for (int mi = 0; mi < MT; ++mi) pre[mi] = pre0[mi];
+        } else {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+          for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+        }
         if constexpr (SC) {
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi) pre[mi].rstd = rstd_l[min((mtp - mt_first + mi) * 16 + row, passes * MT * 16 - 1)];
