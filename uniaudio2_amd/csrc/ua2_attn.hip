@@ -44,7 +44,9 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-template <int DT, int HS>
+// kG = query heads per kv head, a template parameter: with a run-time G padded to kMaxG = 4 the Llama trunk (G = 3) spent a
+// quarter of its vector-ALU work on a head that does not exist (the launch is ALU-bound from 64 rows up, profiles/r3_notes.md)
+template <int DT, int HS, int kG>
 __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_attn_args a) {
   constexpr int EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
   constexpr int LPR = HS / EPL, RPW = 64 / LPR;   // lanes per cache row, row groups per wave
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
   // through LDS, in (wave, group) order.
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int r = blockIdx.x, kvh = blockIdx.y;
-  const int G = a.kv.n_head / a.kv.n_kv;
+  constexpr int G = kG;
   float* st_m = sm;                    // [NS][G]
   float* st_l = st_m + NS * kMaxG;     // [NS][G]
   float* st_o = st_l + NS * kMaxG;     // [NS][G][HS]
@@ -72,20 +74,20 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
   const int chunk = ((n - lo + kFusedWaves * RPW - 1) / (kFusedWaves * RPW)) * RPW;
   const int j0 = lo + wave * chunk, j1 = min(n, j0 + chunk);
 
-  float q[kMaxG][EPL];
+  float q[kG][EPL];
 #pragma unroll
-  for (int h = 0; h < kMaxG; ++h) {
-    const float* qp = a.q + ((size_t)r * a.kv.n_head + (size_t)kvh * G + (h < G ? h : 0)) * HS + sub * EPL;
-    const float sc = (h < G) ? scale : 0.f;
+  for (int h = 0; h < kG; ++h) {
+    const float* qp = a.q + ((size_t)r * a.kv.n_head + (size_t)kvh * G + h) * HS + sub * EPL;
+    const float sc = scale;
 #pragma unroll
     for (int e4 = 0; e4 < EPL / 4; ++e4) {
       const float4 t = *reinterpret_cast<const float4*>(qp + 4 * e4);
       q[h][4 * e4 + 0] = t.x * sc; q[h][4 * e4 + 1] = t.y * sc; q[h][4 * e4 + 2] = t.z * sc; q[h][4 * e4 + 3] = t.w * sc;
     }
   }
-  float m_run[kMaxG], l_run[kMaxG], o_run[kMaxG][EPL];
+  float m_run[kG], l_run[kG], o_run[kG][EPL];
 #pragma unroll
-  for (int h = 0; h < kMaxG; ++h) {
+  for (int h = 0; h < kG; ++h) {
     m_run[h] = -INFINITY;
     l_run[h] = 0.f;
 #pragma unroll
@@ -112,10 +114,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
     bool ok[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) ok[u] = (jb + u * RPW + rin) < j1;
-    float s[UNR][kMaxG];
-    float gmax[kMaxG];
+    float s[UNR][kG];
+    float gmax[kG];
 #pragma unroll
-    for (int h = 0; h < kMaxG; ++h) gmax[h] = -INFINITY;
+    for (int h = 0; h < kG; ++h) gmax[h] = -INFINITY;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       float kf[EPL];
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
         for (int e = 0; e < 4; ++e) kf[e] = __uint_as_float(kraw[u][e]);
       }
 #pragma unroll
-      for (int h = 0; h < kMaxG; ++h) {
+      for (int h = 0; h < kG; ++h) {
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) d += q[h][e] * kf[e];
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
     // online softmax of THIS row group (its rows jb + u*RPW + rin, u < UNR); u = 0 may be masked
     // for trailing groups, so guard the all-masked case
 #pragma unroll
-    for (int h = 0; h < kMaxG; ++h) {
+    for (int h = 0; h < kG; ++h) {
       const float m_new = fmaxf(m_run[h], gmax[h]);
       const float resc = (m_new == -INFINITY) ? 1.f : fast_exp(m_run[h] - m_new);
       m_run[h] = m_new;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
         for (int e = 0; e < 4; ++e) vf[e] = __uint_as_float(vraw[u][e]);
       }
 #pragma unroll
-      for (int h = 0; h < kMaxG; ++h) {
+      for (int h = 0; h < kG; ++h) {
         const float p = ok[u] ? fast_exp(s[u][h] - m_run[h]) : 0.f;
         l_run[h] += p;
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
   // publish the state of this row group
   const int sidx = wave * RPW + rin;
 #pragma unroll
-  for (int h = 0; h < kMaxG; ++h) {
+  for (int h = 0; h < kG; ++h) {
     if (h < G) {
       if (sub == 0) { st_m[sidx * kMaxG + h] = m_run[h]; st_l[sidx * kMaxG + h] = l_run[h]; }
       float* o = st_o + ((size_t)sidx * G + h) * HS + sub * EPL;
@@ -234,14 +236,23 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
   }
 }
 
-template <int DT, int HS>
-void launch_fused_hs(const ua2_attn_args& a, hipStream_t s) {
+template <int DT, int HS, int kG>
+void launch_fused_g(const ua2_attn_args& a, hipStream_t s) {
   constexpr int EPL = Elem<DT>::EPL, RPW = 64 / (HS / EPL), NS = kFusedWaves * RPW;
-  const int G = a.kv.n_head / a.kv.n_kv;
-  const size_t smem = (size_t)(2 * NS * kMaxG + (size_t)NS * G * HS) * sizeof(float);
-  constexpr auto kern = attn_fused_kernel<DT, HS>;
+  const size_t smem = (size_t)(2 * NS * kMaxG + (size_t)NS * kG * HS) * sizeof(float);
+  constexpr auto kern = attn_fused_kernel<DT, HS, kG>;
   ua2_allow_big_lds<kern>();
   hipLaunchKernelGGL(kern, dim3(a.R, a.kv.n_kv), dim3(kFusedWaves * 64), smem, s, a);
+}
+
+template <int DT, int HS>
+void launch_fused_hs(const ua2_attn_args& a, hipStream_t s) {
+  switch (a.kv.n_head / a.kv.n_kv) {       // <= kMaxG (checked by ua2_attn_launch)
+    case 1: launch_fused_g<DT, HS, 1>(a, s); break;
+    case 2: launch_fused_g<DT, HS, 2>(a, s); break;
+    case 3: launch_fused_g<DT, HS, 3>(a, s); break;
+    default: launch_fused_g<DT, HS, 4>(a, s); break;
+  }
 }
 
 template <int DT>
