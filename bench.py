@@ -30,6 +30,7 @@ PROMPT_LEN = 33
 FRAMES = 74
 SEM_CARD, REASON_CARD = 8196, 4100          # V_a = 12296 (placeholder sizes; the real ones live in a yaml not in the repo)
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PMC_SWIGLU_TRAFFIC = 100816384              # bytes per launch, profiles/r3_pmc_swiglu.txt (refreshed in round 3)
 
 
 SCALAR_CFG = dict(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
@@ -79,13 +80,16 @@ def utterance(model, tokens, mask, frames=FRAMES):
 
 
 def roofline_leg(model):
-    """HIP-event timing of the dominant kernel — gemv_kernel<bf16, NORM, SWIGLU, CPW=4, multi-round>
-    (rocprof symbol `gemv_kernel<1, 1, 2, 4, true>`): fused RMSNorm + fc_1/fc_2 + SwiGLU at 3072 -> 2x8192 —
-    over exactly its launches in one frame: the 33 layers of the three 3072-d GPTs, each with its own
-    100.7 MB of weights (so every launch streams cold data).  The 2048-d local decoder's SwiGLU is a
-    different instantiation and is reported by tools/ubench/gemv_shapes.py, not here."""
+    """HIP-event timing of the dominant kernel — the fused (RMSNorm) + fc_1/fc_2 + SwiGLU weight-streaming GEMV at
+    3072 -> 2x8192, in the form the B = 1 frame runs since round 3: `gemv_kernel<1, 4, 2, 4, true>` (bf16, UA2_PRO_SCALED
+    prologue — the operand row RNE_bf16(x (.) w) and the sum-of-squares partials are handed over by the producer of x, the
+    row scale is applied to the fp32 sums — SWIGLU epilogue, CPW = 4, multi-round) — over exactly its launches in one frame:
+    the 33 layers of the three 3072-d GPTs, each with its own 100.7 MB of weights (so every launch streams cold data).  The
+    2048-d local decoder's SwiGLU is a different instantiation and is reported by tools/ubench/gemv_shapes.py, not here.
+    ua2_linear_chain_timed brackets the launches with hipEvents on the stream they are issued on."""
     from uniaudio2_amd import ops
-    from uniaudio2_amd._lib import EPI_SWIGLU, PRO_NORM
+    from uniaudio2_amd._lib import EPI_SWIGLU
+    PRO_SCALED = 4
     dev = model.projection.weight.device
     args, bytes_total = [], 0
     keep = []
@@ -93,16 +97,17 @@ def roofline_leg(model):
     def add(gpt, reps):
         nonlocal bytes_total
         cfg, p = gpt.config, gpt.plan
-        x = torch.randn(1, cfg.n_embd, device=dev)
+        xh = (torch.randn(1, cfg.n_embd, device=dev)).to(torch.bfloat16)
+        ssq = torch.rand(1, cfg.n_embd // 16, device=dev) * 16
         y = torch.empty(1, cfg.intermediate_size, device=dev)
-        keep.extend([x, y])
+        keep.extend([xh, ssq, y])
         for _ in range(reps):
             for l in range(cfg.n_layer):
                 args.append(ops.linear(dtype=torch.bfloat16, M=1, N=cfg.intermediate_size, K=cfg.n_embd,
-                                       w0=p["fc1"][l], w1=p["fc2"][l], prologue=PRO_NORM, epilogue=EPI_SWIGLU, x=x,
-                                       norm_w=p["norm2"][l], eps=cfg.norm_eps, y=y, launch=False))
-                # algorithmic bytes: both weight matrices once (bf16) + x, norm weight (fp32) + y (fp32)
-                bytes_total += 2 * cfg.intermediate_size * cfg.n_embd * 2 + 2 * cfg.n_embd * 4 + cfg.intermediate_size * 4
+                                       w0=p["fc1"][l], w1=p["fc2"][l], prologue=PRO_SCALED, epilogue=EPI_SWIGLU, x_h=xh, x_ssq=ssq,
+                                       eps=cfg.norm_eps, y=y, launch=False))
+                # algorithmic bytes: both weight matrices once (bf16) + the operand row (bf16) + its partials (fp32) + y (fp32)
+                bytes_total += 2 * cfg.intermediate_size * cfg.n_embd * 2 + cfg.n_embd * 2 + cfg.n_embd // 16 * 4 + cfg.intermediate_size * 4
 
     add(model.audio_understanding_expert, 1)
     add(model.backbone, 1)
@@ -111,11 +116,12 @@ def roofline_leg(model):
     ms = ops.linear_chain_timed(args, 10)
     per_launch_bytes = bytes_total / len(args)
     achieved = per_launch_bytes / (ms * 1e-3) / 1e9
-    return {"kernel": "gemv_kernel<1, 1, 2, 4, true> (RMSNorm + fc_1/fc_2 + SwiGLU GEMV, 3072 -> 2x8192, bf16)", "bound": "hbm",
+    return {"kernel": "gemv_kernel<1, 4, 2, 4, true> (scaled-RMSNorm + fc_1/fc_2 + SwiGLU GEMV, 3072 -> 2x8192, bf16)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # HBM read bytes per launch from a separate PMC pass (profiles/r1_pmc_swiglu.txt: FETCH_SIZE x 1024 x 2, re-measured on the final kernel,
-            # the gfx950 half-count correction of MI355X_MICROARCH.md §HBM); 1.003x the algorithmic bytes
-            "traffic": 100995000, "traffic_source": "cited, not measured in this run: profiles/r1_pmc_swiglu.txt (rocprofv3 --pmc FETCH_SIZE pass on the same kernel and shape)",
+            # HBM read bytes per launch from a separate PMC pass on this kernel and shape (profiles/r3_pmc_swiglu.txt:
+            # rocprofv3 --pmc FETCH_SIZE, x 1024 x 2 — the gfx950 half-count correction of MI355X_MICROARCH.md §HBM)
+            "traffic": PMC_SWIGLU_TRAFFIC, "traffic_source": "profiles/r3_pmc_swiglu.txt (rocprofv3 --pmc FETCH_SIZE pass of round 3 on this kernel and shape; "
+                                                              "counters are collected in their own run, not inside bench.py)",
             "launches_per_frame": len(args), "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_bytes_per_launch": int(per_launch_bytes)}
 
