@@ -18,12 +18,17 @@ def packed(N, K):
 
 
 MS = [int(v) for v in sys.argv[1:]] or [64, 512, 6272]
+TRUNK = (("swiglu 3072->2x8192", 8192, 3072, PRO_NORM, EPI_SWIGLU),
+         ("down 8192->3072", 3072, 8192, PRO_CAST, EPI_RESIDUAL),
+         ("qkv-sized 3072->5120", 5120, 3072, PRO_NORM, EPI_STORE),
+         ("oproj 3072->3072", 3072, 3072, PRO_CAST, EPI_RESIDUAL))
+DIT = (("dit ff1 1536->6144", 6144, 1536, PRO_CAST, EPI_STORE),      # UA2_SHAPES=dit: the codec DiT's four GEMMs (M = 1000)
+       ("dit ff2 6144->1536", 1536, 6144, PRO_CAST, EPI_RESIDUAL),
+       ("dit qkv 1536->4608", 4608, 1536, PRO_CAST, EPI_STORE),
+       ("dit o 1536->1536", 1536, 1536, PRO_CAST, EPI_RESIDUAL))
 for M in MS:
     ws = ops.linear_workspace(dt, M, 8192, dev)
-    for name, N, K, pro, epi in (("swiglu 3072->2x8192", 8192, 3072, PRO_NORM, EPI_SWIGLU),
-                                 ("down 8192->3072", 3072, 8192, PRO_CAST, EPI_RESIDUAL),
-                                 ("qkv-sized 3072->5120", 5120, 3072, PRO_NORM, EPI_STORE),
-                                 ("oproj 3072->3072", 3072, 3072, PRO_CAST, EPI_RESIDUAL)):
+    for name, N, K, pro, epi in (DIT if os.environ.get("UA2_SHAPES") == "dit" else TRUNK):
         w0 = packed(N, K)
         w1 = packed(N, K) if epi == EPI_SWIGLU else [None] * L
         x = torch.randn(M, K, device=dev); nw = torch.ones(K, device=dev)

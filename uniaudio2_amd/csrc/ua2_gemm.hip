@@ -99,7 +99,11 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
 constexpr int kKS = 2;      // chunks per LDS stage
 constexpr int kGroupM = 8;  // row-blocks per L2 patch
 
-template <int DT, int EPI, int kBMT, bool HO>
+// GL: the operand ring is filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight from L2 into the ring,
+// three ring slots) instead of global -> registers -> ds_write_b128 (two slots).  The 32- / 64-row tiles were bound by the LDS
+// pipe — a ds_write_b128 costs 13 LDS-issue cycles per KiB against 4 for the ds_read_b128 that reads it back
+// (MI355X_MICROARCH.md §LDS), PMC: LDS 48 % busy, MFMA 10 %, L2 27 % on the DiT's FF2 (profiles/r3_notes.md §7).
+template <int DT, int EPI, int kBMT, bool HO, int GL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
                                                       const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
@@ -109,9 +113,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   constexpr int BNT = 2 * WN;         // column tiles per workgroup, per matrix
   constexpr int TILES = kBMT + NT * BNT;            // fragment streams per chunk (16)
   constexpr int LOADS = TILES * kKS * 64 / 256;     // 16-byte pieces per thread per stage (8)
-  __shared__ u32x4 lds[2][TILES][kKS][64];          // 64 KiB
+  constexpr int NBUF = GL ? GL : 2;                 // ring slots of TILES x kKS KiB (GL = 0: register staging, two slots; else the LDS-DMA ring depth)
+  extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+  u32x4 (*lds)[TILES][kKS][64] = reinterpret_cast<u32x4 (*)[TILES][kKS][64]>(gemm_smem);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nchunks = (a.K + KC - 1) / KC;
   const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
@@ -144,9 +150,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
     src[j] = p + (size_t)kc * 64 + lane;
   }
   const int nstages = (nchunks + kKS - 1) / kKS;
-  // two register staging sets: stage s+1 and s+2 are in flight while stage s is multiplied (one set
-  // would expose a full memory round trip per stage; measured 1.1 us/stage before, see profiles/r1_notes.md)
-  u32x4 stg0[LOADS], stg1[LOADS];
+  // NS register staging sets: stages s+1 .. s+NS are in flight while stage s is multiplied.  One set exposed a full memory
+  // round trip per stage (1.1 us/stage, profiles/r1_notes.md); two hide it when the tile is 128 rows (32 KiB and 32 MFMAs per
+  // wave and stage); the 32- and 64-row tiles of small grids (the DiT's M = 1000) move 20 / 24 KiB and 8 / 16 MFMAs per
+  // stage and were still latency-bound at 0.8 us per stage with two — they have the registers for 6 / 4 sets.
+  constexpr int NS = 2;
+  constexpr int NU = (NS % 2) ? 2 * NS : NS;     // steps per unrolled round: ring half and set both compile-time
+  u32x4 stg[NS][LOADS];
   auto fetch = [&](u32x4 (&stg)[LOADS], int s) {
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
@@ -188,52 +198,107 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   int seg = 1;                                   // next range boundary: chunk (seg * nchunks) / nw
   int boundary = (seg * nchunks) / nw;
 
+  // Fragment reads against MFMAs, per tile size (cycle stamps and A/B runs in profiles/r3_notes.md §7):
+  //   32 rows: ALL reads of the stage before its first MFMA.  The retire checks sit between the chunks and the compiler will not
+  //            move a ds_read across that control flow; left to itself it emitted read - wait - MFMA chains, 710 cycles per stage
+  //            for 128 cycles of MFMA work (470 with the reads up front).  A chunk past K is read like any other (the loader
+  //            clamps, the slot holds valid data) and not multiplied.
+  //   64 rows: the compiler's own interleave (reads up front cost 10-15 % there: three workgroups share a CU and the fine
+  //            interleave is what lets them overlap).
+  //   128 rows: a chunk's reads before its MFMAs, pinned with a scheduling barrier (-2 ... -5 %; no registers for both chunks).
   auto compute = [&](int buf, int s) {
+    constexpr int RD = kBMT == 2 ? kKS : 1;              // chunks read ahead of the MFMAs
+    u32x4 fa[RD][kWM], fb[RD][NT][WN];
+    auto read = [&](int kc) {
+#pragma unroll
+      for (int mi = 0; mi < kWM; ++mi) fa[kc % RD][mi] = lds[buf][wm * kWM + mi][kc][lane];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) fb[kc % RD][t][ni] = lds[buf][kBMT + t * BNT + wn * WN + ni][kc][lane];
+    };
+    if constexpr (RD == kKS) {
+#pragma unroll
+      for (int kc = 0; kc < kKS; ++kc) read(kc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int kc = 0; kc < kKS; ++kc) {
       const int c = s * kKS + kc;
+      if constexpr (RD != kKS) {
+        read(kc);
+        if constexpr (kBMT == 8) __builtin_amdgcn_sched_barrier(0);
+      }
       if (c < nchunks) {
         while (seg < nw && c == boundary) {      // `while`: empty ranges (nw > nchunks) retire zeros, as the decode kernel adds them
           retire();
           ++seg;
           boundary = (seg * nchunks) / nw;
         }
-        u32x4 fa[kWM], fb[NT][WN];
-#pragma unroll
-        for (int mi = 0; mi < kWM; ++mi) fa[mi] = lds[buf][wm * kWM + mi][kc][lane];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int ni = 0; ni < WN; ++ni) fb[t][ni] = lds[buf][kBMT + t * BNT + wn * WN + ni][kc][lane];
 #pragma unroll
         for (int mi = 0; mi < kWM; ++mi) {
           AFrag<DT> af;
-          af.v = __builtin_bit_cast(decltype(af.v), fa[mi]);
+          af.v = __builtin_bit_cast(decltype(af.v), fa[kc % RD][mi]);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) af.mma(fb[t][ni], chain[t][mi][ni]);
+            for (int ni = 0; ni < WN; ++ni) af.mma(fb[kc % RD][t][ni], chain[t][mi][ni]);
         }
       }
     }
   };
 
-  fetch(stg0, 0);
-  commit(0, stg0);
-  if (nstages > 1) fetch(stg0, 1);
-  if (nstages > 2) fetch(stg1, 2);
-  // ua2_lds_barrier, not __syncthreads(): in front of an s_barrier it can see, the compiler drains vmcnt to 0 — with it
-  // the two register staging sets never had more than one stage of MFMAs to cover a memory round trip
-  ua2_lds_barrier();
-  for (int s = 0; s < nstages; s += 2) {
-    compute(0, s);                               // even stage: lds[0]; stg0 = stage s+1, stg1 = stage s+2
-    if (s + 1 < nstages) commit(1, stg0);
+  if constexpr (GL) {
+    // stage t -> ring slot t % NBUF.  Per stage: wait for MY pieces of stage s (everything but the newest NBUF - 2 stages' requests),
+    // barrier (now everyone's pieces of s have landed AND everyone is done reading the slot of stage s - 1), request stage
+    // s + NBUF - 1 into that slot, multiply stage s.  Requests past the last stage are clamped onto it (into a slot nobody reads again), so
+    // the count in front of every barrier is the same.  The wait is hand-counted: an LDS-DMA is invisible to the compiler's
+    // s_waitcnt bookkeeping for the ds_reads that follow.
+    auto dma = [&](int t, int slot) {
+      const int st = min(t, nstages - 1);
+#pragma unroll
+      for (int j = 0; j < LOADS; ++j) {
+        const int blk = j * 4 + wave, kc = blk % kKS;
+        const int c = min(st * kKS + kc, nchunks - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)(c - kc) * 64),
+                                         (__attribute__((address_space(3))) void*)&lds[slot][blk / kKS][kc][0], 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t) dma(t, t);
+    int slot = 0, fill = NBUF - 1;               // slot of stage s; slot of stage s + NBUF - 1 (= the one stage s - 1 was read from)
+    for (int s = 0; s < nstages; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * LOADS) : "memory");
+      dma(s + NBUF - 1, fill);
+      compute(slot, s);
+      slot = slot == NBUF - 1 ? 0 : slot + 1;
+      fill = fill == NBUF - 1 ? 0 : fill + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's fragment reads are done before the wave reports at the next barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests: nothing may land in the ring once the epilogue reuses it
+  } else {
+    // stage t travels in set t % NS: stage 0 goes straight to the ring, stages 1 .. NS are requested behind it
+    fetch(stg[0], 0);
+    commit(0, stg[0]);
+#pragma unroll
+    for (int t = 1; t <= NS; ++t)
+      if (t < nstages) fetch(stg[t % NS], t);
+    // ua2_lds_barrier, not __syncthreads(): in front of an s_barrier it can see, the compiler drains vmcnt to 0 — with it
+    // the register staging sets never had more than one stage of MFMAs to cover a memory round trip
     ua2_lds_barrier();
-    if (s + 3 < nstages) fetch(stg0, s + 3);
-    if (s + 1 < nstages) compute(1, s + 1);      // odd stage: lds[1]
-    if (s + 2 < nstages) commit(0, stg1);
-    ua2_lds_barrier();
-    if (s + 4 < nstages) fetch(stg1, s + 4);
+    for (int s0 = 0; s0 < nstages; s0 += NU) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int s = s0 + u;
+        if (s >= nstages) break;
+        // the other ring half was read in stage s - 1 and everyone has passed the barrier since: fill it first, so that the
+        // ds_write latency runs under this stage's MFMAs instead of in front of the barrier
+        if (s + 1 < nstages) commit((u + 1) & 1, stg[(u + 1) % NS]);
+        if (s + 1 + NS < nstages) fetch(stg[(u + 1) % NS], s + 1 + NS);
+        compute(u & 1, s);
+        ua2_lds_barrier();
+      }
+    }
   }
   while (seg <= nw) { retire(); ++seg; }         // the last range (and any empty ones after it)
 
@@ -582,15 +647,23 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
   constexpr bool kCanHo = (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL);
   const bool ho = kCanHo && a.y_norm_w != nullptr;
-  auto go = [&](auto bmt_c, auto ho_c) {
-    constexpr int B = decltype(bmt_c)::value;
+  const bool no_glds = getenv("UA2_GEMM_NO_GLDS") != nullptr;                                                          // experiment hook: register staging everywhere
+  auto go = [&](auto bmt_c, auto ho_c, auto gl_c) {
+    constexpr int B = decltype(bmt_c)::value, G = decltype(gl_c)::value;
     constexpr bool H = decltype(ho_c)::value;
+    constexpr int TILES = B + NT * BNT;
+    constexpr auto kern = gemm_kernel<DT, EPI, B, H, G>;
+    ua2_allow_big_lds<kern>();
     const int mblocks = ua2_ceil_div(mtiles, B);
-    hipLaunchKernelGGL((gemm_kernel<DT, EPI, B, H>), dim3(mblocks * nblocks), dim3(256), 0, s, a, ap, nw, mblocks, nblocks, group_m);
+    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks), dim3(256), (size_t)(G ? G : 2) * TILES * kKS * 1024, s, a, ap, nw, mblocks, nblocks, group_m);
   };
   auto pick = [&](auto bmt_c) {
-    if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}); return; } }
-    go(bmt_c, std::false_type{});
+    constexpr int B = decltype(bmt_c)::value;
+    if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}, std::integral_constant<int, 0>{}); return; } }
+    // the LDS-DMA ring pays on the 32-row tile only (DiT FF2 80 -> 65 us, 512-row down-projection 95 -> 75); on the 64-row
+    // tile it loses 10 % (three slots there cost the third co-resident workgroup), deeper rings lose everywhere
+    if constexpr (B == 2) { if (!no_glds) { go(bmt_c, std::false_type{}, std::integral_constant<int, 3>{}); return; } }
+    go(bmt_c, std::false_type{}, std::integral_constant<int, 0>{});
   };
   if (bmt == 2) pick(std::integral_constant<int, 2>{});
   else if (bmt == 4) pick(std::integral_constant<int, 4>{});
