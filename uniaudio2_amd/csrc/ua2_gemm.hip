@@ -17,12 +17,12 @@
 //          decode kernel stages a row — same thread partition, same fixed-order statistics — and
 //          writes the operand rows in MFMA fragment order [M/16][K/KC][64 lanes][16 B] (the layout
 //          ua2_pack_linear gives the weights), so both GEMM operands stream as 1 KiB fragment blocks.
-//   gemm:  workgroup = 4 waves (2 x 2) = 128 rows x 128 columns (SwiGLU: 64 columns of each matrix);
-//          K advances two chunks per stage through a double-buffered 64 KiB LDS ring (global -> registers
-//          issued before the stage's MFMAs, registers -> LDS after); every wave reads its 4 + 4
-//          fragments per chunk from LDS with conflict-free 16-byte reads and issues 16 MFMAs.
-//          Workgroup ids are remapped so that each XCD works on a compact patch of (row-block,
-//          column-block) pairs: the fragments an L2 fetches are reused by its 32 CUs.
+//   gemm:  workgroup = 4 waves (2 x 2) = 128 rows x 128 columns (SwiGLU: 64 columns of each matrix); K advances through an LDS
+//          ring of fragment blocks — filled by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, hand-counted vmcnt in
+//          front of a raw s_barrier) on the 128- and 32-row tiles, through registers on the 64-row tile; every wave reads its
+//          4 + 4 fragments per chunk with conflict-free 16-byte reads — the NEXT chunk's while it multiplies this one on the
+//          128-row tile — and issues 16 MFMAs per chunk.  Workgroup ids are remapped so that each XCD works on a compact patch
+//          of (row-block, column-block) pairs: the fragments an L2 fetches are reused by its 32 CUs.
 // Bound: MFMA (2*M*N*K flop over (M + N)*K operand bytes); see DESIGN.md §5 for the measured fraction.
 #include <stdlib.h>
 
@@ -107,15 +107,17 @@ template <int DT, int EPI, int kBMT, bool HO, int GL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
                                                       const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
-  constexpr int kWM = kBMT / 2;       // row tiles per wave
+  constexpr int NWV = 4;                    // waves: 2 down the rows x 2 across the columns
+  constexpr int kWM = kBMT / (NWV / 2);     // row tiles per wave
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int WN = 4 / NT;          // column tiles per wave, per matrix
   constexpr int BNT = 2 * WN;         // column tiles per workgroup, per matrix
   constexpr int TILES = kBMT + NT * BNT;            // fragment streams per chunk (16)
-  constexpr int LOADS = TILES * kKS * 64 / 256;     // 16-byte pieces per thread per stage (8)
-  constexpr int NBUF = GL ? GL : 2;                 // ring slots of TILES x kKS KiB (GL = 0: register staging, two slots; else the LDS-DMA ring depth)
+  constexpr int KS = (GL && kBMT == 8) ? 1 : kKS;   // chunks per ring slot: the 128-row tile's LDS-DMA ring advances one chunk at a time (4 x 16 KiB)
+  constexpr int LOADS = TILES * KS / NWV;            // 16-byte pieces per thread per stage (8)
+  constexpr int NBUF = GL ? GL : 2;                 // ring slots of TILES x KS KiB (GL = 0: register staging, two slots; else the LDS-DMA ring depth)
   extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
-  u32x4 (*lds)[TILES][kKS][64] = reinterpret_cast<u32x4 (*)[TILES][kKS][64]>(gemm_smem);
+  u32x4 (*lds)[TILES][KS][64] = reinterpret_cast<u32x4 (*)[TILES][KS][64]>(gemm_smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   const u32x4* src[LOADS];
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) {
-    const int blk = j * 4 + wave, tile = blk / kKS, kc = blk % kKS;
+    const int blk = j * NWV + wave, tile = blk / KS, kc = blk % KS;
     const u32x4* p;
     if (tile < kBMT) {
       const int mt = min(pm * kBMT + tile, mtiles - 1);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
     }
     src[j] = p + (size_t)kc * 64 + lane;
   }
-  const int nstages = (nchunks + kKS - 1) / kKS;
+  const int nstages = (nchunks + KS - 1) / KS;
   // NS register staging sets: stages s+1 .. s+NS are in flight while stage s is multiplied.  One set exposed a full memory
   // round trip per stage (1.1 us/stage, profiles/r1_notes.md); two hide it when the tile is 128 rows (32 KiB and 32 MFMAs per
   // wave and stage); the 32- and 64-row tiles of small grids (the DiT's M = 1000) move 20 / 24 KiB and 8 / 16 MFMAs per
@@ -160,16 +162,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   auto fetch = [&](u32x4 (&stg)[LOADS], int s) {
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
-      const int kc = (j * 4 + wave) % kKS;
-      const int c = min(s * kKS + kc, nchunks - 1);          // clamped: a chunk past K is loaded but never used
+      const int kc = (j * NWV + wave) % KS;
+      const int c = min(s * KS + kc, nchunks - 1);          // clamped: a chunk past K is loaded but never used
       stg[j] = src[j][(size_t)(c - kc) * 64];
     }
   };
   auto commit = [&](int buf, const u32x4 (&stg)[LOADS]) {
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
-      const int blk = j * 4 + wave;
-      lds[buf][blk / kKS][blk % kKS][lane] = stg[j];
+      const int blk = j * NWV + wave;
+      lds[buf][blk / KS][blk % KS][lane] = stg[j];
     }
   };
 
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   //   64 rows: the compiler's own interleave (reads up front cost 10-15 % there: three workgroups share a CU and the fine
   //            interleave is what lets them overlap).
   //   128 rows: a chunk's reads before its MFMAs, pinned with a scheduling barrier (-2 ... -5 %; no registers for both chunks).
-  auto compute = [&](int buf, int s) {
-    constexpr int RD = kBMT == 2 ? kKS : 1;              // chunks read ahead of the MFMAs
+  auto compute = [&](int buf, int s, auto&& after_reads) {   // after_reads: issued between the stage's fragment reads and its MFMAs (the LDS-DMA requests)
+    constexpr int RD = kBMT == 2 ? KS : 1;              // chunks read ahead of the MFMAs
     u32x4 fa[RD][kWM], fb[RD][NT][WN];
     auto read = [&](int kc) {
 #pragma unroll
@@ -217,15 +219,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) fb[kc % RD][t][ni] = lds[buf][kBMT + t * BNT + wn * WN + ni][kc][lane];
     };
-    if constexpr (RD == kKS) {
+    if constexpr (RD == KS) {
 #pragma unroll
-      for (int kc = 0; kc < kKS; ++kc) read(kc);
+      for (int kc = 0; kc < KS; ++kc) read(kc);
       __builtin_amdgcn_sched_barrier(0);
+    } else {
+      after_reads();
     }
 #pragma unroll
-    for (int kc = 0; kc < kKS; ++kc) {
-      const int c = s * kKS + kc;
-      if constexpr (RD != kKS) {
+    for (int kc = 0; kc < KS; ++kc) {
+      const int c = s * KS + kc;
+      if constexpr (RD != KS) {
         read(kc);
         if constexpr (kBMT == 8) __builtin_amdgcn_sched_barrier(0);
       }
@@ -235,6 +239,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
           ++seg;
           boundary = (seg * nchunks) / nw;
         }
+        // LDS-DMA requests of the stage: behind the reads (whose latency they cover) and — first chunk of a live stage, so
+        // always executed — in one block with the MFMAs, spread among them: a request costs ~60 issue cycles, four MFMAs 64
+        if constexpr (RD == KS) { if (kc == 0) after_reads(); }
 #pragma unroll
         for (int mi = 0; mi < kWM; ++mi) {
           AFrag<DT> af;
@@ -243,6 +250,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
           for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) af.mma(fb[kc % RD][t][ni], chain[t][mi][ni]);
+        }
+        if constexpr (GL && RD == KS) {
+          if (kc == 0) {
+            constexpr int MF = kWM * NT * WN;            // MFMAs of the chunk
+#pragma unroll
+            for (int g = 0; g < LOADS; ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x008, MF / LOADS > 0 ? MF / LOADS : 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+          }
         }
       }
     }
@@ -258,22 +275,82 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
       const int st = min(t, nstages - 1);
 #pragma unroll
       for (int j = 0; j < LOADS; ++j) {
-        const int blk = j * 4 + wave, kc = blk % kKS;
-        const int c = min(st * kKS + kc, nchunks - 1);
+        const int blk = j * NWV + wave, kc = blk % KS;
+        const int c = min(st * KS + kc, nchunks - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)(c - kc) * 64),
-                                         (__attribute__((address_space(3))) void*)&lds[slot][blk / kKS][kc][0], 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)&lds[slot][blk / KS][kc][0], 16, 0, 0);
       }
     };
+    if constexpr (kBMT == 8) {
+      // 128-row tile: one chunk per slot (KS = 1), four slots, and the fragments of chunk c + 1 are READ while chunk c is
+      // multiplied (two fragment register sets: the staging registers this variant does not need).  Per chunk:
+      //   wait: my pieces of chunk c + 1 have landed (chunks c + 2, c + 3 stay in flight) and my fragment reads of chunk c are
+      //         complete (they were issued a whole chunk of MFMAs ago) | barrier: everyone's are |
+      //   read chunk c + 1 -> the other set | request chunk c + 4 into chunk c's slot (its fragments are in registers on every
+      //   wave: the barrier said so) spread among the MFMAs of chunk c.
+      // Cycle stamps before this (profiles/r3_notes.md §7): ~1040 cycles per wave and chunk for 256 cycles of MFMA issue, 300 of
+      // them the read -> wait -> first MFMA chain.
+      constexpr int NF = kWM + NT * WN;
+      u32x4 fr[2][NF];
+      auto read = [&](u32x4 (&f)[NF], int sl) {
+#pragma unroll
+        for (int mi = 0; mi < kWM; ++mi) f[mi] = lds[sl][wm * kWM + mi][0][lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) f[kWM + t * WN + ni] = lds[sl][kBMT + t * BNT + wn * WN + ni][0][lane];
+      };
+      auto step = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], int c) {
+        // `cur` rides through the statement as in/out operands: the compiler then places its own wait for those reads HERE (they
+        // were issued a chunk ago) instead of a conservative lgkmcnt(0) behind the next chunk's reads, in front of the first MFMA
+        static_assert(NF == 8, "operand list below");
+        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7])
+                     : "n"(2 * LOADS)
+                     : "memory");
+        while (seg < nw && c == boundary) {        // as in compute(); in front of the reads: everything behind it is one block
+          retire();
+          ++seg;
+          boundary = (seg * nchunks) / nw;
+        }
+        read(nxt, (c + 1) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        dma(c + 4, c & 3);
+#pragma unroll
+        for (int mi = 0; mi < kWM; ++mi) {
+          AFrag<DT> af;
+          af.v = __builtin_bit_cast(decltype(af.v), cur[mi]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) af.mma(cur[kWM + t * WN + ni], chain[t][mi][ni]);
+        }
+        constexpr int MF = kWM * NT * WN;
+#pragma unroll
+        for (int g = 0; g < LOADS; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MF / LOADS, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      };
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dma(t, t);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LOADS) : "memory");
+      read(fr[0], 0);
+      for (int c = 0; c < nchunks; c += 2) {
+        step(fr[0], fr[1], c);
+        if (c + 1 < nchunks) step(fr[1], fr[0], c + 1);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NBUF - 1; ++t) dma(t, t);
     int slot = 0, fill = NBUF - 1;               // slot of stage s; slot of stage s + NBUF - 1 (= the one stage s - 1 was read from)
     for (int s = 0; s < nstages; ++s) {
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * LOADS) : "memory");
-      dma(s + NBUF - 1, fill);
-      compute(slot, s);
+      compute(slot, s, [&]() { dma(s + NBUF - 1, fill); });   // the read latency runs under the requests' issue (~60 cycles apiece)
       slot = slot == NBUF - 1 ? 0 : slot + 1;
       fill = fill == NBUF - 1 ? 0 : fill + 1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's fragment reads are done before the wave reports at the next barrier
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests: nothing may land in the ring once the epilogue reuses it
   } else {
@@ -295,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
         // ds_write latency runs under this stage's MFMAs instead of in front of the barrier
         if (s + 1 < nstages) commit((u + 1) & 1, stg[(u + 1) % NS]);
         if (s + 1 + NS < nstages) fetch(stg[(u + 1) % NS], s + 1 + NS);
-        compute(u & 1, s);
+        compute(u & 1, s, []() {});
         ua2_lds_barrier();
       }
     }
@@ -643,11 +720,11 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   // 64-row tiles when the 128-row grid cannot give every CU two workgroups (measured on the DiT, M = 1000: 12.0 -> 9.5 ms per
   // step; no change at 2048 rows); 32-row tiles when even those leave CUs idle (M = 1000 x N = 1536: 192 workgroups)
   const int64_t g8 = (int64_t)ua2_ceil_div(mtiles, 8) * nblocks, g4 = (int64_t)ua2_ceil_div(mtiles, 4) * nblocks;
-  const int bmt = force_bmt ? force_bmt : (g8 >= 512 ? 8 : (g4 >= 256 ? 4 : 2));
-  const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
   constexpr bool kCanHo = (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL);
   const bool ho = kCanHo && a.y_norm_w != nullptr;
   const bool no_glds = getenv("UA2_GEMM_NO_GLDS") != nullptr;                                                          // experiment hook: register staging everywhere
+  const int bmt = force_bmt ? force_bmt : (g8 >= 512 ? 8 : (g4 >= 256 ? 4 : 2));
+  const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
   auto go = [&](auto bmt_c, auto ho_c, auto gl_c) {
     constexpr int B = decltype(bmt_c)::value, G = decltype(gl_c)::value;
     constexpr bool H = decltype(ho_c)::value;
@@ -655,14 +732,20 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
     constexpr auto kern = gemm_kernel<DT, EPI, B, H, G>;
     ua2_allow_big_lds<kern>();
     const int mblocks = ua2_ceil_div(mtiles, B);
-    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks), dim3(256), (size_t)(G ? G : 2) * TILES * kKS * 1024, s, a, ap, nw, mblocks, nblocks, group_m);
+    constexpr int NWV = 4;
+    size_t smem = (size_t)(G ? G : 2) * TILES * ((G && B == 8) ? 1 : kKS) * 1024;
+    if (EPI == UA2_EPI_QKV_ROPE) smem = std::max(smem, (size_t)NWV * (B / (NWV / 2)) * 16 * 64 * sizeof(float));          // the staged epilogues park a 64-column patch per wave in the ring
+    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks), dim3(64 * NWV), smem, s, a, ap, nw, mblocks, nblocks, group_m);
   };
   auto pick = [&](auto bmt_c) {
     constexpr int B = decltype(bmt_c)::value;
     if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}, std::integral_constant<int, 0>{}); return; } }
-    // the LDS-DMA ring pays on the 32-row tile only (DiT FF2 80 -> 65 us, 512-row down-projection 95 -> 75); on the 64-row
-    // tile it loses 10 % (three slots there cost the third co-resident workgroup), deeper rings lose everywhere
+    // LDS-DMA ring: three two-chunk slots on the 32-row tile (DiT FF2 80 -> 59 us, 512-row down-projection 95 -> 65), four
+    // one-chunk slots with fragment read-ahead on the 128-row tile (6272-row SwiGLU 921 -> 724 us).  On the 64-row tile it loses
+    // 10 % (three slots there cost the third co-resident workgroup); deeper rings and a 256-row / 8-wave tile lose as well
+    // (profiles/r3_notes.md §7)
     if constexpr (B == 2) { if (!no_glds) { go(bmt_c, std::false_type{}, std::integral_constant<int, 3>{}); return; } }
+    if constexpr (B == 8) { if (!no_glds) { go(bmt_c, std::false_type{}, std::integral_constant<int, 4>{}); return; } }
     go(bmt_c, std::false_type{}, std::integral_constant<int, 0>{});
   };
   if (bmt == 2) pick(std::integral_constant<int, 2>{});
