@@ -99,11 +99,10 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
 constexpr int kKS = 2;      // chunks per LDS stage
 constexpr int kGroupM = 8;  // row-blocks per L2 patch
 
-// GL: the operand ring is filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight from L2 into the ring,
-// three ring slots) instead of global -> registers -> ds_write_b128 (two slots).  The 32- / 64-row tiles were bound by the LDS
-// pipe — a ds_write_b128 costs 13 LDS-issue cycles per KiB against 4 for the ds_read_b128 that reads it back
-// (MI355X_MICROARCH.md §LDS), PMC: LDS 48 % busy, MFMA 10 %, L2 27 % on the DiT's FF2 (profiles/r3_notes.md §7).
-template <int DT, int EPI, int kBMT, bool HO, int GL>
+// GL: the operand ring is filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight from L2 into the
+// ring) instead of global -> registers -> ds_write_b128: see the main loop.  !GL (register staging) serves the hand-over
+// instantiations (HO) and the UA2_GEMM_NO_GLDS experiment hook.
+template <int DT, int EPI, int kBMT, bool HO, bool GL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
                                                       const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
@@ -113,9 +112,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   constexpr int WN = 4 / NT;          // column tiles per wave, per matrix
   constexpr int BNT = 2 * WN;         // column tiles per workgroup, per matrix
   constexpr int TILES = kBMT + NT * BNT;            // fragment streams per chunk (16)
-  constexpr int KS = (GL && kBMT == 8) ? 1 : kKS;   // chunks per ring slot: the 128-row tile's LDS-DMA ring advances one chunk at a time (4 x 16 KiB)
-  constexpr int LOADS = TILES * KS / NWV;            // 16-byte pieces per thread per stage (8)
-  constexpr int NBUF = GL ? GL : 2;                 // ring slots of TILES x KS KiB (GL = 0: register staging, two slots; else the LDS-DMA ring depth)
+  constexpr int KS = GL ? 1 : kKS;          // chunks per ring slot
+  constexpr int LOADS = (TILES * KS + NWV - 1) / NWV;   // 16-byte pieces per thread per stage; 10 blocks over 4 waves: the last two are requested twice (same bytes, same place)
+  constexpr int NBUF = GL ? 4 : 2;                  // ring slots of TILES x KS KiB
   extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
   u32x4 (*lds)[TILES][KS][64] = reinterpret_cast<u32x4 (*)[TILES][KS][64]>(gemm_smem);
 
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   const u32x4* src[LOADS];
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) {
-    const int blk = j * NWV + wave, tile = blk / KS, kc = blk % KS;
+    const int blk = min(j * NWV + wave, TILES * KS - 1), tile = blk / KS, kc = blk % KS;
     const u32x4* p;
     if (tile < kBMT) {
       const int mt = min(pm * kBMT + tile, mtiles - 1);
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   auto fetch = [&](u32x4 (&stg)[LOADS], int s) {
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
-      const int kc = (j * NWV + wave) % KS;
+      const int kc = min(j * NWV + wave, TILES * KS - 1) % KS;
       const int c = min(s * KS + kc, nchunks - 1);          // clamped: a chunk past K is loaded but never used
       stg[j] = src[j][(size_t)(c - kc) * 64];
     }
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   auto commit = [&](int buf, const u32x4 (&stg)[LOADS]) {
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
-      const int blk = j * NWV + wave;
+      const int blk = min(j * NWV + wave, TILES * KS - 1);
       lds[buf][blk / KS][blk % KS][lane] = stg[j];
     }
   };
@@ -200,160 +199,126 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
   int seg = 1;                                   // next range boundary: chunk (seg * nchunks) / nw
   int boundary = (seg * nchunks) / nw;
 
-  // Fragment reads against MFMAs, per tile size (cycle stamps and A/B runs in profiles/r3_notes.md §7):
-  //   32 rows: ALL reads of the stage before its first MFMA.  The retire checks sit between the chunks and the compiler will not
-  //            move a ds_read across that control flow; left to itself it emitted read - wait - MFMA chains, 710 cycles per stage
-  //            for 128 cycles of MFMA work (470 with the reads up front).  A chunk past K is read like any other (the loader
-  //            clamps, the slot holds valid data) and not multiplied.
-  //   64 rows: the compiler's own interleave (reads up front cost 10-15 % there: three workgroups share a CU and the fine
-  //            interleave is what lets them overlap).
-  //   128 rows: a chunk's reads before its MFMAs, pinned with a scheduling barrier (-2 ... -5 %; no registers for both chunks).
-  auto compute = [&](int buf, int s, auto&& after_reads) {   // after_reads: issued between the stage's fragment reads and its MFMAs (the LDS-DMA requests)
-    constexpr int RD = kBMT == 2 ? KS : 1;              // chunks read ahead of the MFMAs
-    u32x4 fa[RD][kWM], fb[RD][NT][WN];
-    auto read = [&](int kc) {
-#pragma unroll
-      for (int mi = 0; mi < kWM; ++mi) fa[kc % RD][mi] = lds[buf][wm * kWM + mi][kc][lane];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[kc % RD][t][ni] = lds[buf][kBMT + t * BNT + wn * WN + ni][kc][lane];
-    };
-    if constexpr (RD == KS) {
-#pragma unroll
-      for (int kc = 0; kc < KS; ++kc) read(kc);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      after_reads();
-    }
-#pragma unroll
-    for (int kc = 0; kc < KS; ++kc) {
-      const int c = s * KS + kc;
-      if constexpr (RD != KS) {
-        read(kc);
-        if constexpr (kBMT == 8) __builtin_amdgcn_sched_barrier(0);
-      }
-      if (c < nchunks) {
-        while (seg < nw && c == boundary) {      // `while`: empty ranges (nw > nchunks) retire zeros, as the decode kernel adds them
-          retire();
-          ++seg;
-          boundary = (seg * nchunks) / nw;
-        }
-        // LDS-DMA requests of the stage: behind the reads (whose latency they cover) and — first chunk of a live stage, so
-        // always executed — in one block with the MFMAs, spread among them: a request costs ~60 issue cycles, four MFMAs 64
-        if constexpr (RD == KS) { if (kc == 0) after_reads(); }
-#pragma unroll
-        for (int mi = 0; mi < kWM; ++mi) {
-          AFrag<DT> af;
-          af.v = __builtin_bit_cast(decltype(af.v), fa[kc % RD][mi]);
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni) af.mma(fb[kc % RD][t][ni], chain[t][mi][ni]);
-        }
-        if constexpr (GL && RD == KS) {
-          if (kc == 0) {
-            constexpr int MF = kWM * NT * WN;            // MFMAs of the chunk
-#pragma unroll
-            for (int g = 0; g < LOADS; ++g) {
-              __builtin_amdgcn_sched_group_barrier(0x008, MF / LOADS > 0 ? MF / LOADS : 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            }
-          }
-        }
-      }
+  // A chunk boundary of the decode kernel's K split: retire the running chain (`while`: empty ranges — nw > nchunks — retire
+  // zeros, as the decode kernel adds them)
+  auto retire_at = [&](int c) {
+    while (seg < nw && c == boundary) {
+      retire();
+      ++seg;
+      boundary = (seg * nchunks) / nw;
     }
   };
 
   if constexpr (GL) {
-    // stage t -> ring slot t % NBUF.  Per stage: wait for MY pieces of stage s (everything but the newest NBUF - 2 stages' requests),
-    // barrier (now everyone's pieces of s have landed AND everyone is done reading the slot of stage s - 1), request stage
-    // s + NBUF - 1 into that slot, multiply stage s.  Requests past the last stage are clamped onto it (into a slot nobody reads again), so
-    // the count in front of every barrier is the same.  The wait is hand-counted: an LDS-DMA is invisible to the compiler's
-    // s_waitcnt bookkeeping for the ds_reads that follow.
-    auto dma = [&](int t, int slot) {
-      const int st = min(t, nstages - 1);
+    // ---- LDS-DMA ring: one chunk per slot, four slots; the fragments of chunk c + 1 are READ while chunk c is multiplied ----
+    // Per chunk:
+    //   wait: my pieces of chunk c + 1 have landed (chunks c + 2, c + 3 stay in flight) and my fragment reads of chunk c are
+    //         complete (they were issued a whole chunk of MFMAs ago) | barrier: everyone's are |
+    //   retire check | read chunk c + 1 -> the other fragment set | request chunk c + 4 into chunk c's slot (its fragments are
+    //   in registers on every wave: the barrier said so), the requests spread among the MFMAs of chunk c (a request costs
+    //   ~60-85 issue cycles, four MFMAs 64).
+    // Requests past the last chunk are clamped onto it (into a slot nobody reads again), so the count in front of every barrier
+    // is the same.  The waits are hand-counted: an LDS-DMA is invisible to the compiler's s_waitcnt bookkeeping for the
+    // ds_reads that follow, and a __syncthreads() would drain vmcnt to 0.
+    // How this came about (cycle stamps per phase, profiles/r3_notes.md §7): with register staging a wave of the 128-row tile
+    // spent ~750 cycles per two-chunk stage issuing ds_write_b128 (13 LDS-issue cycles per KiB), ~1000 issuing its 8 global
+    // loads behind everyone else's and ~1500 in read -> wait -> MFMA chains, for 512 cycles of MFMA issue.
+    constexpr int NF = kWM + NT * WN;
+    u32x4 fr[2][NF];
+    auto dma = [&](int c_req, int slot) {
+      const int c = min(c_req, nchunks - 1);
 #pragma unroll
       for (int j = 0; j < LOADS; ++j) {
-        const int blk = j * NWV + wave, kc = blk % KS;
-        const int c = min(st * KS + kc, nchunks - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)(c - kc) * 64),
-                                         (__attribute__((address_space(3))) void*)&lds[slot][blk / KS][kc][0], 16, 0, 0);
+        const int blk = min(j * NWV + wave, TILES - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)c * 64),
+                                         (__attribute__((address_space(3))) void*)&lds[slot][blk][0][0], 16, 0, 0);
       }
     };
-    if constexpr (kBMT == 8) {
-      // 128-row tile: one chunk per slot (KS = 1), four slots, and the fragments of chunk c + 1 are READ while chunk c is
-      // multiplied (two fragment register sets: the staging registers this variant does not need).  Per chunk:
-      //   wait: my pieces of chunk c + 1 have landed (chunks c + 2, c + 3 stay in flight) and my fragment reads of chunk c are
-      //         complete (they were issued a whole chunk of MFMAs ago) | barrier: everyone's are |
-      //   read chunk c + 1 -> the other set | request chunk c + 4 into chunk c's slot (its fragments are in registers on every
-      //   wave: the barrier said so) spread among the MFMAs of chunk c.
-      // Cycle stamps before this (profiles/r3_notes.md §7): ~1040 cycles per wave and chunk for 256 cycles of MFMA issue, 300 of
-      // them the read -> wait -> first MFMA chain.
-      constexpr int NF = kWM + NT * WN;
-      u32x4 fr[2][NF];
-      auto read = [&](u32x4 (&f)[NF], int sl) {
+    auto read = [&](u32x4 (&f)[NF], int slot) {
 #pragma unroll
-        for (int mi = 0; mi < kWM; ++mi) f[mi] = lds[sl][wm * kWM + mi][0][lane];
+      for (int mi = 0; mi < kWM; ++mi) f[mi] = lds[slot][wm * kWM + mi][0][lane];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int ni = 0; ni < WN; ++ni) f[kWM + t * WN + ni] = lds[sl][kBMT + t * BNT + wn * WN + ni][0][lane];
-      };
-      auto step = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], int c) {
-        // `cur` rides through the statement as in/out operands: the compiler then places its own wait for those reads HERE (they
-        // were issued a chunk ago) instead of a conservative lgkmcnt(0) behind the next chunk's reads, in front of the first MFMA
-        static_assert(NF == 8, "operand list below");
+        for (int ni = 0; ni < WN; ++ni) f[kWM + t * WN + ni] = lds[slot][kBMT + t * BNT + wn * WN + ni][0][lane];
+    };
+    auto step = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], int c) {
+      // `cur` rides through the statement as in/out operands: the compiler then places its own wait for those reads HERE (they
+      // were issued a chunk ago) instead of a conservative lgkmcnt(0) behind the next chunk's reads, in front of the first MFMA
+      static_assert(NF == 8 || NF == 6 || NF == 5, "operand lists below");
+      if constexpr (NF == 8) {
         asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
                      : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7])
                      : "n"(2 * LOADS)
                      : "memory");
-        while (seg < nw && c == boundary) {        // as in compute(); in front of the reads: everything behind it is one block
-          retire();
-          ++seg;
-          boundary = (seg * nchunks) / nw;
-        }
-        read(nxt, (c + 1) & 3);
-        __builtin_amdgcn_sched_barrier(0);
-        dma(c + 4, c & 3);
-#pragma unroll
-        for (int mi = 0; mi < kWM; ++mi) {
-          AFrag<DT> af;
-          af.v = __builtin_bit_cast(decltype(af.v), cur[mi]);
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni) af.mma(cur[kWM + t * WN + ni], chain[t][mi][ni]);
-        }
-        constexpr int MF = kWM * NT * WN;
-#pragma unroll
-        for (int g = 0; g < LOADS; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, MF / LOADS, 0);
-          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
-      };
-#pragma unroll
-      for (int t = 0; t < 4; ++t) dma(t, t);
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LOADS) : "memory");
-      read(fr[0], 0);
-      for (int c = 0; c < nchunks; c += 2) {
-        step(fr[0], fr[1], c);
-        if (c + 1 < nchunks) step(fr[1], fr[0], c + 1);
+      } else if constexpr (NF == 6) {
+        asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5])
+                     : "n"(2 * LOADS)
+                     : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4])
+                     : "n"(2 * LOADS)
+                     : "memory");
       }
-    } else {
+      retire_at(c);                              // in front of the reads: everything behind it is one block
+      read(nxt, (c + 1) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      dma(c + 4, c & 3);
 #pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t) dma(t, t);
-    int slot = 0, fill = NBUF - 1;               // slot of stage s; slot of stage s + NBUF - 1 (= the one stage s - 1 was read from)
-    for (int s = 0; s < nstages; ++s) {
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * LOADS) : "memory");
-      compute(slot, s, [&]() { dma(s + NBUF - 1, fill); });   // the read latency runs under the requests' issue (~60 cycles apiece)
-      slot = slot == NBUF - 1 ? 0 : slot + 1;
-      fill = fill == NBUF - 1 ? 0 : fill + 1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's fragment reads are done before the wave reports at the next barrier
-    }
+      for (int mi = 0; mi < kWM; ++mi) {
+        AFrag<DT> af;
+        af.v = __builtin_bit_cast(decltype(af.v), cur[mi]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) af.mma(cur[kWM + t * WN + ni], chain[t][mi][ni]);
+      }
+      constexpr int MF = kWM * NT * WN;          // MFMAs of the chunk
+#pragma unroll
+      for (int g = 0; g < LOADS; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MF / LOADS > 0 ? MF / LOADS : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dma(t, t);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LOADS) : "memory");
+    read(fr[0], 0);
+    for (int c = 0; c < nchunks; c += 2) {
+      step(fr[0], fr[1], c);
+      if (c + 1 < nchunks) step(fr[1], fr[0], c + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests: nothing may land in the ring once the epilogue reuses it
   } else {
+    // ---- register staging (the hand-over instantiations and the UA2_GEMM_NO_GLDS hook): two-chunk stages, two ring halves ----
+    auto compute = [&](int buf, int s) {
+#pragma unroll
+      for (int kc = 0; kc < KS; ++kc) {
+        const int c = s * KS + kc;
+        u32x4 fa[kWM], fb[NT][WN];
+#pragma unroll
+        for (int mi = 0; mi < kWM; ++mi) fa[mi] = lds[buf][wm * kWM + mi][kc][lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) fb[t][ni] = lds[buf][kBMT + t * BNT + wn * WN + ni][kc][lane];
+        if constexpr (kBMT == 8) __builtin_amdgcn_sched_barrier(0);   // a chunk's reads before its MFMAs (-2 ... -5 % on the 128-row tile)
+        if (c < nchunks) {
+          retire_at(c);
+#pragma unroll
+          for (int mi = 0; mi < kWM; ++mi) {
+            AFrag<DT> af;
+            af.v = __builtin_bit_cast(decltype(af.v), fa[mi]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int ni = 0; ni < WN; ++ni) af.mma(fb[t][ni], chain[t][mi][ni]);
+          }
+        }
+      }
+    };
     // stage t travels in set t % NS: stage 0 goes straight to the ring, stages 1 .. NS are requested behind it
     fetch(stg[0], 0);
     commit(0, stg[0]);
@@ -372,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, c
         // ds_write latency runs under this stage's MFMAs instead of in front of the barrier
         if (s + 1 < nstages) commit((u + 1) & 1, stg[(u + 1) % NS]);
         if (s + 1 + NS < nstages) fetch(stg[(u + 1) % NS], s + 1 + NS);
-        compute(u & 1, s, []() {});
+        compute(u & 1, s);
         ua2_lds_barrier();
       }
     }
@@ -726,27 +691,20 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   const int bmt = force_bmt ? force_bmt : (g8 >= 512 ? 8 : (g4 >= 256 ? 4 : 2));
   const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
   auto go = [&](auto bmt_c, auto ho_c, auto gl_c) {
-    constexpr int B = decltype(bmt_c)::value, G = decltype(gl_c)::value;
-    constexpr bool H = decltype(ho_c)::value;
+    constexpr int B = decltype(bmt_c)::value;
+    constexpr bool H = decltype(ho_c)::value, G = decltype(gl_c)::value;
     constexpr int TILES = B + NT * BNT;
     constexpr auto kern = gemm_kernel<DT, EPI, B, H, G>;
     ua2_allow_big_lds<kern>();
     const int mblocks = ua2_ceil_div(mtiles, B);
-    constexpr int NWV = 4;
-    size_t smem = (size_t)(G ? G : 2) * TILES * ((G && B == 8) ? 1 : kKS) * 1024;
-    if (EPI == UA2_EPI_QKV_ROPE) smem = std::max(smem, (size_t)NWV * (B / (NWV / 2)) * 16 * 64 * sizeof(float));          // the staged epilogues park a 64-column patch per wave in the ring
-    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks), dim3(64 * NWV), smem, s, a, ap, nw, mblocks, nblocks, group_m);
+    size_t smem = (size_t)(G ? 4 : 2 * kKS) * TILES * 1024;
+    if (EPI == UA2_EPI_QKV_ROPE) smem = std::max(smem, (size_t)4 * (B / 2) * 16 * 64 * sizeof(float));   // the staged epilogues park a 64-column patch per wave in the ring
+    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks), dim3(256), smem, s, a, ap, nw, mblocks, nblocks, group_m);
   };
   auto pick = [&](auto bmt_c) {
-    constexpr int B = decltype(bmt_c)::value;
-    if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}, std::integral_constant<int, 0>{}); return; } }
-    // LDS-DMA ring: three two-chunk slots on the 32-row tile (DiT FF2 80 -> 59 us, 512-row down-projection 95 -> 65), four
-    // one-chunk slots with fragment read-ahead on the 128-row tile (6272-row SwiGLU 921 -> 724 us).  On the 64-row tile it loses
-    // 10 % (three slots there cost the third co-resident workgroup); deeper rings and a 256-row / 8-wave tile lose as well
-    // (profiles/r3_notes.md §7)
-    if constexpr (B == 2) { if (!no_glds) { go(bmt_c, std::false_type{}, std::integral_constant<int, 3>{}); return; } }
-    if constexpr (B == 8) { if (!no_glds) { go(bmt_c, std::false_type{}, std::integral_constant<int, 4>{}); return; } }
-    go(bmt_c, std::false_type{}, std::integral_constant<int, 0>{});
+    if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}, std::false_type{}); return; } }
+    if (no_glds) go(bmt_c, std::false_type{}, std::false_type{});
+    else go(bmt_c, std::false_type{}, std::true_type{});
   };
   if (bmt == 2) pick(std::integral_constant<int, 2>{});
   else if (bmt == 4) pick(std::integral_constant<int, 4>{});
