@@ -728,6 +728,20 @@ bool choose_skinny(const ua2_linear_args& a, int nt) {
   return t_skinny <= t_tiled;
 }
 
+// Rows up to which the weights-stationary kernel (ua2_skinny.hip) beats the tiled one on MI355X, per (N, K, matrices) of the model's
+// Linear layers — both give the same bits, so this is a cost table, measured by tools/ubench/skinny_vs_tiled.py
+// (profiles/r3_skinny_vs_tiled.txt); 320 for shapes it does not list (the cut-over of the round-3 sweeps).  The tiled kernel's time
+// is nearly flat below ~256 rows (one workgroup per CU, ~0.16 us per chunk of K), the stationary kernel's grows with the operand
+// bytes every CU has to pull in.
+int skinny2_max_rows(int64_t N, int64_t K, int nt) {
+  struct Cut { int N, K, nt, rows; };
+  static constexpr Cut kCut[] = {{5120, 3072, 1, 176},  {3072, 3072, 1, 288}, {8192, 3072, 2, 96},  {3072, 8192, 1, 192}, {3072, 2048, 1, 288},
+                                 {2048, 2048, 1, 320},  {8192, 2048, 2, 208}, {2048, 8192, 1, 320}, {2048, 3072, 1, 320}, {12296, 2048, 1, 192}};
+  for (const Cut& c : kCut)
+    if (c.N == N && c.K == K && c.nt == nt) return c.rows;
+  return 320;
+}
+
 template <int DT>
 int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
   const int nt = a.epilogue == UA2_EPI_SWIGLU ? 2 : 1;
@@ -743,7 +757,7 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
   const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
   // The weights-stationary form (ua2_skinny.hip) serves the model's bf16 shapes up to a few hundred rows: measured against
   // the tiled kernel it wins up to 256 rows everywhere except the 128k-column lm_head (profiles/r3_skinny_sweep.txt).
-  const bool prefer2 = force != 5 && a.dtype == UA2_BF16 && a.M <= 320 && a.N < 32768;
+  const bool prefer2 = force != 5 && a.dtype == UA2_BF16 && a.M <= skinny2_max_rows(a.N, a.K, nt) && a.N < 32768;
   const bool old_skinny = skinny_ok && (force == 4 || (force != 5 && choose_skinny(a, nt)));
   if (prefer2 || old_skinny)
     if (const int rc = ua2_skinny2_try_launch(a, geo, s); rc <= 0) return rc;
