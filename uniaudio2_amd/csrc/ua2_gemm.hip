@@ -103,7 +103,7 @@ constexpr int kGroupM = 8;  // row-blocks per L2 patch
 // ring) instead of global -> registers -> ds_write_b128: see the main loop.  !GL (register staging) serves the hand-over
 // instantiations (HO) and the UA2_GEMM_NO_GLDS experiment hook.
 template <int DT, int EPI, int kBMT, bool HO, bool GL>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
+__global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ? 3 : 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
                                                       const int mblocks, const int nblocks, const int group_m) {
   constexpr int KC = Elem<DT>::KC;
   constexpr int NWV = 4;                    // waves: 2 down the rows x 2 across the columns
