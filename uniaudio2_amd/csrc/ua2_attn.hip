@@ -321,15 +321,13 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = 0.f;
       }
-      unsigned h[8], l[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = __fmul_rn(f[e], sc);
-        h[e] = f2bf(v);
-        l[e] = f2bf(v - bf2f((unsigned short)h[e]));
+      for (int e = 0; e < 4; ++e) {               // hardware pair conversion (finite values: the bits of f2bf)
+        unsigned hi, lo;
+        split_pair(__fmul_rn(f[2 * e], sc), __fmul_rn(f[2 * e + 1], sc), hi, lo);
+        qh[dc][e] = hi;
+        qlo[dc][e] = lo;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { qh[dc][e] = h[2 * e] | (h[2 * e + 1] << 16); qlo[dc][e] = l[2 * e] | (l[2 * e + 1] << 16); }
     }
   }
   float m_run = -INFINITY, l_run = 0.f;
@@ -401,17 +399,23 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
     u32x4 ph[2], pl[2];                                          // P^T fragments of the two 32-key chunks
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
-      unsigned h[8], l[8];
+      float pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {                              // element e <-> key kc*32 + (e < 4 ? 4g + e : 16 + 4g + e - 4)
         const float sv = st[2 * kc + (e >> 2)][e & 3];
-        const float pv = (sv == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv - m_new);
-        ps += pv;
-        h[e] = f2bf(pv);
-        l[e] = f2bf(pv - bf2f((unsigned short)h[e]));
+        pv[e] = (sv == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv - m_new);
+        ps += pv[e];
       }
+      // hi / lo split with the hardware pair conversion (v_cvt_pk_bf16_f32; finite values: the bits of f2bf).  The scalar
+      // f2bf form was 32 calls of ~8 VALU instructions per block: the softmax took 3300 of a block's 6800 cycles
+      // (cycle stamps, profiles/r3_notes.md §8)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { ph[kc][e] = h[2 * e] | (h[2 * e + 1] << 16); pl[kc][e] = l[2 * e] | (l[2 * e + 1] << 16); }
+      for (int e = 0; e < 4; ++e) {
+        unsigned hi, lo;
+        split_pair(pv[2 * e], pv[2 * e + 1], hi, lo);
+        ph[kc][e] = hi;
+        pl[kc][e] = lo;
+      }
     }
     ps += __shfl_xor(ps, 16);
     ps += __shfl_xor(ps, 32);

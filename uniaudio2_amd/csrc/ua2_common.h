@@ -72,6 +72,19 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
 
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+// (lo half = bf16(a), hi half = bf16(b)), round to nearest even: one v_cvt_pk_bf16_f32 (finite values: same bits as f2bf)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const f32x2_hw v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
+}
+// hi/lo split of a pair: hi = RNE(x), lo = RNE(x - hi)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(x0, x1);
+  lo = pack_bf16x2(__fsub_rn(x0, __uint_as_float(hi << 16)), __fsub_rn(x1, __uint_as_float(hi & 0xffff0000u)));
+}
+
 template <int DT> __device__ __forceinline__ float load_elem(const void* p, size_t i);
 template <> __device__ __forceinline__ float load_elem<UA2_F32>(const void* p, size_t i) { return ((const float*)p)[i]; }
 template <> __device__ __forceinline__ float load_elem<UA2_BF16>(const void* p, size_t i) {

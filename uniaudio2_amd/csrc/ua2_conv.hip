@@ -393,19 +393,6 @@ __global__ __launch_bounds__(256, 4) void conv1d_x3_kernel(const ua2_conv1d_args
 //     the 120 / 240 kHz-rate work) pipeline across tiles.
 // One barrier per unit (two more inside a fused residual-unit epilogue).  Arithmetic, operand split and summation
 // order are those of conv1d_x3_kernel: the two kernels are bit-identical (tests/test_gpu_conv.py).
-typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
-typedef float f32x2_hw __attribute__((ext_vector_type(2)));
-// (lo half = bf16(a), hi half = bf16(b)), round to nearest even: one v_cvt_pk_bf16_f32 (finite values: same bits as f2bf)
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  const f32x2_hw v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
-}
-// hi/lo split of a pair: hi = RNE(x), lo = RNE(x - hi)
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-  hi = pack_bf16x2(x0, x1);
-  lo = pack_bf16x2(__fsub_rn(x0, __uint_as_float(hi << 16)), __fsub_rn(x1, __uint_as_float(hi & 0xffff0000u)));
-}
-
 constexpr int kKC = 8;         // most weight chunks (tap x channel group) a unit holds in registers
 
 // NTT 16-step time tiles per wave (one 16-row tile per wave), CPU weight chunks per unit = GPU channel groups x K taps.
