@@ -58,16 +58,22 @@ def linear_mode():
     """ua2_debug_force_general_linear: 2 = row-tiled decode kernel only, 4 / 5 = skinny / tiled large-M kernel."""
     from uniaudio2_amd._lib import lib
 
-    def set_mode(m, bmt=None):
-        """bmt: row tiles per workgroup of the tiled kernel (UA2_GEMM_BMT: 8 = 128 x 128 tile, 4 = 64 x 128), None = its own choice."""
+    def set_mode(m, bmt=None, no_glds=False):
+        """bmt: row tiles per workgroup of the tiled kernel (UA2_GEMM_BMT: 8 = 128 x 128 tile, 4 = 64 x 128), None = its own choice;
+        no_glds: the register-staged operand ring (UA2_GEMM_NO_GLDS) instead of the LDS-DMA ring."""
         lib.ua2_debug_force_general_linear(m)
         if bmt is None:
             os.environ.pop("UA2_GEMM_BMT", None)
         else:
             os.environ["UA2_GEMM_BMT"] = str(bmt)
+        if no_glds:
+            os.environ["UA2_GEMM_NO_GLDS"] = "1"
+        else:
+            os.environ.pop("UA2_GEMM_NO_GLDS", None)
     yield set_mode
     lib.ua2_debug_force_general_linear(0)
     os.environ.pop("UA2_GEMM_BMT", None)
+    os.environ.pop("UA2_GEMM_NO_GLDS", None)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -113,11 +119,12 @@ def test_large_m_kernel_is_bit_identical_to_the_decode_kernel(dtype, N, K, linea
         for M in (1, 5, 40, 130, 300):
             linear_mode(2)
             ref = run(M, pro, epi, nk)
-            for mode, bmt in ((4, None), (5, 8), (5, 4), (5, 2)):     # skinny form; 128-, 64- and 32-row tiled forms
-                linear_mode(mode, bmt)
+            # skinny form; 128-, 64- and 32-row tiled forms on the LDS-DMA ring; the register-staged ring (128- and 32-row)
+            for mode, bmt, reg in ((4, None, False), (5, 8, False), (5, 4, False), (5, 2, False), (5, 8, True), (5, 2, True)):
+                linear_mode(mode, bmt, reg)
                 got = run(M, pro, epi, nk)
                 for r, o, name in zip(ref, got, ("y", "part_max", "part_idx")):
-                    assert torch.equal(r, o), (pro, epi, nk, M, mode, bmt, name, (r.float() - o.float()).abs().max().item())
+                    assert torch.equal(r, o), (pro, epi, nk, M, mode, bmt, reg, name, (r.float() - o.float()).abs().max().item())
         linear_mode(0)                      # the launcher's own choice (cost model between the two forms)
         got = run(300, pro, epi, nk)
         for r, o in zip(ref, got):
