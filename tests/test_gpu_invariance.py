@@ -299,3 +299,36 @@ def test_scaled_norm_handover_is_kernel_and_row_count_invariant(linear_mode):
     y, ssq, h, pk = produce(slice(0, 64), 4, True)
     gm = consume(64, 4, h, pk, ssq, True)
     assert torch.equal(gm[::9], g1[:8])
+
+
+@pytest.mark.parametrize("M,N,K,bmt", [(6272, 1024, 3072, 8), (2048, 3072, 8192, 4), (1000, 1536, 6144, 2), (333, 384, 1056, 2)])
+def test_tiled_gemm_ring_is_repeatable(M, N, K, bmt, linear_mode):
+    """Race screen for the LDS-DMA operand ring (hand-counted vmcnt + raw s_barrier): 25 launches of the same problem on a
+    busy device give the same bits every time, and those bits are the register-staged ring's (a different synchronisation
+    structure).  An early fragment read or a late ring refill would show up as rare wrong tiles."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST
+    dev = torch.device("cuda")
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt)
+    x = torch.randn(M, K, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    ws = ops.linear_workspace(dt, M, K, dev)
+    noise = torch.randn(4096, 4096, device=dev)
+
+    def run(reg):
+        linear_mode(5, bmt, reg)
+        y = torch.empty(M, N, device=dev)
+        ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x, y=y, resid=res, workspace=ws)
+        return y
+
+    ref = run(True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for i in range(25):
+        with torch.cuda.stream(side):              # unrelated traffic on another stream: shifts arrival times in the ring
+            noise = noise * 1.0001
+        got = run(False)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), (i, (got - ref).abs().max().item())
