@@ -151,10 +151,9 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
     src[j] = p + (size_t)kc * 64 + lane;
   }
   const int nstages = (nchunks + KS - 1) / KS;
-  // NS register staging sets: stages s+1 .. s+NS are in flight while stage s is multiplied.  One set exposed a full memory
-  // round trip per stage (1.1 us/stage, profiles/r1_notes.md); two hide it when the tile is 128 rows (32 KiB and 32 MFMAs per
-  // wave and stage); the 32- and 64-row tiles of small grids (the DiT's M = 1000) move 20 / 24 KiB and 8 / 16 MFMAs per
-  // stage and were still latency-bound at 0.8 us per stage with two — they have the registers for 6 / 4 sets.
+  // Register-staged ring (!GL) — NS staging sets: stages s+1 .. s+NS are in flight while stage s is multiplied.  One set exposed a
+  // full memory round trip per stage (1.1 us/stage, profiles/r1_notes.md); two hide it.  Four / six sets on the small tiles were
+  // measured in round 3 and lost 10-30 % (profiles/r3_notes.md §7): those tiles were not waiting for memory.
   constexpr int NS = 2;
   constexpr int NU = (NS % 2) ? 2 * NS : NS;     // steps per unrolled round: ring half and set both compile-time
   u32x4 stg[NS][LOADS];
