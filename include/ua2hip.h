@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 5
+#define UA2_VERSION 6
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -291,10 +291,15 @@ int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32
  * d2 = sum_k fma(x_k-e_k, x_k-e_k, .), k ascending; lowest index wins ties (= oracle/rvq_oracle.c bit for bit).
  * workspace (optional, >= ua2_rvq_workspace_bytes(N, L) bytes of device scratch): lets a launch with few vectors (one
  * clip) split each level's codebook over several workgroups per group of 8 vectors (candidates merged by 64-bit atomic
- * min, lowest index on ties); same codes and sums with or without it. */
+ * min, lowest index on ties); same codes and sums with or without it.  The workgroups of a split launch wait for each
+ * other with BOUNDED spins; if one expires (a peer held back by another stream / process) the launch raises a device
+ * flag and a second, self-contained launch behind it on the same stream — a no-op when the flag is clean — recomputes
+ * every vector: rc 0 always means oracle-exact codes.  ua2_rvq_fallbacks counts how often that happened (health counter;
+ * synchronous copy from the device).  Env UA2_RVQ_SPIN_LIMIT overrides the spin bound (tests force the path with 0). */
 int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C, int32_t D,
                    int32_t* codes, float* quantized, void* workspace, size_t workspace_bytes, void* stream);
 size_t ua2_rvq_workspace_bytes(int64_t N, int32_t L);
+int ua2_rvq_fallbacks(uint32_t* out);
 /* Lookup + sum over levels (core_vq.py:378-384; AudioDiffusion1D.py:577-583 get_output_from_indices). */
 int ua2_rvq_decode(const int32_t* codes, const float* emb, int64_t N, int32_t L, int32_t C, int32_t D, float* out,
                    void* stream);

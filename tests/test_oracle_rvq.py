@@ -30,3 +30,24 @@ def test_rvq_oracle_matches_reference_codes(golden_dir, name):
     ref_dec = np.transpose(d[f"{name}_decoded"], (0, 2, 1)).reshape(-1, c["D"])
     np.testing.assert_allclose(dec, ref_dec, rtol=0, atol=1e-6)
     np.testing.assert_array_equal(q[same], dec[same])       # encode's quantised sum == lookup of its own codes
+
+
+@pytest.mark.parametrize("name", ["acoustic", "semantic"])
+def test_rvq_oracle_vs_reference_at_real_codebook_sizes(golden_dir, name):
+    """the live codec's codebook sizes (6 x 8192 x 32, 8 x 4096 x 64), 2048 vectors, codes from the
+    reference's vendored core_vq (cdist = GEMM expansion).  Seeds were NOT selected: rows where the expansion's arg-min
+    differs from the direct form's are an exact recorded list (tests/golden/make_golden_rvq_real.py); every other row must
+    be equal on every level."""
+    from make_golden_rvq_real import REAL_CASES, make_real_inputs
+    d = np.load(os.path.join(golden_dir, "rvq_real.npz"))
+    c = REAL_CASES[name]
+    x, emb = make_real_inputs(c)
+    codes, q = rvq_oracle.rvq_encode(x.numpy(), emb.numpy())
+    ref = d[f"{name}_codes"].astype(np.int32)
+    listed = d[f"{name}_mismatch"]
+    bad = np.nonzero((codes != ref).any(1))[0]
+    assert bad.tolist() == listed[:, 0].tolist(), "rows where cdist-argmin != direct-form argmin must be exactly the recorded ones"
+    for r, l, a, b in listed:
+        assert ref[r, l] == a and codes[r, l] == b and (codes[r, :l] == ref[r, :l]).all()
+    assert (d[f"{name}_mismatch_relgap"] < 1e-5).all(), "a recorded mismatch must be an fp32 near-tie, not a rule difference"
+    print(f"rvq real-size parity [{name}]: {len(listed)} near-tie rows of {c['N']} ({c['N'] * c['L']} searches)")

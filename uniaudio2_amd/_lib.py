@@ -101,6 +101,7 @@ _EXPORTS = {
     "ua2_avgpool1d": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, C.c_size_t, vp]),
     "ua2_rvq_workspace_bytes": (C.c_size_t, [i64, i32]),
+    "ua2_rvq_fallbacks": (C.c_int, [vp]),
     "ua2_rvq_decode": (C.c_int, [vp, vp, i64, i32, i32, i32, vp, vp]),
     "ua2_ew_fma": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp]),
     "ua2_ew_act": (C.c_int, [vp, vp, i64, i32, vp]),

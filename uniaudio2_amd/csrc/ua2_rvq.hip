@@ -37,6 +37,9 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// number of split-codebook launches whose bounded spin expired and that were redone by the fall-through launch (ua2_rvq_fallbacks)
+__device__ unsigned g_rvq_fallbacks = 0;
+
 __device__ __forceinline__ void argmin_pair(float& v, int& i, float ov, int oi) {
   if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
@@ -45,7 +48,14 @@ template <int kVB>
 __global__ __launch_bounds__(kThreads) void rvq_encode_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                               const float* __restrict__ embT, int64_t N, int L, int C,
                                                               int D, int32_t* __restrict__ codes,
-                                                              float* __restrict__ quantized) {
+                                                              float* __restrict__ quantized, const unsigned* gate) {
+  // `gate` (optional): the error flag of a split-codebook launch issued just before on the same stream.  Clean (0xffffffff):
+  // nothing to do.  Tripped: the split launch gave up on a peer (bounded spin) and its codes are not to be trusted — this
+  // launch recomputes every vector with the self-contained scan, so the caller never sees rc 0 with wrong codes.
+  if (gate) {
+    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xffffffffu) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_rvq_fallbacks, 1u);
+  }
   extern __shared__ float sm[];
   float* res = sm;                 // [kVB][D]
   float* qs = res + kVB * D;       // [kVB][D]
@@ -122,7 +132,8 @@ template <int kVB>
 __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                     const float* __restrict__ embT, int64_t N, int L, int C, int D,
                                                                     int32_t* __restrict__ codes, float* __restrict__ quantized,
-                                                                    unsigned long long* keys, unsigned* counters, unsigned* err) {
+                                                                    unsigned long long* keys, unsigned* counters, unsigned* err,
+                                                                    const int spin_limit) {
   extern __shared__ float sm[];
   float* res = sm;                 // [kVB][D]
   float* qs = res + kVB * D;       // [kVB][D]
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float*
   const int64_t n0 = (int64_t)grp * kVB;
   const int nv = (int)min((int64_t)kVB, N - n0);
   const int c_lo = (int)((int64_t)C * cs / S), c_hi = (int)((int64_t)C * (cs + 1) / S);
+  if (spin_limit <= 0 && tid == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // test hook: a bound of 0 = "gave up"
   for (int idx = tid; idx < kVB * D; idx += kThreads) {
     const int v = idx / D, k = idx - v * D;
     res[idx] = (v < nv) ? x[(n0 + v) * D + k] : 0.f;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void rvq_encode_split_kernel(const float*
       int spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(S - 1)) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     __syncthreads();
@@ -220,7 +232,8 @@ template <int kVB, int kD>
 __global__ __launch_bounds__(kThreads, (kD <= 32 ? 4 : 2)) void rvq_encode_split1_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                      const float* __restrict__ embT, int64_t N, int L, int C,
                                                                      int32_t* __restrict__ codes, float* __restrict__ quantized,
-                                                                     unsigned long long* keys, unsigned* counters, unsigned* err) {
+                                                                     unsigned long long* keys, unsigned* counters, unsigned* err,
+                                                                     const int spin_limit) {
   __shared__ float res[kVB * kD], qs[kVB * kD], dist[kVB * kThreads];
   __shared__ int best_i[kVB];
   __shared__ unsigned long long skeys[kThreads];
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(kThreads, (kD <= 32 ? 4 : 2)) void rvq_encode_split
   const int64_t n0 = (int64_t)grp * kVB;
   const int nv = (int)min((int64_t)kVB, N - n0);
   const int c = cs * kThreads + tid;                       // this thread's codeword (C == S * 256)
+  if (spin_limit <= 0 && tid == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // test hook: a bound of 0 = "gave up"
   float e_cur[kD], e_next[kD];
 #pragma unroll
   for (int k = 0; k < kD; ++k) e_cur[k] = embT[(size_t)k * C + c];      // level 0, all k in flight at once
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(kThreads, (kD <= 32 ? 4 : 2)) void rvq_encode_split
       int spins = 0;
       while ((mine = __hip_atomic_load(lkeys + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kKeyInit) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     skeys[tid] = mine;
@@ -350,8 +364,24 @@ extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* emb
                               int32_t D, int32_t* codes, float* quantized, void* workspace, size_t workspace_bytes, void* stream) {
   UA2_CHECK(x && emb && embT && codes && N > 0 && L > 0 && C > 0 && D > 0 && D <= 1024, "ua2_rvq_encode: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  // the self-contained scan; with `gate` = a split launch's error flag it is that launch's fall-through (a no-op when clean)
+  auto launch_plain = [&](const unsigned* gate) -> int {
+    int vb = 8;
+    while (vb > 1 && (N + vb - 1) / vb < 256) vb = vb == 8 ? 2 : 1;
+    const size_t smem = (size_t)(2 * vb * D + 4 * vb) * sizeof(float) + (size_t)(4 * vb + vb) * sizeof(int);
+    UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
+    const int blocks = (int)((N + vb - 1) / vb);
+    if (vb == 8) hipLaunchKernelGGL(rvq_encode_kernel<8>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized, gate);
+    else if (vb == 2) hipLaunchKernelGGL(rvq_encode_kernel<2>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized, gate);
+    else hipLaunchKernelGGL(rvq_encode_kernel<1>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized, gate);
+    UA2_LAUNCH_CHECK();
+    return 0;
+  };
   int groups = 0, S = 1;
   rvq_split_plan(N, C, &groups, &S);
+  // bounded spins of the split kernels; UA2_RVQ_SPIN_LIMIT (read per call) lets a test force the time-out path
+  int spin1 = 1 << 20, spin2 = 1 << 22;
+  if (const char* e = getenv("UA2_RVQ_SPIN_LIMIT")) spin1 = spin2 = std::max(0, atoi(e));
   static const bool no_split = getenv("UA2_RVQ_NO_SPLIT") != nullptr;      // A/B hook
   if (S > 1 && workspace && !no_split) {
     const size_t need = ua2_rvq_workspace_bytes(N, L);
@@ -375,11 +405,11 @@ extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* emb
     const int64_t room1 = (int64_t)cus * (D == 32 ? occ32 : occ64) / 2;      // half of the device: other streams may hold the rest
     if ((D == 32 || D == 64) && C % kThreads == 0 && s1 * kSplitVB <= kThreads && (int64_t)groups * s1 <= room1) {
       if (D == 32) hipLaunchKernelGGL((rvq_encode_split1_kernel<kSplitVB, 32>), dim3(groups, s1), dim3(kThreads), 0, s, x, emb, embT, N, L, C,
-                                      codes, quantized, keys, counters, err);
+                                      codes, quantized, keys, counters, err, spin1);
       else hipLaunchKernelGGL((rvq_encode_split1_kernel<kSplitVB, 64>), dim3(groups, s1), dim3(kThreads), 0, s, x, emb, embT, N, L, C, codes,
-                              quantized, keys, counters, err);
+                              quantized, keys, counters, err, spin1);
       UA2_LAUNCH_CHECK();
-      return 0;
+      return launch_plain(err);   // fall-through: redoes everything if a spin expired, returns at once otherwise
     }
     const size_t smem = (size_t)(2 * kSplitVB * D + 4 * kSplitVB) * sizeof(float) + (size_t)(4 * kSplitVB + kSplitVB) * sizeof(int);
     UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
@@ -387,19 +417,16 @@ extern "C" int ua2_rvq_encode(const float* x, const float* emb, const float* emb
     UA2_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occg, rvq_encode_split_kernel<kSplitVB>, kThreads, smem));
     while (S > 1 && (int64_t)groups * S > (int64_t)cus * occg / 2) S /= 2;
     hipLaunchKernelGGL(rvq_encode_split_kernel<kSplitVB>, dim3(groups, S), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes,
-                       quantized, keys, counters, err);
+                       quantized, keys, counters, err, spin2);
     UA2_LAUNCH_CHECK();
-    return 0;
+    return launch_plain(err);
   }
-  int vb = 8;
-  while (vb > 1 && (N + vb - 1) / vb < 256) vb = vb == 8 ? 2 : 1;
-  const size_t smem = (size_t)(2 * vb * D + 4 * vb) * sizeof(float) + (size_t)(4 * vb + vb) * sizeof(int);
-  UA2_CHECK(smem <= 64 * 1024, "ua2_rvq_encode: D=%d too large", D);
-  const int blocks = (int)((N + vb - 1) / vb);
-  if (vb == 8) hipLaunchKernelGGL(rvq_encode_kernel<8>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
-  else if (vb == 2) hipLaunchKernelGGL(rvq_encode_kernel<2>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
-  else hipLaunchKernelGGL(rvq_encode_kernel<1>, dim3(blocks), dim3(kThreads), smem, s, x, emb, embT, N, L, C, D, codes, quantized);
-  UA2_LAUNCH_CHECK();
+  return launch_plain(nullptr);
+}
+
+extern "C" int ua2_rvq_fallbacks(uint32_t* out) {
+  UA2_CHECK(out != nullptr, "ua2_rvq_fallbacks: NULL argument");
+  UA2_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rvq_fallbacks), sizeof(unsigned)));   // synchronous: a test / health-check call
   return 0;
 }
 
