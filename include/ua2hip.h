@@ -46,7 +46,7 @@ enum ua2_prologue {
                        squares of the fp32 x (x_ssq) — see y_norm_w below — so that no launch stands between the
                        producer and this GEMM, whatever the row count; the row scale is applied to the fp32 sums in
                        the epilogue.  Mathematically RMSNorm(x) W^T; numerically the bf16 rounding happens before
-                       the row scale instead of after it (same relative error).  K % 16 == 0. */
+                       the row scale instead of after it (same relative error).  K % 32 == 0. */
 };
 
 /* What happens to the GEMM result (the ops the reference runs right after the Linear). */
@@ -168,7 +168,7 @@ typedef struct ua2_linear_args {
      y the launch writes, for the UA2_PRO_SCALED consumer that follows, RNE_bf16(y[m][n] * y_norm_w[n]) into y_h (row-major
      [M, ldh] bf16) and / or y_packed (fragment order, N % 32 == 0), and y_ssq[m][n / 16] = the sum of y[m][n]^2 over the
      16-column tile, added in a fixed butterfly order (xor 1, 2, 4, 8) — the same tree in every kernel, so a row's
-     statistic does not depend on the row count.  N % 16 == 0.
+     statistic does not depend on the row count.  N % 32 == 0 (the launcher enforces it: whole bf16 MFMA chunks of the consumer).
      Consumer side — UA2_PRO_SCALED: x_h (M <= the decode kernel's row tile) or x_packed, and x_ssq [M, K / 16]; eps as
      for UA2_PRO_NORM.  rstd[m] = rsqrt(sum_j x_ssq[m][j] / K + eps), j summed as 16 interleaved chains + butterfly. */
   const float* y_norm_w;

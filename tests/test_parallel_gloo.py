@@ -133,3 +133,39 @@ def test_utterance_seeds_are_distinct_and_sharding_independent():
     from uniaudio2_amd.parallel import utterance_seed
     keys = {utterance_seed(888, i) for i in range(512)} | {utterance_seed(889, i) for i in range(512)}
     assert len(keys) == 1024 and all(0 <= k < 2 ** 64 for k in keys)
+
+
+def _worker_fatal(rank, world, port, n, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uniaudio2_amd.parallel import run_sharded, run_sharded_batched
+
+    def gen(i):
+        if i == 1:                                             # lands on exactly one rank
+            raise ValueError("ua2_linear: status -3 (a library error, not an utterance-level failure)")
+        return fake_generate(i)
+
+    got = []
+    for runner in (lambda: run_sharded(list(range(n)), [1] * n, gen),
+                   lambda: run_sharded_batched(list(range(n)), [1] * n, lambda idx: [gen(i) for i in idx], batch_size=2)):
+        try:
+            runner()
+            got.append("returned")
+        except RuntimeError as e:
+            got.append(str(e))
+    ret[rank] = got
+    dist.destroy_process_group()
+
+
+def test_fatal_error_on_one_rank_raises_on_every_rank_world2():
+    """a non-utterance exception on one rank must not leave the peers blocked in the all-gather — the rank enters
+    the collective with a fatal flag and every rank raises after it (the failing rank chains the original exception)."""
+    n, world = 6, 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_fatal, args=(world, 29597, n, ret), nprocs=world, join=True)
+        for r in range(world):
+            assert len(ret[r]) == 2
+            for msg in ret[r]:
+                assert "aborted" in msg and "status -3" in msg and "rank" in msg, ret[r]

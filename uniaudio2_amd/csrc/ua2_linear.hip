@@ -71,6 +71,10 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
               "ua2_linear: UA2_PRO_SCALED needs UA2_BF16, K %% 32 == 0, K <= 4096, x_ssq and x_h (ldh %% 8 == 0) or x_packed");
     UA2_CHECK(a.epilogue == UA2_EPI_QKV_ROPE || a.epilogue == UA2_EPI_SWIGLU || a.epilogue == UA2_EPI_STORE,
               "ua2_linear: UA2_PRO_SCALED serves the QKV_ROPE, SWIGLU and STORE epilogues");
+    // The tiled kernel's staged no-rotation head-size-64 q|k|v epilogue (the DiT's) writes the un-scaled sums: no caller
+    // pairs it with the scaled hand-over, and the ABI refuses the pair instead of returning un-normalised q / k / v.
+    UA2_CHECK(a.epilogue != UA2_EPI_QKV_ROPE || a.rope_mode != UA2_ROPE_NONE,
+              "ua2_linear: UA2_PRO_SCALED with a QKV_ROPE epilogue needs a rotation mode (UA2_ROPE_NONE is served by the NORM / CAST prologues)");
   }
   if (a.x_packed) {   // operand handed over in fragment order by its producer: only the many-row kernels read it
     UA2_CHECK((a.prologue == UA2_PRO_CAST || a.prologue == UA2_PRO_SCALED) && g_force_general != 2,

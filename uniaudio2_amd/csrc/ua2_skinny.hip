@@ -281,6 +281,9 @@ int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipS
   if (a.K % 32) return 1;
   const int nchunks = a.K / 32;
   if (nchunks % geo.waves) return 1;
+  // the packed operand is addressed through one buffer resource (32-bit size / offsets): past 4 GiB the loads would wrap
+  // and return zeros — leave such a problem to the tiled kernel
+  if ((uint64_t)ua2_ceil_div(a.M, 16) * (uint64_t)nchunks * 1024ull >= (1ull << 32)) return 1;
   const int ch = nchunks / geo.waves;
   const int nm = a.epilogue == UA2_EPI_SWIGLU ? 2 : 1;
   Variant v = pick_variant(a, geo.waves, ch, nm);

@@ -5,7 +5,8 @@ they are independent, so each rank keeps a full weight replica and its own KV po
 utterances `i % world == rank` of a longest-first ordering, and the only exchange of the path is one
 all-gather of the output token tensors at the end of the shard (RCCL over xGMI: `torch.distributed`
 backend "nccl" on ROCm; "gloo" in the CPU tests).  Payload <= 2 x 8 x 500 x 4 B = 32 KB per
-utterance: latency-bound, one fixed-shape padded int32 tensor + a lengths tensor, no all-reduce.
+utterance: latency-bound, ONE fixed-shape padded int32 tensor (lengths, failure messages and a per-rank fatal flag ride in
+its header words), no all-reduce.
 """
 from typing import Dict, List, Sequence, Tuple
 
@@ -51,54 +52,95 @@ def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:
     return [order[i] for i in range(rank, len(order), world)]
 
 
-def pack_local(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_local_max: int, device, n_cb: int = 8):
-    """results: global index -> (reason (8,T_r), semantic (8,T_s)) int32.  Fixed-shape buffers for the all-gather."""
-    tok = torch.zeros(n_local_max, 2, n_cb, MAX_FRAMES, dtype=torch.int32, device=device)
-    meta = torch.full((n_local_max, 3), -1, dtype=torch.int32, device=device)      # (global index, T_r, T_s)
-    msg = torch.zeros(n_local_max, MSG_BYTES, dtype=torch.uint8, device=device)
+HDR = 4 + MSG_BYTES // 4  # int32 header words per slot: (global index, T_r, T_s, reserved) + the message bytes
+SLOT_WORDS = HDR + 2 * 8 * MAX_FRAMES
+
+
+def _msg_words(message: str) -> torch.Tensor:
+    raw = message.encode("utf-8", "replace")[:MSG_BYTES]
+    buf = torch.zeros(MSG_BYTES, dtype=torch.uint8)
+    buf[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    return buf.view(torch.int32)
+
+
+def _msg_text(words: torch.Tensor) -> str:
+    return bytes(words.contiguous().view(torch.uint8).tolist()).rstrip(b"\0").decode("utf-8", "replace")
+
+
+def pack_local(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_local_max: int, device, n_cb: int = 8, fatal: str = ""):
+    """results: global index -> (reason (8,T_r), semantic (8,T_s)) int32.  ONE fixed-shape int32 buffer for the all-gather
+    (north_star: a single all-gather of the token tensors): row = [global index, T_r, T_s, 0, message (96 B), tokens
+    (2, 8, 500)]; one extra row per rank carries that rank's fatal-error flag + message.  Built on the host and moved with
+    one copy (no per-utterance host->device traffic)."""
+    assert n_cb == 8
+    buf = torch.zeros(n_local_max + 1, SLOT_WORDS, dtype=torch.int32)
+    buf[:, 0] = -1
+    toks = [t for res in results.values() if not isinstance(res, Failed) for t in res]
+    if toks and any(t.is_cuda for t in toks):
+        torch.cuda.current_stream().synchronize()         # results come back to the host once, after the shard is done
     for slot, (gi, res) in enumerate(sorted(results.items(), key=lambda kv: kv[0])):
         if not isinstance(res, Failed) and max(res[0].shape[1], res[1].shape[1]) > MAX_FRAMES:
             # never raise between the ranks' collectives (the peers would wait forever): an over-long result is a failed slot
             res = Failed(f"result longer than MAX_FRAMES={MAX_FRAMES}: T_r={res[0].shape[1]} T_s={res[1].shape[1]}")
+        row = buf[slot]
         if isinstance(res, Failed):
-            meta[slot] = torch.tensor([gi, -1, -1], dtype=torch.int32)
-            raw = res.message.encode("utf-8", "replace")[:MSG_BYTES]
-            msg[slot, :len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+            row[0], row[1], row[2] = gi, -1, -1
+            row[4:HDR] = _msg_words(res.message)
             continue
         r, s = res
-        tok[slot, 0, :, :r.shape[1]] = r.to(device=device, dtype=torch.int32)
-        tok[slot, 1, :, :s.shape[1]] = s.to(device=device, dtype=torch.int32)
-        meta[slot] = torch.tensor([gi, r.shape[1], s.shape[1]], dtype=torch.int32)
-    return tok, meta, msg
+        row[0], row[1], row[2] = gi, r.shape[1], s.shape[1]
+        tok = row[HDR:].view(2, n_cb, MAX_FRAMES)
+        tok[0, :, :r.shape[1]] = r.to(device="cpu", dtype=torch.int32)
+        tok[1, :, :s.shape[1]] = s.to(device="cpu", dtype=torch.int32)
+    if fatal:
+        buf[n_local_max, 1] = 1
+        buf[n_local_max, 4:HDR] = _msg_words(fatal)
+    return buf.to(device)
 
 
-def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_total: int, device=None):
-    """All ranks end up with every utterance's (reason, semantic) tensors, keyed by global index."""
+def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_total: int, device=None, fatal: str = ""):
+    """All ranks end up with every utterance's (reason, semantic) tensors, keyed by global index.  `fatal`: this rank hit a
+    non-utterance error (device fault, ua2_* status, a bug) while working on its shard — it still enters the collective (the
+    peers would otherwise wait in it until the backend's time-out) and EVERY rank raises after it."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if fatal:
+            raise RuntimeError(fatal)
         return dict(results)
     world = dist.get_world_size()
     n_local_max = (n_total + world - 1) // world
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    tok, meta, msg = pack_local(results, n_local_max, device)
-    toks = [torch.empty_like(tok) for _ in range(world)]
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    msgs = [torch.empty_like(msg) for _ in range(world)]
-    dist.all_gather(toks, tok)          # the path's only collective (+ its two small side-cars)
-    dist.all_gather(metas, meta)
-    dist.all_gather(msgs, msg)
+    buf = pack_local(results, n_local_max, device, fatal=fatal)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)          # the path's only collective
     out = {}
-    for t, m, g in zip(toks, metas, msgs):
-        m = m.cpu()
+    fatals = []
+    for rk, b in enumerate(bufs):
+        hdr = b[:, :HDR].cpu()
+        if int(hdr[n_local_max, 1]) == 1:
+            fatals.append(f"rank {rk}: {_msg_text(hdr[n_local_max, 4:HDR])}")
         for slot in range(n_local_max):
-            gi, tr, ts = (int(v) for v in m[slot])
+            gi, tr, ts = (int(v) for v in hdr[slot, :3])
             if gi >= 0:
                 if tr < 0:
-                    raw = bytes(g[slot].cpu().tolist()).rstrip(b"\0")
-                    out[gi] = Failed(raw.decode("utf-8", "replace") or "generation failed on its rank")
+                    out[gi] = Failed(_msg_text(hdr[slot, 4:HDR]) or "generation failed on its rank")
                 else:
-                    out[gi] = (t[slot, 0, :, :tr].clone(), t[slot, 1, :, :ts].clone())
+                    tok = b[slot, HDR:].view(2, 8, MAX_FRAMES)
+                    out[gi] = (tok[0, :, :tr].clone(), tok[1, :, :ts].clone())
+    if fatals:
+        raise RuntimeError("sharded generation aborted — " + "; ".join(fatals))
     return out
+
+
+def _shard_loop(body):
+    """Runs `body()` (this rank's shard); a non-utterance exception is carried INTO the gather instead of past it."""
+    try:
+        body()
+        return "", None
+    except GenerationFailed:
+        raise
+    except Exception as e:                               # noqa: BLE001 — re-raised on every rank after the collective
+        return f"{type(e).__name__}: {e}"[:MSG_BYTES], e
 
 
 def run_sharded(items: Sequence, lengths: Sequence[int], generate_fn) -> Dict[int, Tuple[torch.Tensor, torch.Tensor]]:
@@ -106,12 +148,23 @@ def run_sharded(items: Sequence, lengths: Sequence[int], generate_fn) -> Dict[in
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     local = {}
-    for i in shard_indices(lengths, world, rank):
-        try:
-            local[i] = generate_fn(items[i])
-        except GenerationFailed as e:                    # e.g. PhaseSplitter.result: no frames of a phase were produced
-            local[i] = Failed(f"{type(e).__name__}: {e}")
-    return gather_results(local, len(items))
+
+    def body():
+        for i in shard_indices(lengths, world, rank):
+            try:
+                local[i] = generate_fn(items[i])
+            except GenerationFailed as e:                # e.g. PhaseSplitter.result: no frames of a phase were produced
+                local[i] = Failed(f"{type(e).__name__}: {e}")
+
+    fatal, exc = _shard_loop(body)
+    if exc is not None and world == 1:
+        raise exc
+    try:
+        return gather_results(local, len(items), fatal=fatal)
+    except RuntimeError as e:
+        if exc is not None:
+            raise e from exc
+        raise
 
 
 def run_sharded_batched(items: Sequence, lengths: Sequence[int], generate_batch_fn, batch_size: int):
@@ -121,12 +174,23 @@ def run_sharded_batched(items: Sequence, lengths: Sequence[int], generate_batch_
     rank = dist.get_rank() if world > 1 else 0
     mine = list(shard_indices(lengths, world, rank))
     local = {}
-    for s0 in range(0, len(mine), max(1, batch_size)):
-        chunk = mine[s0:s0 + max(1, batch_size)]
-        try:
-            for i, res in zip(chunk, generate_batch_fn([items[i] for i in chunk])):
-                local[i] = res
-        except GenerationFailed as e:
-            for i in chunk:
-                local.setdefault(i, Failed(f"{type(e).__name__}: {e}"))
-    return gather_results(local, len(items))
+
+    def body():
+        for s0 in range(0, len(mine), max(1, batch_size)):
+            chunk = mine[s0:s0 + max(1, batch_size)]
+            try:
+                for i, res in zip(chunk, generate_batch_fn([items[i] for i in chunk])):
+                    local[i] = res
+            except GenerationFailed as e:
+                for i in chunk:
+                    local.setdefault(i, Failed(f"{type(e).__name__}: {e}"))
+
+    fatal, exc = _shard_loop(body)
+    if exc is not None and world == 1:
+        raise exc
+    try:
+        return gather_results(local, len(items), fatal=fatal)
+    except RuntimeError as e:
+        if exc is not None:
+            raise e from exc
+        raise
