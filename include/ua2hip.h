@@ -85,7 +85,8 @@ enum ua2_rope_mode {
 const char* ua2_last_error(void);
 int ua2_version(void);
 /* sizeof() of the ABI structs as this library was compiled, for a binding to check its own layout against:
- * which = 0 ua2_kv_geom, 1 ua2_linear_args, 2 ua2_attn_args, 3 ua2_conv1d_args, 4 ua2_gpt_desc, 5 ua2_stage3_desc; else 0. */
+ * which = 0 ua2_kv_geom, 1 ua2_linear_args, 2 ua2_attn_args, 3 ua2_conv1d_args, 4 ua2_gpt_desc, 5 ua2_stage3_desc,
+ * 6 ua2_convtc_args; else 0. */
 size_t ua2_struct_size(int which);
 
 /* Number of elements (of `dtype`) in the packed form of an [N,K] Linear weight. */
@@ -348,6 +349,53 @@ typedef struct ua2_conv1d_args {
 } ua2_conv1d_args;
 
 int ua2_conv1d(const ua2_conv1d_args* a, void* stream);
+/* ---- codec decode side: convolutions on "time-major split planes" (round 4) --------------------------------------
+ * Between the layers of the waveform DECODER (scalar24k.py:403-407: ScalarModel.decode = Conv1d -> N x ResDecoderBlock
+ * [ConvTranspose1d up-sampler -> 5 dilated ResidualUnits, :143-151] -> PostProcessor -> Conv1d) activations travel as two
+ * bf16 planes hi = RNE(x), lo = RNE(x - hi) (16 significant bits, the same 4 bytes per element as fp32), each laid out
+ * [B][T][C] — time-major, channels contiguous — instead of fp32 [B][C][T].  The layout is what the bf16 x 3 matrix-pipe
+ * form consumes (an MFMA B fragment = 8 consecutive channels of one time step), so a layer's input window goes from L2
+ * to LDS by LDS-DMA (global_load_lds, no register staging, no conversion, no transposing LDS writes) and the epilogue of
+ * every layer emits the next layer's operand.  C must be a multiple of 32 (channel groups of the MFMA K dimension).
+ * Arithmetic per output: the ua2_conv1d precision-1 sum (chunks = (channel group, tap) ascending; per chunk Wl*Xh, Wh*Xl,
+ * Wh*Xh), bias added once, PReLU with single roundings, residual x = hi + lo (exact in fp32) added last, then the hi / lo
+ * split.  Two kernels with identical bits (`variant`): 1 = plain (any K <= 32, reference of the bit-identity test),
+ * 2 = software-pipelined LDS-DMA form (K in {1, 2, 7}), 0 = automatic. */
+typedef struct ua2_convtc_args {
+  int32_t B, Cin, Cout, Tin, Tout;
+  int32_t K, dilation, pad_left;   /* stride is 1 on the decode side */
+  int32_t in_repeat;               /* input row of window position p is p / in_repeat (repeat-upsampling, scalar24k.py:136-140) */
+  int32_t out_phases, out_trim_left; /* transposed conv as out_phases phase filters: packed row n = phase * Cout + co lands at
+                                      y[t * out_phases + phase - out_trim_left][co] (see ua2_conv1d) */
+  int32_t post_act;                /* UA2_ACT_NONE or UA2_ACT_PRELU */
+  int32_t variant;                 /* 0 auto, 1 plain, 2 pipelined (error if the shape is outside its instantiations) */
+  const uint16_t* x_hi;            /* [B, Tin, Cin] bf16 */
+  const uint16_t* x_lo;
+  const void* w;                   /* ops.pack_conv_weight_x3 of the [rows, Cin, K] filter: hi ... */
+  const void* w_lo;                /* ... and lo halves */
+  const float* bias;               /* [Cout] or NULL */
+  const float* post_alpha;         /* PReLU slope(s) */
+  int32_t post_alpha_n;            /* 1 or Cout */
+  /* fused residual unit (scalar24k.py:143-151): y = x + PReLU(alpha2, W2 h + bias2), h = post_act(conv(x) + bias) kept on
+     chip; needs Cin == Cout in {32, 64, 128}, out_phases == 1, in_repeat == 1, Tin == Tout.  The residual is the input. */
+  const void* w2;
+  const void* w2_lo;
+  const float* bias2;
+  const float* alpha2;             /* 1 value; NULL = slope 0 */
+  /* separate residual (the un-fused second conv of a wide residual unit): added after the activation */
+  const uint16_t* res_hi;          /* [B, Tout, Cout] bf16 or NULL */
+  const uint16_t* res_lo;
+  /* output: planes, or fp32 [B, Cout, Tout] (the waveform: last layer) — exactly one of (y_hi & y_lo) / y_f32 */
+  uint16_t* y_hi;
+  uint16_t* y_lo;
+  float* y_f32;
+} ua2_convtc_args;
+
+int ua2_conv1d_tc(const ua2_convtc_args* a, void* stream);
+/* fp32 [B, C, T] -> planes [B, T, C] (hi, lo) and back (x = hi + lo, exact).  C % 2 == 0. */
+int ua2_tc_pack(const float* x, uint16_t* hi, uint16_t* lo, int32_t B, int32_t C, int32_t T, void* stream);
+int ua2_tc_unpack(const uint16_t* hi, const uint16_t* lo, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+
 /* torch.nn.AvgPool1d(kernel_size=k) over the last axis of [rows, Tin] (scalar24k.py:118). */
 int ua2_avgpool1d(const float* x, float* y, int64_t rows, int32_t Tin, int32_t k, void* stream);
 

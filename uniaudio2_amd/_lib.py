@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libua2hip.so")
+LIB_PATH = os.environ.get("UA2_LIB", os.path.join(_HERE, "libua2hip.so"))   # UA2_LIB: timing experiments load an instrumented build (tools/ubench)
 
 UA2_F32, UA2_BF16 = 0, 1
 PRO_CAST, PRO_NORM, PRO_LOCAL_ATTN = 0, 1, 3
@@ -55,6 +55,14 @@ class Conv1dArgs(C.Structure):
                 ("dilation", i32), ("pad_left", i32), ("in_repeat", i32), ("out_phases", i32), ("out_trim_left", i32),
                 ("pre_act", i32), ("post_act", i32), ("x", vp), ("w", vp), ("bias", vp), ("pre_alpha", vp),
                 ("post_alpha", vp), ("post_alpha_n", i32), ("residual", vp), ("y", vp), ("w_lo", vp), ("precision", i32), ("w2", vp), ("w2_lo", vp), ("bias2", vp), ("alpha2", vp)]
+
+
+class ConvTcArgs(C.Structure):
+    _fields_ = [("B", i32), ("Cin", i32), ("Cout", i32), ("Tin", i32), ("Tout", i32), ("K", i32), ("dilation", i32),
+                ("pad_left", i32), ("in_repeat", i32), ("out_phases", i32), ("out_trim_left", i32), ("post_act", i32),
+                ("variant", i32), ("x_hi", vp), ("x_lo", vp), ("w", vp), ("w_lo", vp), ("bias", vp), ("post_alpha", vp),
+                ("post_alpha_n", i32), ("w2", vp), ("w2_lo", vp), ("bias2", vp), ("alpha2", vp), ("res_hi", vp), ("res_lo", vp),
+                ("y_hi", vp), ("y_lo", vp), ("y_f32", vp)]
 
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_TANH, ACT_ROUND9 = 0, 1, 2, 3, 4
@@ -98,6 +106,9 @@ _EXPORTS = {
     "ua2_rmsnorm_blend": (C.c_int, [i32, i32, vp, vp, f32, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ua2_argmax_embed": (C.c_int, [C.c_int, i32, i32, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
     "ua2_conv1d": (C.c_int, [C.POINTER(Conv1dArgs), vp]),
+    "ua2_conv1d_tc": (C.c_int, [C.POINTER(ConvTcArgs), vp]),
+    "ua2_tc_pack": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "ua2_tc_unpack": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "ua2_avgpool1d": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "ua2_rvq_encode": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, C.c_size_t, vp]),
     "ua2_rvq_workspace_bytes": (C.c_size_t, [i64, i32]),
@@ -123,7 +134,7 @@ _EXPORTS = {
 }
 
 
-ABI_STRUCTS = (KvGeom, LinearArgs, AttnArgs, Conv1dArgs, GptDesc, Stage3Desc)
+ABI_STRUCTS = (KvGeom, LinearArgs, AttnArgs, Conv1dArgs, GptDesc, Stage3Desc, ConvTcArgs)
 
 
 def exported_symbols():

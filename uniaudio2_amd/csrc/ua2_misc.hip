@@ -26,6 +26,7 @@ extern "C" size_t ua2_struct_size(int which) {
     case 3: return sizeof(ua2_conv1d_args);
     case 4: return sizeof(ua2_gpt_desc);
     case 5: return sizeof(ua2_stage3_desc);
+    case 6: return sizeof(ua2_convtc_args);
     default: return 0;
   }
 }

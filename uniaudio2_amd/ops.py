@@ -266,6 +266,92 @@ def conv1d(x, w_packed, K, Cout, *, stride=1, dilation=1, pad_left=0, Tout=None,
     return y
 
 
+class TC:
+    """Activation in the decode side's layout: two bf16 planes hi = RNE(x), lo = RNE(x - hi), each [B, T, C] (time-major,
+    channels contiguous) — include/ua2hip.h, ua2_conv1d_tc.  `planes` is one (2, B, T, C) bf16 tensor."""
+
+    def __init__(self, planes):
+        assert planes.dim() == 4 and planes.shape[0] == 2 and planes.dtype == torch.bfloat16 and planes.is_contiguous()
+        self.planes = planes
+
+    @property
+    def hi(self):
+        return self.planes[0]
+
+    @property
+    def lo(self):
+        return self.planes[1]
+
+    @property
+    def shape(self):                      # (B, C, T): what the fp32 tensor it stands for would report
+        _, B, T, Cc = self.planes.shape
+        return (B, Cc, T)
+
+    @staticmethod
+    def empty(B, Cc, T, device):
+        return TC(torch.empty(2, B, T, Cc, dtype=torch.bfloat16, device=device))
+
+
+def tc_w2_order(w2):
+    """[Cout, C, 1] filter of a fused residual unit's 1 x 1 conv -> the same filter with its input channels in the K order the
+    ua2_conv1d_tc kernels reduce in (csrc/ua2_convtc.hip, "tc_w2_order"): inside each group of 32, k' = 8 g + e holds channel
+    4 g + e (e < 4) or 16 + 4 g + (e - 4) (e >= 4).  Pack the result with pack_conv_weight_x3 and pass it as `fused2`."""
+    Cc = w2.shape[1]
+    assert Cc % 32 == 0
+    k = torch.arange(32)
+    g, e = k // 8, k % 8
+    ch = torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4))
+    perm = (torch.arange(0, Cc, 32).view(-1, 1) + ch.view(1, -1)).reshape(-1).to(w2.device)
+    return w2[:, perm].contiguous()
+
+
+def tc_pack(x):
+    """fp32 [B, C, T] -> TC (ua2_tc_pack)."""
+    B, Cc, T = x.shape
+    out = TC.empty(B, Cc, T, x.device)
+    check(lib.ua2_tc_pack(ptr(x.contiguous()), ptr(out.hi), ptr(out.lo), B, Cc, T, stream()), "ua2_tc_pack")
+    return out
+
+
+def tc_unpack(t):
+    """TC -> fp32 [B, C, T], x = hi + lo exactly (ua2_tc_unpack)."""
+    B, Cc, T = t.shape
+    y = torch.empty(B, Cc, T, dtype=torch.float32, device=t.planes.device)
+    check(lib.ua2_tc_unpack(ptr(t.hi), ptr(t.lo), ptr(y), B, Cc, T, stream()), "ua2_tc_unpack")
+    return y
+
+
+def conv1d_tc(x, w_hi, w_lo, K, Cout, *, dilation=1, pad_left=0, Tout=None, bias=None, post_act=0, post_alpha=None, in_repeat=1,
+              out_phases=1, out_trim_left=0, fused2=None, residual=None, out_f32=False, variant=0):
+    """ua2_conv1d_tc: x a TC; (w_hi, w_lo) = pack_conv_weight_x3(filter rows).  Returns a TC, or fp32 [B, Cout, Tout] with
+    out_f32 (the waveform).  fused2 = (w2_hi, w2_lo, bias2, alpha2): the 1 x 1 conv + PReLU + residual of a residual unit in
+    the same launch (residual = x), with (w2_hi, w2_lo) = pack_conv_weight_x3(tc_w2_order(W2)); residual = a TC added after the
+    activation (un-fused second conv).  variant: 0 automatic, 1 plain, 2 pipelined, 3 big-tile."""
+    from ._lib import ConvTcArgs
+    B, Cin, Tin = x.shape
+    a = ConvTcArgs()
+    a.B, a.Cin, a.Cout, a.Tin, a.Tout = B, Cin, Cout, Tin, Tout
+    a.K, a.dilation, a.pad_left, a.in_repeat = K, dilation, pad_left, in_repeat
+    a.out_phases, a.out_trim_left, a.post_act, a.variant = out_phases, out_trim_left, post_act, variant
+    a.x_hi, a.x_lo, a.w, a.w_lo, a.bias = ptr(x.hi), ptr(x.lo), ptr(w_hi), ptr(w_lo), ptr(bias)
+    a.post_alpha = ptr(post_alpha)
+    a.post_alpha_n = post_alpha.numel() if post_alpha is not None else 0
+    if fused2 is not None:
+        a.w2, a.w2_lo, a.bias2, a.alpha2 = ptr(fused2[0]), ptr(fused2[1]), ptr(fused2[2]), ptr(fused2[3])
+    if residual is not None:
+        assert residual.shape == (B, Cout, Tout)
+        a.res_hi, a.res_lo = ptr(residual.hi), ptr(residual.lo)
+    dev = x.planes.device
+    if out_f32:
+        y = torch.empty(B, Cout, Tout, dtype=torch.float32, device=dev)
+        a.y_f32 = ptr(y)
+    else:
+        y = TC.empty(B, Cout, Tout, dev)
+        a.y_hi, a.y_lo = ptr(y.hi), ptr(y.lo)
+    check(lib.ua2_conv1d_tc(C.byref(a), stream()), "ua2_conv1d_tc")
+    return y
+
+
 def dwconv1d(x, w, *, stride=1, dilation=1, pad_left=0, Tout=None, bias=None, transposed=False):
     """Depthwise conv / transposed conv: x [B,C,Tin] fp32, w [C,K] fp32 -> [B,C,Tout] (ua2_dwconv1d)."""
     B, Cc, Tin = x.shape

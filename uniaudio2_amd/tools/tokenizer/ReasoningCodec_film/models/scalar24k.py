@@ -66,6 +66,7 @@ class _ConvOp:
         self.alpha = alpha.detach().float().contiguous() if alpha is not None else None
         if isinstance(conv, nn.ConvTranspose1d):
             self.transposed, self.stride = True, conv.stride[0]
+            self.cin = w.shape[0]
             self.cout, self.kfull = w.shape[1], w.shape[2]
             rows, self.K = ops.convtr_phase_rows(w, self.stride)
             self.w, self.w_lo = ops.pack_conv_weight_x3(rows) if fast else (ops.pack_conv_weight(rows)[0], None)
@@ -73,13 +74,37 @@ class _ConvOp:
             self.causal = conv.causal
         else:
             self.transposed, self.stride, self.dil = False, conv.stride[0], conv.dilation[0]
+            self.cin = w.shape[1]
             self.cout, self.kfull = w.shape[0], w.shape[2]
             self.K = w.shape[2]
             self.w, self.w_lo = ops.pack_conv_weight_x3(w) if fast else (ops.pack_conv_weight(w)[0], None)
             self.pad_l = conv.left_padding if conv.causal else conv.padding[0]
             self.pad_r = 0 if conv.causal else conv.padding[0]
 
+    def tc_ok(self):
+        """This op can run on time-major split planes (ua2_conv1d_tc): bf16 x 3 weights, stride 1, no input pre-activation,
+        PReLU / no activation, whole channel groups in."""
+        cin = self.cin
+        return (self.w_lo is not None and (self.transposed or self.stride == 1) and self.pre_act == ACT_NONE and
+                self.post_act in (ACT_NONE, ACT_PRELU) and cin % 32 == 0)
+
+    def run_tc(self, x, residual=None, out_f32=False, fused2=None, variant=0):
+        """x: ops.TC.  The decode side's form of __call__ (same geometry, planes in / planes or the fp32 waveform out)."""
+        T = x.shape[-1] * self.in_repeat
+        if self.transposed:
+            full = (T - 1) * self.stride + self.kfull
+            tout = full - self.stride if self.causal else full - 2 * self.trim
+            return ops.conv1d_tc(x, self.w, self.w_lo, self.K, self.cout, pad_left=self.K - 1, Tout=tout, bias=self.bias,
+                                 post_act=self.post_act, post_alpha=self.alpha, out_phases=self.stride, out_trim_left=self.trim,
+                                 residual=residual, out_f32=out_f32, variant=variant)
+        tout = (T + self.pad_l + self.pad_r - self.dil * (self.kfull - 1) - 1) // self.stride + 1
+        return ops.conv1d_tc(x, self.w, self.w_lo, self.K, self.cout, dilation=self.dil, pad_left=self.pad_l, Tout=tout,
+                             bias=self.bias, post_act=self.post_act, post_alpha=self.alpha, in_repeat=self.in_repeat,
+                             residual=residual, out_f32=out_f32, fused2=fused2, variant=variant)
+
     def __call__(self, x, residual=None):
+        if isinstance(x, ops.TC):
+            return self.run_tc(x, residual=residual)
         T = x.shape[-1] * self.in_repeat
         if self.transposed:
             full = (T - 1) * self.stride + self.kfull
@@ -136,10 +161,17 @@ class ResidualUnit(nn.Module):
         # reduction over channels closes inside the workgroup that holds them), h never leaves the chip
         c = self.conv1.out_channels
         self._fused = None
+        self._fused_tc = None
         if self._op1.w_lo is not None and self.conv1.in_channels == c and c in (32, 64, 128) and self.conv2.kernel_size[0] == 1:
             self._fused = (self._op2.w, self._op2.w_lo, self._op2.bias, self._op2.alpha)
+            # the split-plane kernels reduce the 1 x 1 conv in their own K order (ops.tc_w2_order)
+            self._fused_tc = (*ops.pack_conv_weight_x3(ops.tc_w2_order(_folded(self.conv2))), self._op2.bias, self._op2.alpha)
 
     def run(self, x):
+        if isinstance(x, ops.TC):
+            if self._fused_tc is not None:
+                return self._op1.run_tc(x, fused2=self._fused_tc)     # x read once; h and the residual never leave the chip
+            return self._op2.run_tc(self._op1.run_tc(x), residual=x)
         if self._fused is not None:
             o = self._op1
             return ops.conv1d(x, o.w, o.K, o.cout, dilation=o.dil, pad_left=o.pad_l, Tout=x.shape[-1], bias=o.bias, post_act=o.post_act,
@@ -277,8 +309,27 @@ class ScalarModel(nn.Module):
                     layer.prepare(); self._dec_ops.append(layer.run)
         finally:
             _ConvOp.default_fast = False
+        self._dec_tc = bool(fast_decode) and self._decoder_tc_ok()
         self._ready = True
         return self
+
+    def _decoder_tc_ok(self):
+        """Every decoder conv behind the first one can run on split planes (channel counts in whole groups of 32, PReLU-only
+        epilogues); the last conv writes the fp32 waveform."""
+        convs = []
+        for layer in list(self.decoder)[1:]:
+            if isinstance(layer, nn.Conv1d):
+                continue
+            if isinstance(layer, ResDecoderBlock):
+                convs.append(layer.up_conv._op)
+                for u in layer.convs:
+                    convs += [u._op1, u._op2]
+            elif isinstance(layer, PostProcessor):
+                convs.append(layer._op)
+            else:
+                return False
+        last = self._dec_ops[-1]
+        return isinstance(last, _ConvOp) and last.tc_ok() and all(c.tc_ok() and c.cout % 32 == 0 for c in convs)
 
     @torch.inference_mode()
     def encode(self, x):
@@ -296,6 +347,15 @@ class ScalarModel(nn.Module):
         if not self._ready:
             self.prepare()
         x = x.float().contiguous()
-        for op in self._dec_ops:
+        ops_ = self._dec_ops
+        x = ops_[0](x)                                                # latent (fp32 [C][T], snapped to the 1/9 grid) -> widest layer
+        if self._dec_tc:
+            # round 4: from here to the waveform the activations travel as hi / lo bf16 planes [B][T][C] (ops.TC): every layer's
+            # window goes L2 -> LDS by LDS-DMA and every epilogue writes the next layer's matrix-pipe operand
+            x = ops.tc_pack(x)
+            for op in ops_[1:-1]:
+                x = op(x)
+            return ops_[-1].run_tc(x, out_f32=True)
+        for op in ops_[1:]:
             x = op(x)
         return x
