@@ -126,6 +126,38 @@ def roofline_leg(model):
             "algorithmic_bytes_per_launch": int(per_launch_bytes)}
 
 
+def scalar_decode_work(cfg, T):
+    """Algorithmic bytes / flops of ScalarModel.decode for a (1, latent, T) input (see codec_leg): 1.80 GB and 181.5 GFLOP at the
+    placeholder widths, T = 500 — the figures rounds 2-3 measured against."""
+    by = fl = 0.0
+
+    def conv(cin, cout, k, tin, tout, res=False):
+        nonlocal by, fl
+        by += 4.0 * (cin * tin + cout * tout + (cout * tout if res else 0)) + 4.0 * cin * cout * k
+        fl += 2.0 * cout * tout * cin * k
+
+    c = cfg["init_channel"] * 2 ** len(cfg["upsample_factors"])
+    conv(cfg["latent_hidden_dim"], c, cfg["delay_kernel_size"], T, T)
+    for s_, k in zip(cfg["upsample_factors"], cfg["upsample_kernel_sizes"]):
+        taps = -(-k // s_)                                   # a transposed conv = s phase filters of ceil(k / s) taps
+        by += 4.0 * (c * T + (c // 2) * T * s_) + 4.0 * (s_ * (c // 2)) * c * taps
+        fl += 2.0 * (c // 2) * (T * s_) * c * taps
+        c //= 2
+        T *= s_
+        for _ in range(5):
+            if c <= 128:
+                by += 4.0 * 3 * c * T + 4.0 * c * c * cfg["res_kernel_size"]
+                fl += 2.0 * c * T * c * cfg["res_kernel_size"]
+            else:
+                conv(c, c, cfg["res_kernel_size"], T, T)
+                conv(c, c, 1, T, T, res=True)
+    if cfg["num_samples"] > 1:
+        conv(c, c, cfg["default_kernel_size"], T, T * cfg["num_samples"])
+        T *= cfg["num_samples"]
+    conv(c, cfg["num_bands"], cfg["default_kernel_size"], T, T)
+    return {"flop": fl, "bytes": by}
+
+
 def codec_leg(dev, cpu=False):
     """Codec side of the metric ("codec RTF"): the in-scope deterministic stage-2 sub-graph on one 20-s
     window — ScalarModel.decode of a (1, 136, 500) latent -> 480 000 samples — and the RVQ search of a
@@ -137,24 +169,25 @@ def codec_leg(dev, cpu=False):
     torch.manual_seed(1)
     sq = ScalarModel(**SCALAR_CFG).to(dev).prepare()
     lat = torch.tanh(torch.randn(1, 136, 500, device=dev))
-    # algorithmic work of one decode: every ua2_conv1d launch's 2 * B * Cout * Tout * Cin * K flops and its
-    # activation + weight bytes (counted by wrapping the op for one call)
-    work = {"flop": 0.0, "bytes": 0.0, "launches": 0}
-    real_conv1d = ops.conv1d
-
-    def counting_conv1d(x, w_packed, K, Cout, **kw):
-        y = real_conv1d(x, w_packed, K, Cout, **kw)
-        B_, Cin, Tin = x.shape
-        work["flop"] += 2.0 * B_ * Cout * y.shape[-1] * Cin * K
-        work["bytes"] += 4.0 * (x.numel() + y.numel() + (y.numel() if kw.get("residual") is not None else 0)) + 4.0 * w_packed.numel()
-        work["launches"] += 1
-        return y
-
-    ops.conv1d = counting_conv1d
+    # algorithmic work of one decode, a property of the LAYER STACK (not of how this round launches it): per convolution
+    # of the reference's decode chain its input + output (+ residual) tensors and its filter once, fp32, and
+    # 2 * Cout * Tout * Cin * taps flops — the accounting rounds 2-3 obtained by counting their ua2_conv1d launches (a residual
+    # unit of <= 128 channels was one launch there: x, y and the residual read, the k7 filter; its 1 x 1 conv is not counted)
+    work = scalar_decode_work(SCALAR_CFG, lat.shape[-1])
+    wav = sq.decode(lat)
+    launches = {"n": 0}
+    saved = {name: getattr(ops, name) for name in ("conv1d", "conv1d_tc", "tc_pack")}
+    for name, real in saved.items():
+        def counting(*a_, _real=real, **kw_):
+            launches["n"] += 1
+            return _real(*a_, **kw_)
+        setattr(ops, name, counting)
     try:
-        wav = sq.decode(lat)
+        sq.decode(lat)
     finally:
-        ops.conv1d = real_conv1d
+        for name, real in saved.items():
+            setattr(ops, name, real)
+    work["launches"] = launches["n"]
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -312,6 +345,22 @@ def stage2_leg(dev, steps=10):
                "reason_tokens": list(rc[0].shape), "semantic_tokens": list(mc[0].shape)}
     except Exception as e:  # noqa: BLE001 — an information leg must not take the bench line down
         enc = {"encode_post_ssl_error": repr(e)[:200]}
+    # BASELINE config 3's codec-encode half at its batch: 32 clips x 10 s = 32 segments in one call (32 x (125 x 8 +
+    # 51 x 8) RVQ searches + the strided down-samplers on (32, 1024, 1500) features), AudioDiffusion1D.py:526-550
+    try:
+        g = torch.Generator(device="cpu").manual_seed(4)
+        f = [torch.randn(32, c, t, generator=g).to(dev) for c, t in ((1024, 1500), (768, 1500), (1024, 750), (1024, 750))]
+        masks = torch.zeros(3, 32, dtype=torch.bool)
+        model.fetch_codes_from_features(*f, film_masks=masks)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            rc, mc, _ = model.fetch_codes_from_features(*f, film_masks=masks)
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t1) / 3 * 1e3
+        enc.update({"config3_encode_post_ssl_ms_per_batch32": round(ms32, 2), "config3_encode_post_ssl_clips_per_s": round(32e3 / ms32, 1)})
+    except Exception as e:  # noqa: BLE001
+        enc["config3_encode_post_ssl_error"] = repr(e)[:200]
     return {**enc, "euler_steps": steps, "window_s": 20.0, "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
             "dit_ms_per_guided_step": round(step_ms, 2), "dit_tflops": round(flop / (step_ms * 1e-3) / 1e12, 1),
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
@@ -418,7 +467,27 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
     `value` is the whole-utterance rate the GPU `value` is quoted on (33-token prompt + 74 frames), composed from the
     measured Tall prefill time and median frame time.  Bounded: ~3 frames at T1, ~20 at Tall."""
     import statistics
+    import concurrent.futures
+    import types
+    import torch.nn.functional as TF
+    from oracle import lm_oracle
     from oracle.lm_oracle import GPTShape, Stage3Oracle
+    # Decode frames are M = 1 products: on the GPU boxes' hosts torch's sgemv ran on ONE core whatever set_num_threads said
+    # (round 3: 702.7 ms/frame at T1 vs 688.4 at 16 threads while the prefill scaled 4.9x) — "Tall" was not a multi-thread
+    # number.  Same arithmetic (each output row is one fp32 dot product by the same routine), row blocks dealt to a pool of
+    # `par["threads"]` workers; many-row products (prefill) keep torch's own threading.
+    par = {"threads": 1, "pool": None}
+
+    def par_linear(x, w, bias=None):
+        n = par["threads"]
+        if n <= 1 or x.numel() != x.shape[-1] or w.shape[0] < 1024 or par["pool"] is None:
+            return TF.linear(x, w, bias)
+        blocks = w.chunk(n, 0)
+        outs = list(par["pool"].map(lambda wb: TF.linear(x, wb), blocks))
+        y = torch.cat(outs, dim=-1)
+        return y if bias is None else y + bias
+
+    lm_oracle.F = types.SimpleNamespace(linear=par_linear, scaled_dot_product_attention=TF.scaled_dot_product_attention, silu=TF.silu)
     sd = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}
     shapes = dict(backbone=GPTShape(28, 3072, 24, 8, 8192), understanding=GPTShape(3, 3072, 24, 8, 8192),
                   generation=GPTShape(2, 3072, 24, 8, 8192), decoder=GPTShape(4, 2048, 32, 8, 8192))
@@ -430,13 +499,22 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
     budget = host_cpu_budget()
     ncores = budget["usable"]                      # affinity / cgroup-limited, not os.cpu_count()
 
+    def set_threads(t):
+        """prefill: torch's intra-op threads; decode GEMVs: `t` pool workers with one torch thread each"""
+        if par["pool"] is not None:
+            par["pool"].shutdown()
+        par["threads"], par["pool"] = t, (concurrent.futures.ThreadPoolExecutor(t) if t > 1 else None)
+
     def run(threads, frames, prefill=True):
         """-> (prefill seconds or None, per-frame seconds list, (frames, 9) ids)"""
         torch.set_num_threads(threads)
+        set_threads(1)
         o.reset_caches()
         t0 = time.perf_counter()
         o.forward_prefix(tk[:, :-1], mk, pos[:, :-1])
         pre = time.perf_counter() - t0
+        torch.set_num_threads(1)
+        set_threads(threads)
         ct, cm = tk[:, -1:], mk[:, -1:]
         cur, maxp1, per, ids = torch.full((1,), L - 1, dtype=torch.long), L, [], []
         for _ in range(frames):
@@ -457,7 +535,8 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
         o.reset_caches()
         sweep = {}
         for t in cands:
-            torch.set_num_threads(t)
+            torch.set_num_threads(1)
+            set_threads(t)
             ct, cm = tk[:, -1:], mk[:, -1:]
             o.generate_frame(ct, cm, torch.tensor([L - 1]), L)                       # warm
             t0 = time.perf_counter()
@@ -466,8 +545,34 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
         best = min(sweep, key=sweep.get)
         pre_all, per_all, ids = run(best, frames_all)
         pre_1, per_1, _ = run(1, frames_t1)
+        # bf16 contract on the host: 8 free-running frames of the bf16 oracle (what tests/test_gpu_fullsize.py teacher-forces)
+        # for the id-agreement count of the bench line
+        bf16_ids = None
+        try:
+            ob = Stage3Oracle(sd, shapes, SEM_CARD, REASON_CARD, 8, mode="bf16")
+            ob.setup_caches(1)
+            torch.set_num_threads(best)
+            set_threads(1)
+            ob.forward_prefix(tk[:, :-1], mk, pos[:, :-1])
+            torch.set_num_threads(1)
+            set_threads(best)
+            ct, cm = tk[:, -1:], mk[:, -1:]
+            cur, maxp1, got = torch.full((1,), L - 1, dtype=torch.long), L, []
+            for _ in range(8):
+                smp = ob.generate_frame(ct, cm, cur, maxp1)
+                got.append(smp)
+                audio, text_tok = smp[:, 1:].long(), smp[:, 0:1].long()
+                ct = torch.cat([audio, text_tok], dim=-1).unsqueeze(1)
+                cm = torch.cat([torch.ones_like(audio).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+                cur, maxp1 = cur + 1, maxp1 + 1
+            bf16_ids = torch.stack(got)[:, 0]
+            del ob
+        except Exception as e:  # noqa: BLE001 — information only
+            bf16_ids = repr(e)[:200]
     finally:
         torch.set_num_threads(old)
+        set_threads(1)
+        lm_oracle.F = TF
     f_all, f_1 = statistics.median(per_all), statistics.median(per_1)
     whole = 8 * FRAMES / (pre_all + FRAMES * f_all)
     return {"value": round(whole, 2), "unit": "audio tokens/s", "cores": best, "kind": "port",
@@ -482,7 +587,9 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
                    "decode_audio_tokens_per_s": round(8 / f_1, 2)},
             "note": "BASELINE.md §3 measured the imported reference itself at 374 ms/frame on 8 threads of the authoring "
                     "container (21 audio tokens/s); round 1 reported 2.3 tokens/s here because it ran the port on all 128 "
-                    "threads only (over-subscribed GEMVs) and folded the 2048-slot prefill into 6 frames"}, ids[:, 0]
+                    "threads only (over-subscribed GEMVs) and folded the 2048-slot prefill into 6 frames",
+            "decode_threading": "M = 1 products are dealt to a pool of `cores` workers by row blocks (torch's own sgemv ran them on one core: "
+                                "round 3's Tall == T1); prefill uses torch's intra-op threads"}, ids[:, 0], bf16_ids
 
 
 def config3_leg(model, dev, B=32, n_text=15, n_reason=53, n_sem=128, frames=32):
@@ -656,22 +763,45 @@ def main():
     res = {"metric": "audio tokens/sec (TTS greedy)", "value": round(audio_tokens / dt, 1), "unit": "audio tokens/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "TTS --stage 1, single utterance, greedy (topk=1), bf16, B=1 per GPU: "
-                                  f"{PROMPT_LEN}-token prompt + {FRAMES} frames x (8 audio + 1 text) tokens; "
+           "config": {"workload": "TTS --stage all (BASELINE config 2), single utterance, greedy (topk=1), bf16, B=1 per GPU: "
+                                  f"{PROMPT_LEN}-token prompt + {FRAMES} frames x (8 audio + 1 text) tokens; `value` = the stage-1 "
+                                  "audio-token rate (multi_task_inference.py:486-525), stage 2 (codes -> waveform, :527-548) = "
+                                  "top-level `codec_rtf`, `stage_all_ms_per_utterance` = both; "
                                   "Llama-3.2-3B backbone + 3L/2L experts + 4L local decoder x8, V_a=12296, random init",
                       "parallelism": f"dp{world} (one utterance per GPU, RCCL all-gather of token tensors)"},
            "decode_ms_per_frame": round(ms_frame, 3), "decode_frames_per_s": round(1e3 / ms_frame, 1),
            "decode_ms_per_frame_p50": round(p50, 3), "decode_ms_per_frame_p99": round(p99, 3)}
     solo = rank == 0 and world == 1
+    if solo and not a.no_legs:
+        # the contract on which ids are IDENTICAL to the reference's (UA2_F32: the reference ships fp32, multi_task_inference.py:181-183)
+        try:
+            model.setup_caches(1, dtype=torch.float32, max_seq_length=2048, max_rows=64, log_frames=128)
+            utterance(model, tokens, mask)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                utterance(model, tokens, mask)
+            torch.cuda.synchronize()
+            res["fp32_contract_audio_tokens_per_s"] = round(8 * FRAMES * 2 / (time.perf_counter() - t0), 1)
+        except Exception as e:  # noqa: BLE001
+            res["fp32_contract_audio_tokens_per_s"] = repr(e)[:200]
+        model.setup_caches(1, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=128)
     if solo and not a.no_roofline:
         res["roofline"] = roofline_leg(model)
         # whole-frame view of the same roofline: unique weight bytes a frame must stream (bf16)
         res["frame_hbm_frac_unique_weights"] = round(8.33e9 / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if solo and not a.no_cpu_baseline:
-        cb, cpu_ids = cpu_baseline_leg(model, tokens, mask)
+        cb, cpu_ids, bf16_ids = cpu_baseline_leg(model, tokens, mask)
         res["cpu_baseline"] = cb
         n = cpu_ids.shape[0]
         res["cpu_fp32_vs_gpu_bf16_same_ids_frames"] = int((cpu_ids.int() == log[:n, 0].cpu().int()).all(-1).sum())
+        if torch.is_tensor(bf16_ids):
+            # free-running: after the first differing id the two runs see different inputs, so this is a lower bound on agreement
+            eq = (bf16_ids.int() == log[:bf16_ids.shape[0], 0].cpu().int())
+            first = int((~eq.all(-1)).nonzero()[0]) if not bool(eq.all()) else int(eq.shape[0])
+            res["bf16_free_running_ids_equal_bf16_oracle_first8frames"] = {"equal": int(eq.sum()), "of": int(eq.numel()), "frames_before_first_difference": first}
+        else:
+            res["bf16_free_running_ids_equal_bf16_oracle_first8frames"] = {"error": bf16_ids}
         res["parity_notes"] = ("bf16 ids are asserted teacher-forced against the bf16 oracle (tests/test_gpu_fullsize.py); the live "
                                "codec's ResidualVQ is restated from vector_quantize_pytorch==1.27.15's published algorithm and is "
                                "parity-UNPINNED against the package itself (absent here)")
@@ -681,6 +811,11 @@ def main():
     if solo and not a.no_legs:
         res["codec"] = codec_leg(dev, cpu=not a.no_cpu_baseline)
         res["codec"]["stage2_codes_to_wav"] = stage2_leg(dev)
+        s2 = res["codec"]["stage2_codes_to_wav"]
+        res["codec_rtf"] = s2.get("rtf")                         # stage 2 of `--stage all`: wall / audio seconds of one 20-s window
+        res["codec_rtf_scalar_decode_only"] = res["codec"].get("scalar_decode_rtf")
+        if s2.get("ms_per_window") is not None:                 # a 74-frame utterance decodes as one window (<= 250 semantic frames)
+            res["stage_all_ms_per_utterance"] = round(dt / a.steps * 1e3 + s2["ms_per_window"], 2)
         res["config5_ttm_500_frames"] = config5_leg(model, dev)
         res["batched_decode"] = batched_leg(model, dev)
         res["batched_decode_256"] = batched_leg(model, dev, B=256, frames=12, max_seq=128)

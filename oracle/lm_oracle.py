@@ -226,18 +226,21 @@ class Stage3Oracle:
         return self._trunk(tokens, tokens_mask[:, :-1], input_pos, None, scaled=False)     # the product's prefill passes keep the unscaled form
 
     @torch.inference_mode()
-    def generate_frame(self, tokens, tokens_mask, input_pos, input_pos_maxp1=None, forbid_prefix=0, cfg_scale=1.0):
+    def generate_frame(self, tokens, tokens_mask, input_pos, input_pos_maxp1=None, forbid_prefix=0, cfg_scale=1.0, scaled=True):
         """model_new.py:568-645 with topk=1, temperature=1 (greedy).  tokens (B,1,9); input_pos (B,) or (1,).
         Returns (B, 9) int32 [text, a0..a7].  Tie-break = lowest index (the reference resolves exact
         ties with the RNG, :141-143; the golden vectors record that no tie occurred).
         cfg_scale > 1 with B > 1 (:618-622, 634-637): row 0 is the conditional prompt, rows 1.. the unconditional one;
-        the samplers see l[1:] + (l[0:1] - l[1:]) * cfg_scale and every row continues from that sample."""
+        the samplers see l[1:] + (l[0:1] - l[1:]) * cfg_scale and every row continues from that sample.
+        scaled (bf16 mode only): the form of the RMSNorm + Linear pairs of a decode frame — True: the product's plans for <= 64
+        sequences (row scale applied to the fp32 sums), False: its plans for more than 64 sequences (the prefill form:
+        normalised row rounded to bf16) — csrc/ua2_stage3.hip, DESIGN.md §2."""
         B = tokens.size(0)
         cfg = cfg_scale > 1.0 and B > 1
         mix = (lambda l: l[1:] + (l[0:1] - l[1:]) * cfg_scale) if cfg else (lambda l: l)
         rep = (lambda t: t.repeat(2, 1)) if cfg else (lambda t: t)
         pos = input_pos.view(-1, 1).expand(B, 1) if input_pos.numel() in (1, B) else input_pos
-        h_final = self._trunk(tokens, tokens_mask, pos, input_pos_maxp1)
+        h_final = self._trunk(tokens, tokens_mask, pos, input_pos_maxp1, scaled=scaled)
         last_h = h_final[:, -1, :]
         text_logits = F.linear(self.qa(last_h), self.lm_head)          # :617
         text_logits = mix(text_logits)
@@ -247,8 +250,8 @@ class Stage3Oracle:
         alog = []
         for i in range(self.ncb):                                      # :630-641
             d_in = F.linear(self.qa(curr_h), self.projection)
-            d_x = self.decoder.forward(d_in, torch.full((B, 1), i, dtype=torch.long), None, final_norm=False)
-            lg, = norm_linear(d_x[:, -1, :], self.decoder.ln_f, self.decoder.s.norm_eps, [self.audio_head[i].t()], self.mode)   # ln_f :164 + :632
+            d_x = self.decoder.forward(d_in, torch.full((B, 1), i, dtype=torch.long), None, final_norm=False, scaled=scaled)
+            lg, = norm_linear(d_x[:, -1, :], self.decoder.ln_f, self.decoder.s.norm_eps, [self.audio_head[i].t()], self.mode, scaled)   # ln_f :164 + :632
             lg = mix(lg)
             alog.append(lg)
             lg2 = lg.clone()
@@ -271,7 +274,7 @@ def shapes_from_configs(cfgs: Dict[str, dict]):
 
 
 def run_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=None, reason_card=0, collect_logits=False,
-                    cfg_scale=1.0):
+                    cfg_scale=1.0, scaled=True, teacher=None):
     """The generators' loop (evaluation/tts_task.py:244-282 "audio" feedback;
     evaluation/asr_task.py:658-682 "text" feedback) at fixed length (no EOS exit)."""
     B, L, _ = tokens.shape
@@ -286,8 +289,13 @@ def run_decode_loop(model, tokens, mask, frames, feedback, forbid_switch=None, r
     for f in range(frames):
         if forbid_switch is not None and f == forbid_switch:
             forbid = reason_card
-        s = model.generate_frame(ct, cm, curr_pos, maxp1, forbid_prefix=forbid, **({"cfg_scale": cfg_scale} if cfg_scale != 1.0 else {}))
+        kw = {"cfg_scale": cfg_scale} if cfg_scale != 1.0 else {}
+        if not scaled:
+            kw["scaled"] = False
+        s = model.generate_frame(ct, cm, curr_pos, maxp1, forbid_prefix=forbid, **kw)
         samples.append(s)
+        if teacher is not None:                  # teacher forcing: continue from the given (frames, B, 9) samples, not from our own
+            s = teacher[f]
         if collect_logits:
             tl.append(model.last_text_logits.clone()); al.append(model.last_audio_logits.clone())
         text_tok, audio = s[:, 0:1].long(), s[:, 1:].long()

@@ -63,22 +63,18 @@ def _margin(logits, forbid=0):
     return float(s[-1] - s[-2])
 
 
-@pytest.mark.parametrize("case,frames,feedback,switch", CASES)
-def test_bf16_teacher_forced_vs_oracle_bf16_contract(golden, sd, case, frames, feedback, switch):
-    """bf16 kernels (MFMA 16x16x32, fp32 accumulate) vs the oracle restating the same contract
-    (DESIGN.md §numerics).  Under this contract an fp32 summation-order difference can flip a bf16
-    rounding (1 ulp = 0.4 % of an activation) and the flip propagates: on this toy model
-    (|w| ~ 0.05, K = 128..512) the oracle itself moves by up to 7e-3 when only its GEMMs are
-    evaluated in fp64 instead of fp32.  So the check is teacher-forced per frame: the kernels get
-    the oracle's previous frame as input; logits must agree within 2.5e-2, and every token must be
-    identical as long as the oracle's top-2 margin is >= 2.5e-2 (inside a frame the comparison stops
-    at the first token below that margin, because later local-decoder steps depend on it)."""
+# bf16 bars (the two bars must be consistent): a logit may differ from the oracle's by at most ATOL, so an id
+# is asserted exactly where the oracle's top-2 margin is >= 2 x ATOL (both logits could move against each other by ATOL).
+TEXT_ATOL, AUDIO_ATOL = 3.5e-2, 2.5e-2      # measured maxima: text 3.26e-2 (one of 512 logits, r3), audio 2.1e-2
+
+
+def _bf16_teacher_forced(golden, sd, case, frames, feedback, switch, plan_batch, scaled):
     d, _ = golden
     tokens, mask = _case(d, case)
     B, L, _ = tokens.shape
     o = run_decode_loop(build_oracle(sd, "bf16", B), tokens, mask, frames, feedback, forbid_switch=switch,
-                        reason_card=RC, collect_logits=True)
-    m = build_product_model(sd, torch.bfloat16, batch=B)
+                        reason_card=RC, collect_logits=True, scaled=scaled)
+    m = build_product_model(sd, torch.bfloat16, batch=max(B, plan_batch))
     dev = "cuda"
     tk, mk = tokens.to(dev), mask.to(dev)
     m.reset_caches()
@@ -91,15 +87,15 @@ def test_bf16_teacher_forced_vs_oracle_bf16_contract(golden, sd, case, frames, f
         s = m.generate_frame(ct, cm, input_pos=torch.tensor([L - 1 + f], device=dev), input_pos_maxp1=L + f,
                              forbid_prefix=forbid).cpu()
         tl, al = m.buffer("text_logits", B).cpu(), m.buffer("audio_logits", B).cpu()
-        np.testing.assert_allclose(tl.numpy(), o["text_logits"][f].numpy(), atol=4e-2, rtol=0)   # one of 512 logits sits at the edge: 2.66e-2 in r2 (prefill attention on the MFMA flash kernel: other summation order), 3.26e-2 in r3 (decode frames in the scaled-norm form) — a bf16 rounding flip upstream, same contract on both sides
+        np.testing.assert_allclose(tl.numpy(), o["text_logits"][f].numpy(), atol=TEXT_ATOL, rtol=0)
         for b in range(B):
             total += 9
-            if _margin(o["text_logits"][f, b]) >= 2.5e-2:
+            if _margin(o["text_logits"][f, b]) >= 2 * TEXT_ATOL:
                 assert int(s[b, 0]) == int(o["samples"][f, b, 0]), f"text id differs at frame {f}"
                 compared += 1
             for i in range(8):
-                np.testing.assert_allclose(al[b, i].numpy(), o["audio_logits"][f, b, i].numpy(), atol=2.5e-2, rtol=0)
-                if _margin(o["audio_logits"][f, b, i], forbid) < 2.5e-2:
+                np.testing.assert_allclose(al[b, i].numpy(), o["audio_logits"][f, b, i].numpy(), atol=AUDIO_ATOL, rtol=0)
+                if _margin(o["audio_logits"][f, b, i], forbid) < 2 * AUDIO_ATOL:
                     break
                 assert int(s[b, 1 + i]) == int(o["samples"][f, b, 1 + i]), f"audio id {i} differs at frame {f}"
                 compared += 1
@@ -112,7 +108,31 @@ def test_bf16_teacher_forced_vs_oracle_bf16_contract(golden, sd, case, frames, f
         else:
             ct = torch.cat([torch.zeros_like(audio), text_tok], dim=-1).unsqueeze(1)
             cm = torch.cat([torch.zeros_like(audio).bool(), torch.ones(B, 1, device=dev).bool()], dim=1).unsqueeze(1)
-    assert compared >= total // 3, f"only {compared}/{total} tokens had a defined arg-max"
+    # with the margin at 2 x ATOL about a third of the toy model's ids are decidable (counted on the oracle: 76 / 27 / 80 of
+    # 216 / 90 / 216); the bar is a quarter
+    assert compared >= total // 4, f"only {compared}/{total} tokens had a defined arg-max"
+
+
+@pytest.mark.parametrize("case,frames,feedback,switch", CASES)
+def test_bf16_teacher_forced_vs_oracle_bf16_contract(golden, sd, case, frames, feedback, switch):
+    """bf16 kernels (MFMA 16x16x32, fp32 accumulate) vs the oracle restating the same contract
+    (DESIGN.md §numerics).  Under this contract an fp32 summation-order difference can flip a bf16
+    rounding (1 ulp = 0.4 % of an activation) and the flip propagates: on this toy model
+    (|w| ~ 0.05, K = 128..512) the oracle itself moves by up to 7e-3 when only its GEMMs are
+    evaluated in fp64 instead of fp32.  So the check is teacher-forced per frame: the kernels get
+    the oracle's previous frame as input; logits must agree within ATOL, and every token must be
+    identical as long as the oracle's top-2 margin is >= 2 x ATOL (inside a frame the comparison stops
+    at the first token below that margin, because later local-decoder steps depend on it)."""
+    _bf16_teacher_forced(golden, sd, case, frames, feedback, switch, plan_batch=1, scaled=True)
+
+
+@pytest.mark.parametrize("case,frames,feedback,switch", [CASES[0], CASES[2]])
+def test_bf16_plan_for_more_than_64_sequences_matches_the_unscaled_oracle(golden, sd, case, frames, feedback, switch):
+    """a plan for more than 64 sequences decodes with the RMSNorm-prologue form (csrc/ua2_stage3.hip:
+    `scaled` only when max_batch <= 64), the third bf16 arithmetic of the product — now restated by the oracle
+    (`generate_frame(scaled=False)`) and held to the same bars.  A sequence's bf16 ids therefore depend on the PLAN it runs in
+    (<= 64 or > 64 sequences), never on the live batch inside a plan."""
+    _bf16_teacher_forced(golden, sd, case, min(frames, 8), feedback, switch, plan_batch=66, scaled=False)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
