@@ -265,23 +265,26 @@ int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const float* part_max
                      int32_t* out_tokens, int32_t out_ld, int32_t out_col,
                      const void* emb, int32_t emb_row_offset, int32_t C, float* next_h, void* stream);
 
-/* Classifier-free guidance (model_new.py:618-622, 634-637) over a (conditional, unconditional) pair of logit rows:
- * guided = l1 + (l0 - l1) * scale, written to BOTH rows ([2, ld] fp32), and the per-16-column arg-max partials of
- * both rows ([2, ceil(V/16)], same format and tie rule as UA2_EPI_STORE; columns < forbid[0] excluded) rebuilt
- * from it, so ua2_argmax_embed / ua2_sample_topk run unchanged and both rows continue from the same token. */
+/* Classifier-free guidance (model_new.py:618-622, 634-637) over `pairs` (conditional, unconditional) pairs of logit rows
+ * (rows 2p, 2p + 1 of [2 pairs, ld] fp32; the reference has one pair, batched generation has one per utterance):
+ * guided = l1 + (l0 - l1) * scale, written to BOTH rows of the pair, and the per-16-column arg-max partials of both rows
+ * ([2 pairs, ceil(V/16)], same format and tie rule as UA2_EPI_STORE; columns < forbid[2p] excluded) rebuilt from it, so
+ * ua2_argmax_embed / ua2_sample_topk run unchanged and both rows continue from the same token. */
 int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
-                int32_t* part_idx, void* stream);
+                int32_t* part_idx, int32_t pairs, void* stream);
 
 /* Top-k sampling tail (model_new.py:146-187 with topk > 1: temperature, forbid_prefix, keep logits >= the
  * k-th largest, exponential-race multinomial draw) + next-step embedding gather.  Philox4x32-10 keyed by
  * (seed + device seed word, draw index, row, stream_id) where `counter` is a DEVICE int32[3]: [0] = draw index,
  * [1], [2] = low / high half of a 64-bit word added to `seed` (zeros for a purely by-value seed; the frame
  * executor keeps its seed there so that one captured graph serves every seed).  Reproducible under graph replay;
- * it does not reproduce torch's generator stream (parity with the reference is distributional). */
+ * it does not reproduce torch's generator stream (parity with the reference is distributional).
+ * row_key_shift (0 or 1): the row part of the key is m >> row_key_shift — 1 makes the two rows of a guidance pair draw the
+ * same numbers (they hold the same guided logits: both continue from one sample, model_new.py:622). */
 int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
                     const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
                     int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,
-                    int32_t C, float* next_h, void* stream);
+                    int32_t C, float* next_h, int32_t row_key_shift, void* stream);
 
 /* ---- codec: residual vector quantisation ------------------------------------------------ */
 
@@ -504,7 +507,8 @@ int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint
  * pages on the MFMA flash kernel.  ua2_stage3_frame (decode) never uses groups. */
 int ua2_stage3_set_prefill_groups(ua2_stage3* h, const int32_t* group_rows, const int32_t* group_seq, const int32_t* group_nkeys,
                                   int32_t n_groups, int32_t group_q_tiles);
-/* cfg_scale > 1: frames of exactly two rows (conditional, unconditional) sample from the guided logits (ua2_cfg_mix). */
+/* cfg_scale > 1: frames of (conditional, unconditional) row pairs — rows 2p, 2p + 1; an even row count — sample from the guided
+ * logits (ua2_cfg_mix); feedback mode 2 continues every row from its pair's conditional row. */
 int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale);
 
 /* model_new.py:594-613 (embed-merge -> U-expert -> backbone -> G-expert -> blend) for R rows

@@ -96,7 +96,7 @@ _EXPORTS = {
     "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
     "ua2_struct_size": (C.c_size_t, [C.c_int]),
     "ua2_dwconv1d": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "ua2_cfg_mix": (C.c_int, [vp, i32, i32, C.c_float, vp, vp, vp, vp]),
+    "ua2_cfg_mix": (C.c_int, [vp, i32, i32, C.c_float, vp, vp, vp, i32, vp]),
     "ua2_stage3_set_cfg": (C.c_int, [vp, C.c_float]),
     "ua2_linear_workspace_bytes": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
@@ -123,7 +123,7 @@ _EXPORTS = {
     "ua2_stage3_scratch_floats": (C.c_size_t, [C.POINTER(Stage3Desc)]),
     "ua2_stage3_create": (C.c_int, [C.POINTER(Stage3Desc), C.POINTER(vp)]),
     "ua2_stage3_destroy": (None, [vp]),
-    "ua2_sample_topk": (C.c_int, [C.c_int, i32, vp, i32, i32, i32, f32, vp, C.c_uint64, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp]),
+    "ua2_sample_topk": (C.c_int, [C.c_int, i32, vp, i32, i32, i32, f32, vp, C.c_uint64, vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp]),
     "ua2_stage3_set_sampling": (C.c_int, [vp, i32, f32, C.c_uint64, vp]),
     "ua2_stage3_set_prefill_groups": (C.c_int, [vp, vp, vp, vp, i32, i32]),
     "ua2_stage3_trunk": (C.c_int, [vp, i32, vp]),

@@ -136,8 +136,8 @@ int ua2_gemv_rows_per_tile(int dtype, int K);   // rows one decode-kernel workgr
 extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
                                const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
                                int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,
-                               int32_t C, float* next_h, void* stream);
+                               int32_t C, float* next_h, int32_t row_key_shift, void* stream);
 extern "C" int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
-                           int32_t* part_idx, void* stream);
+                           int32_t* part_idx, int32_t pairs, void* stream);
 // decode-regime specialisation; returns 1 when the problem is outside its regime
 int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s);

@@ -246,7 +246,11 @@ __global__ __launch_bounds__(256) void cfg_mix_kernel(float* __restrict__ logits
                                                       int32_t* __restrict__ pidx) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int nb = (V + 15) / 16;
-  const int fb = forbid ? forbid[0] : 0;
+  const int pair = blockIdx.y;                             // rows 2 pair, 2 pair + 1
+  logits += (size_t)2 * pair * ld;
+  pmax += (size_t)2 * pair * nb;
+  pidx += (size_t)2 * pair * nb;
+  const int fb = forbid ? forbid[2 * pair] : 0;
   float g = -INFINITY;
   if (n < V) {
     const float l0 = logits[n], l1 = logits[ld + n];
@@ -335,9 +339,9 @@ extern "C" int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const floa
 }
 
 extern "C" int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
-                           int32_t* part_idx, void* stream) {
-  UA2_CHECK(logits && part_max && part_idx && V > 0 && ld >= V, "ua2_cfg_mix: bad arguments");
-  hipLaunchKernelGGL(cfg_mix_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ld, V, scale, forbid,
+                           int32_t* part_idx, int32_t pairs, void* stream) {
+  UA2_CHECK(logits && part_max && part_idx && V > 0 && ld >= V && pairs > 0 && pairs < 65536, "ua2_cfg_mix: bad arguments");
+  hipLaunchKernelGGL(cfg_mix_kernel, dim3((V + 255) / 256, pairs), dim3(256), 0, (hipStream_t)stream, logits, ld, V, scale, forbid,
                      part_max, part_idx);
   UA2_LAUNCH_CHECK();
   return 0;

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restri
                                                            unsigned long long seed, const int32_t* __restrict__ counter,
                                                            int stream_id, int32_t* __restrict__ out_tokens, int out_ld,
                                                            int out_col, const void* __restrict__ emb, int emb_off, int C,
-                                                           float* __restrict__ next_h) {
+                                                           float* __restrict__ next_h, int row_key_shift) {
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_prefix, sel_remaining;
   __shared__ float red_v[16];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restri
     const float l = row[c] / temperature;
     if (key_of(l) < kth) continue;               // removed: strictly below the k-th value
     unsigned r[4];
-    philox4x32((unsigned)c, draw, (unsigned)m, (unsigned)stream_id, (unsigned)seed, (unsigned)(seed >> 32), r);
+    philox4x32((unsigned)c, draw, (unsigned)(m >> row_key_shift), (unsigned)stream_id, (unsigned)seed, (unsigned)(seed >> 32), r);
     const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);    // (0, 1)
     const float q = -logf(u);                                                // Exp(1)
     const float score = expf(l - mx) / q;                                    // probs / q up to the softmax constant
@@ -122,18 +122,18 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restri
 extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk,
                                float temperature, const int32_t* forbid, uint64_t seed, const int32_t* counter,
                                int32_t stream_id, int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb,
-                               int32_t emb_row_offset, int32_t C, float* next_h, void* stream) {
-  UA2_CHECK(M > 0 && logits && V > 0 && out_tokens && counter, "ua2_sample_topk: bad arguments");
+                               int32_t emb_row_offset, int32_t C, float* next_h, int32_t row_key_shift, void* stream) {
+  UA2_CHECK(M > 0 && logits && V > 0 && out_tokens && counter && row_key_shift >= 0 && row_key_shift <= 1, "ua2_sample_topk: bad arguments");
   UA2_CHECK(temperature > 0.f, "temperature must be > 0");                       // model_new.py:165-166
   UA2_CHECK(topk >= 1 && topk <= V, "topk must be in 1..%d", V);                 // :177-178 (per-row forbid checked by the host)
   UA2_CHECK(!emb || next_h, "ua2_sample_topk: next_h is NULL");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UA2_BF16)
     hipLaunchKernelGGL((sample_topk_kernel<UA2_BF16>), dim3(M), dim3(1024), 0, s, logits, ld, V, topk, temperature, forbid,
-                       (unsigned long long)seed, counter, stream_id, out_tokens, out_ld, out_col, emb, emb_row_offset, C, next_h);
+                       (unsigned long long)seed, counter, stream_id, out_tokens, out_ld, out_col, emb, emb_row_offset, C, next_h, row_key_shift);
   else if (dtype == UA2_F32)
     hipLaunchKernelGGL((sample_topk_kernel<UA2_F32>), dim3(M), dim3(1024), 0, s, logits, ld, V, topk, temperature, forbid,
-                       (unsigned long long)seed, counter, stream_id, out_tokens, out_ld, out_col, emb, emb_row_offset, C, next_h);
+                       (unsigned long long)seed, counter, stream_id, out_tokens, out_ld, out_col, emb, emb_row_offset, C, next_h, row_key_shift);
   else {
     ua2_set_error("ua2_sample_topk: bad dtype %d", dtype);
     return -1;

@@ -199,9 +199,9 @@ __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int re
     const int32_t* own = out + (size_t)m * w;
     if (frame < log_frames)
       for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = (audio_fb || j == 0) ? own[j] : 0;   // text loop: no audio ids exist
-    // mode 2 (classifier-free-guidance pair, tts_task.py:256-258,278-280): every row continues from
-    // the conditional row's sample
-    const int32_t* o = (mode == 2) ? out : own;
+    // mode 2 (classifier-free-guidance pairs, tts_task.py:256-258,278-280): every row continues from the sample of
+    // its pair's conditional row (rows 2p, 2p + 1; the reference has the one pair)
+    const int32_t* o = (mode == 2) ? out + (size_t)(m & ~1) * w : own;
     bool all_reason_eos = true;
     for (int i = 0; i < ncb; ++i) {
       all_reason_eos = all_reason_eos && (o[1 + i] == reason_eos);
@@ -372,17 +372,16 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
   if (int rc = ua2_linear_launch(a, side)) return rc;
   // model_new.py:618-622: with guidance the sampler sees l[1] + (l[0] - l[1]) * cfg_scale and both rows take its sample
   const bool cfg = h->cfg_scale > 1.f && R > 1;
-  UA2_CHECK(!cfg || R == 2, "ua2_stage3_heads: classifier-free guidance needs exactly the (conditional, unconditional) pair, R=%d", R);
+  UA2_CHECK(!cfg || R % 2 == 0, "ua2_stage3_heads: classifier-free guidance needs (conditional, unconditional) row pairs, R=%d", R);
+  const int key_shift = cfg ? 1 : 0;                       // the two rows of a pair hold the same guided logits and draw the same numbers
   if (cfg)
-    if (int rc = ua2_cfg_mix(h->text_logits, d.vt, d.vt, h->cfg_scale, nullptr, h->pmax_t, h->pidx_t, side)) return rc;
+    if (int rc = ua2_cfg_mix(h->text_logits, d.vt, d.vt, h->cfg_scale, nullptr, h->pmax_t, h->pidx_t, R / 2, side)) return rc;
   if (h->topk == 1) {
     if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
                                   side)) return rc;
   } else {   // model_new.py:623 sample_topk(text_logits, topk, temperature)
-    for (int rep = 0; rep < (cfg ? 2 : 1); ++rep)   // guidance: the same draw (row key 0) written to both rows
-      if (int rc = ua2_sample_topk(d.dtype, cfg ? 1 : R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature,
-                                   nullptr, 0, d.counters + 1, 0, d.out_tokens + (size_t)rep * w, w, 0, nullptr, 0, C,
-                                   nullptr, side)) return rc;
+    if (int rc = ua2_sample_topk(d.dtype, R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature, nullptr, 0,
+                                 d.counters + 1, 0, d.out_tokens, w, 0, nullptr, 0, C, nullptr, key_shift, side)) return rc;
   }
   if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
   const float* curr = h->hfin;
@@ -404,15 +403,14 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (cfg)   // model_new.py:634-637
       if (int rc = ua2_cfg_mix(h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->cfg_scale, d.forbid, h->pmax_a,
-                               h->pidx_a, s)) return rc;
+                               h->pidx_a, R / 2, s)) return rc;
     if (h->topk == 1) {
       if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
                                     i * d.va, C, h->curr_h, s)) return rc;
     } else {   // model_new.py:639 audio_sample_topk(ci_logits, topk, temperature, forbid_prefix)
-      for (int rep = 0; rep < (cfg ? 2 : 1); ++rep)
-        if (int rc = ua2_sample_topk(d.dtype, cfg ? 1 : R, h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->topk,
-                                     h->temperature, d.forbid, 0, d.counters + 1, 1 + i, d.out_tokens + (size_t)rep * w, w,
-                                     1 + i, d.audio_emb, i * d.va, C, h->curr_h + (size_t)rep * C, s)) return rc;
+      if (int rc = ua2_sample_topk(d.dtype, R, h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->topk, h->temperature,
+                                   d.forbid, 0, d.counters + 1, 1 + i, d.out_tokens, w, 1 + i, d.audio_emb, i * d.va, C, h->curr_h,
+                                   key_shift, s)) return rc;
     }
     curr = h->curr_h;
   }

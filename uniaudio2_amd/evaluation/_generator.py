@@ -216,15 +216,25 @@ class GeneratorBase:
         return de_reason.to(self.device), de_sem.to(self.device)
 
     @torch.inference_mode()
-    def _generate_audio_tokens_batch(self, prompts, topk=1, temperature=1.0, max_audio_frames=500):
+    def _generate_audio_tokens_batch(self, prompts, topk=1, temperature=1.0, max_audio_frames=500, cfg_prompts=None):
         """Many utterances at once on one GPU (the reference loops over them one by one,
         multi_task_inference.py:510): prompts = [(tokens (L_b, 9), mask (L_b, 9)), ...] of any lengths.  One ragged prefill,
         then all sequences decode together in device-side chunks; after each chunk the host runs every sequence's own
         phase / EOS bookkeeping (the same PhaseSplitter as the single-utterance loop) and retires the finished ones, so
-        the batch shrinks as utterances end.  Greedy results equal the one-by-one results bit for bit (row invariance)."""
+        the batch shrinks as utterances end.  Greedy results equal the one-by-one results bit for bit (row invariance).
+        With `is_cfg` (the reference's --use_cfg: an unconditional twin of every prompt, tts_task.py:228-245) utterance b
+        occupies the row PAIR (2b, 2b + 1) = (conditional, unconditional): guidance mixes inside a pair
+        (model_new.py:618-622,634-637), both rows continue from the pair's conditional sample (tts_task.py:278-280), the
+        bookkeeping reads the conditional row, and a finished utterance retires both of its rows."""
+        per = 2 if self.is_cfg else 1
         if self.is_cfg:
-            raise NotImplementedError("batched generation with the classifier-free-guidance pair layout is not built")
-        B = len(prompts)
+            if cfg_prompts is None or len(cfg_prompts) != len(prompts):
+                raise ValueError("is_cfg: one unconditional prompt per prompt (prepare_*_for_cfg) is needed")
+            for (t, _), (ct, _) in zip(prompts, cfg_prompts):
+                if t.shape != ct.shape:
+                    raise ValueError("a prompt and its unconditional twin must have the same shape")
+            prompts = [p for pair in zip(prompts, cfg_prompts) for p in pair]
+        B = len(prompts)                                             # rows
         st = getattr(self._model, "_st", None)
         longest = max(int(t.shape[0]) for t, _ in prompts)
         need_rows = sum(int(t.shape[0]) - 1 for t, _ in prompts)
@@ -232,20 +242,22 @@ class GeneratorBase:
             self._model.setup_caches(B, max_rows=max(64, min(need_rows, 8192)), log_frames=max(512, max_audio_frames))
         self._model.begin_ragged([(t, m.bool()) for t, m in prompts])
         self._set_sampling(topk, temperature)
-        splitters = [PhaseSplitter(self.reason_eos, self.semantic_eos, self.audio_reason_card) for _ in range(B)]
-        active, frame = list(range(B)), 0
+        n_utt = B // per
+        splitters = [PhaseSplitter(self.reason_eos, self.semantic_eos, self.audio_reason_card) for _ in range(n_utt)]
+        active, frame = list(range(n_utt)), 0                        # live utterances, in row(-pair) order
         while active and frame < max_audio_frames:
             n = min(self.chunk_frames, max_audio_frames - frame)
-            log = self._model.generate_frames(n, len(active), 0, reason_eos=self.reason_eos, reason_card=self.audio_reason_card,
-                                              max_pos=longest + max_audio_frames).cpu()       # (n, rows, 9)
+            log = self._model.generate_frames(n, per * len(active), 2 if self.is_cfg else 0, reason_eos=self.reason_eos,
+                                              reason_card=self.audio_reason_card, max_pos=longest + max_audio_frames).cpu()       # (n, rows, 9)
             keep = []
             for r, b in enumerate(active):
+                row = per * r                                        # the utterance's (conditional) row
                 for f in range(n):
-                    if not splitters[b].push(log[f, r:r + 1, 1:]):
+                    if not splitters[b].push(log[f, row:row + 1, 1:]):
                         break
                 if not splitters[b].done:
                     keep.append(r)
-            self._model.retire_rows(keep, len(active))
+            self._model.retire_rows([per * r + j for r in keep for j in range(per)], per * len(active))
             active = [active[r] for r in keep]
             frame += n
         out = []

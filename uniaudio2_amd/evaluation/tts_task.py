@@ -30,4 +30,5 @@ class Generator(GeneratorBase):
         returns [(reason (8, T_r), semantic (8, T_s)), ...] in input order, each equal to its own generate_tts result
         under greedy decoding."""
         prompts = [self.prepare_tts_task(task_prompt, t) for t in text_tokens]
-        return self._generate_audio_tokens_batch(prompts, topk=topk, temperature=temperature)
+        cfg = [self.prepare_tts_task_for_cfg(task_prompt, t) for t in text_tokens] if self.is_cfg else None
+        return self._generate_audio_tokens_batch(prompts, topk=topk, temperature=temperature, cfg_prompts=cfg)
