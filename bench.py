@@ -311,20 +311,29 @@ def stage2_leg(dev, steps=10):
     tok = ReasoningTokenizer(sq_codec=sq, model=model, device=dev)
     codes = torch.randint(0, 8192, (8, 250))
     tok.detokenize_no_reason(codes, steps=2)                       # warm: packs, graph capture
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    wav = tok.detokenize_no_reason(codes, steps=steps)
-    torch.cuda.synchronize()
-    total = time.perf_counter() - t0
+    # best of 3: the leg issues ~3000 graph nodes / small launches per window from the host, and on a GPU box whose host cores are
+    # shared (cgroup quota) one pass in a few runs 25x slower (1815 ms against 70.5: round-4 evidence run) — a host artefact, not
+    # a property of the kernels; every pass is reported
+    passes = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wav = tok.detokenize_no_reason(codes, steps=steps)
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t0)
+    total = min(passes)
     est = model.cfm_wrapper.estimator
     x = torch.randn(2, 500, RELEASED_CONFIG["in_channels"], device=dev)
     est(x, 0.5); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        est(x, 0.5)
-    e1.record(); torch.cuda.synchronize()
-    step_ms = e0.elapsed_time(e1) / 5
+    step_passes = []
+    for _ in range(3):
+        e0.record()
+        for _ in range(5):
+            est(x, 0.5)
+        e1.record(); torch.cuda.synchronize()
+        step_passes.append(e0.elapsed_time(e1) / 5)
+    step_ms = min(step_passes)
     flop = 2.0 * 500 * 32 * 2 * 12 * 1536 ** 2
     # encode side of the same model (config 2's "codec encode", everything behind the frozen SSL encoders): one 30-s segment
     # — what a 10-s clip costs since audio2token stopped encoding the segment the reference discards — with synthetic features
@@ -361,7 +370,8 @@ def stage2_leg(dev, steps=10):
         enc.update({"config3_encode_post_ssl_ms_per_batch32": round(ms32, 2), "config3_encode_post_ssl_clips_per_s": round(32e3 / ms32, 1)})
     except Exception as e:  # noqa: BLE001
         enc["config3_encode_post_ssl_error"] = repr(e)[:200]
-    return {**enc, "euler_steps": steps, "window_s": 20.0, "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
+    return {**enc, "euler_steps": steps, "window_s": 20.0, "ms_per_window_passes": [round(p_ * 1e3, 1) for p_ in passes],
+            "dit_ms_per_guided_step_passes": [round(p_, 2) for p_ in step_passes], "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
             "dit_ms_per_guided_step": round(step_ms, 2), "dit_tflops": round(flop / (step_ms * 1e-3) / 1e12, 1),
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
 
