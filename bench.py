@@ -183,7 +183,7 @@ def codec_leg(dev, cpu=False):
             return _real(*a_, **kw_)
         setattr(ops, name, counting)
     try:
-        sq.decode(lat)
+        sq.decode(lat, use_graph=False)
     finally:
         for name, real in saved.items():
             setattr(ops, name, real)
@@ -829,6 +829,10 @@ def main():
         res["config5_ttm_500_frames"] = config5_leg(model, dev)
         res["batched_decode"] = batched_leg(model, dev)
         res["batched_decode_256"] = batched_leg(model, dev, B=256, frames=12, max_seq=128)
+        try:   # where the decode GEMMs stop being an HBM problem: 1024 live sequences (serving regime; the tiled MFMA GEMM takes every Linear)
+            res["batched_decode_1024"] = batched_leg(model, dev, B=1024, frames=6, max_seq=64)
+        except Exception as e:  # noqa: BLE001 — information leg
+            res["batched_decode_1024"] = {"error": repr(e)[:200]}
         res["config3_asr_batch32"] = config3_leg(model, dev)
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -223,3 +223,21 @@ def test_scalar_encode_10s_clip_vs_cpu_oracle():
     ref = o.encode(wav).numpy()
     assert got.shape == ref.shape == (1, 136, 250)
     assert _rms(got, ref) < 1e-5, _rms(got, ref)
+
+
+def test_scalar_decode_graph_replay_equals_launch_by_launch():
+    """round 4: ScalarModel.decode replays a HIP graph of its launch chain per input shape; same bits as issuing the launches
+    one by one, on repeated calls and for a second shape (its own graph)."""
+    import bench
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
+    torch.manual_seed(3)
+    sq = ScalarModel(**bench.SCALAR_CFG).cuda().prepare()
+    for T in (60, 37):
+        lat = torch.tanh(torch.randn(2, 136, T, device="cuda"))
+        ref = sq.decode(lat, use_graph=False)
+        for _ in range(3):
+            got = sq.decode(lat)
+            assert torch.equal(got, ref)
+        other = torch.tanh(torch.randn(2, 136, T, device="cuda"))
+        assert torch.equal(sq.decode(other), sq.decode(other, use_graph=False))      # the replay reads the NEW input
+    assert len(sq._graphs) == 2

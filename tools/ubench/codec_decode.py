@@ -23,7 +23,12 @@ e0.record()
 for _ in range(10):
     wav = sq.decode(lat)
 e1.record(); torch.cuda.synchronize()
-print(f"decode: {e0.elapsed_time(e1) / 10:.3f} ms per 20-s window, tc path = {sq._dec_tc}")
+print(f"decode: {e0.elapsed_time(e1) / 10:.3f} ms per 20-s window, tc path = {sq._dec_tc}, graph = {bool(sq._graphs)}")
+e0.record()
+for _ in range(10):
+    wav2 = sq.decode(lat, use_graph=False)
+e1.record(); torch.cuda.synchronize()
+print(f"decode, launches issued one by one: {e0.elapsed_time(e1) / 10:.3f} ms; identical: {torch.equal(wav, wav2)}")
 if "--layers" in sys.argv:
     rows = []
     for name in ("conv1d", "conv1d_tc", "tc_pack"):
@@ -41,7 +46,7 @@ if "--layers" in sys.argv:
         setattr(ops, name, wrap)
     for _ in range(2):
         rows.clear()
-        sq.decode(lat)
+        sq.decode(lat, use_graph=False)
     torch.cuda.synchronize()
     tot = 0.0
     agg = {}

@@ -8,6 +8,8 @@ torch._weight_norm) and packs every filter for ua2_conv1d; encode/decode then ru
 launch per convolution (bias, PReLU, residual add, tanh, round(9x)/9, repeat-upsampling and the
 transposed conv's interleave live inside the kernel).  No torch math on the data path.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -310,6 +312,7 @@ class ScalarModel(nn.Module):
         finally:
             _ConvOp.default_fast = False
         self._dec_tc = bool(fast_decode) and self._decoder_tc_ok()
+        self._graphs = {}
         self._ready = True
         return self
 
@@ -341,12 +344,7 @@ class ScalarModel(nn.Module):
             x = op(x)
         return x
 
-    @torch.inference_mode()
-    def decode(self, x):
-        """latent -> wav; the latent is snapped to the 1/9 grid first (:403-407)."""
-        if not self._ready:
-            self.prepare()
-        x = x.float().contiguous()
+    def _decode_impl(self, x):
         ops_ = self._dec_ops
         x = ops_[0](x)                                                # latent (fp32 [C][T], snapped to the 1/9 grid) -> widest layer
         if self._dec_tc:
@@ -359,3 +357,38 @@ class ScalarModel(nn.Module):
         for op in ops_[1:]:
             x = op(x)
         return x
+
+    @torch.inference_mode()
+    def decode(self, x, use_graph=None):
+        """latent -> wav; the latent is snapped to the 1/9 grid first (:403-407).
+        use_graph (default: on for the split-plane path): the ~44 launches of a decode are captured once per input shape into a
+        HIP graph and replayed — stage 2 decodes window after window of one shape (reason_tokenizer.py:277-290), and issued one by
+        one from Python the chain is ~0.7 ms of host time against ~1.1 ms of kernels: the next kernel speed-up would have been
+        host-bound."""
+        if not self._ready:
+            self.prepare()
+        x = x.float().contiguous()
+        if use_graph is None:
+            use_graph = self._dec_tc and os.environ.get("UA2_CODEC_NO_GRAPH") is None
+        if not use_graph or torch.cuda.is_current_stream_capturing():
+            return self._decode_impl(x)
+        key = tuple(x.shape)
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 8:                                # bounded: a caller with ever-changing shapes replays nothing
+                return self._decode_impl(x)
+            x_in = torch.empty_like(x)
+            x_in.copy_(x)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                             # warm-up outside capture: one-time kernel attributes, allocator pools
+                self._decode_impl(x_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                y = self._decode_impl(x_in)
+            g = self._graphs[key] = (graph, x_in, y)
+        graph, x_in, y = g
+        x_in.copy_(x)
+        graph.replay()
+        return y.clone()
