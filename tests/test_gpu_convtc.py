@@ -201,3 +201,38 @@ def test_tc_rejects_what_it_cannot_serve():
     x17 = ops.TC(torch.zeros(2, 1, 64, 48, dtype=torch.bfloat16, device="cuda"))
     with pytest.raises(Ua2Error, match="multiple of 32"):
         ops.conv1d_tc(x17, hi, lo, 3, 32, pad_left=2, Tout=64)
+
+
+@pytest.mark.parametrize("case,variant", [
+    ((64, 64, 7, 9, 30000, 1, False, True, 1, 1, 0, False), 2), ((128, 128, 7, 5, 9000, 1, False, True, 1, 1, 0, False), 2),
+    ((512, 512, 7, 3, 1500, 1, False, False, 1, 1, 0, False), 2), ((512, 512, 1, 1, 1500, 1, True, False, 1, 1, 0, False), 2),
+    ((64, 64, 7, 9, 60000, 1, False, True, 1, 1, 0, False), 3), ((32, 32, 7, 7, 120000, 1, False, True, 1, 1, 0, False), 3)])
+def test_lds_dma_kernels_are_repeatable_under_foreign_traffic(case, variant):
+    """Race screen for the hand-counted LDS-DMA waits of the pipelined and the big-tile kernel (an early fragment read or a
+    late window would show up as rare wrong tiles): 25 launches of the same problem, with unrelated traffic on another stream
+    shifting the arrival times, give the plain kernel's bits every time."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import ACT_PRELU
+    Cin, Cout, K, dil, T, B, residual, fused, rep, phases, trim, pca = case
+    g = torch.Generator().manual_seed(1234 + Cin + K)
+    x = ops.tc_pack(_representable(torch.randn(B, Cin, T, generator=g)).cuda())
+    w = (torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5).cuda()
+    hi, lo = ops.pack_conv_weight_x3(w)
+    kw = dict(dilation=dil, pad_left=dil * (K - 1), Tout=T, bias=torch.randn(Cout, generator=g).cuda(), post_act=ACT_PRELU,
+              post_alpha=torch.tensor([0.2]).cuda())
+    if fused:
+        w2 = (torch.randn(Cout, Cout, 1, generator=g) / Cout ** 0.5).cuda()
+        kw["fused2"] = (*ops.pack_conv_weight_x3(ops.tc_w2_order(w2)), torch.randn(Cout, generator=g).cuda(), torch.tensor([0.3]).cuda())
+    elif residual:
+        kw["residual"] = ops.tc_pack(_representable(torch.randn(B, Cout, T, generator=g)).cuda())
+    ref = ops.conv1d_tc(x, hi, lo, K, Cout, variant=1, **kw).planes
+    torch.cuda.synchronize()
+    noise = torch.randn(4096, 4096, device="cuda")
+    side = torch.cuda.Stream()
+    for i in range(25):
+        with torch.cuda.stream(side):
+            for _ in range(1 + i % 3):
+                noise = noise * 1.0001 + 0.5
+        got = ops.conv1d_tc(x, hi, lo, K, Cout, variant=variant, **kw).planes
+        assert torch.equal(got, ref), f"launch {i}"
+    torch.cuda.synchronize()
