@@ -284,3 +284,68 @@ def test_batched_tts_retires_sequences_at_their_own_eos():
     assert sizes[0] == 5 and sizes == sorted(sizes, reverse=True) and sizes[-1] < 5
     assert sorted(b for group in model.retired for b in group) == [0, 1, 2, 3, 4]
     assert model.sampling == (1, 0.9)
+
+
+class _ScriptedPairModel(_ScriptedBatchModel):
+    """As _ScriptedBatchModel, for the classifier-free-guidance pair layout: utterance b owns rows (2b, 2b + 1); the scripted
+    stream is what the conditional row logs, the unconditional row logs the same ids (both continue from the pair's sample)."""
+
+    def begin_ragged(self, prompts):
+        assert len(prompts) % 2 == 0 and len(prompts) <= self._st["B"]
+        self.prompt_lens = [int(t.shape[0]) for t, _ in prompts]
+        self.prompts = prompts
+        self.rows = list(range(len(prompts)))                   # row -> original row; utterance = row // 2
+        self.cursor = {b: 0 for b in range(len(prompts) // 2)}
+
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
+        assert batch == len(self.rows) and mode == 2 and batch % 2 == 0
+        assert all(self.rows[r] + 1 == self.rows[r + 1] and self.rows[r] % 2 == 0 for r in range(0, batch, 2)), "pairs stay adjacent"
+        self.calls.append((n, batch))
+        out = torch.zeros(n, batch, 9, dtype=torch.int32)
+        for r in range(0, batch, 2):
+            u = self.rows[r] // 2
+            s = self.streams[u][self.cursor[u]:self.cursor[u] + n]
+            out[:s.shape[0], r] = s
+            out[:s.shape[0], r + 1] = s
+            self.cursor[u] += n
+        return out
+
+
+def test_batched_tts_with_classifier_free_guidance_keeps_row_pairs():
+    """round 4: generate_tts_batch under --use_cfg — utterance b = rows (2b, 2b + 1) = (prompt, its all-pad twin of the same
+    shape, tts_task.py:175-205), frames in mode 2, bookkeeping from the conditional row, a finished utterance retires BOTH rows
+    and the survivors' pairs stay adjacent; results equal the single-utterance loop's."""
+    from uniaudio2_amd.evaluation.tts_task import Generator
+    g = torch.Generator().manual_seed(12)
+    shapes = [(4, 7), (12, 3), (2, 20)]
+    streams, frames_list = [], []
+    for n_reason, n_sem in shapes:
+        frames = [torch.randint(0, 4096, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_reason)]
+        frames.append(torch.full((1, 8), TA.reason_eos, dtype=torch.int32))
+        frames += [torch.randint(4100, 12292, (1, 8), generator=g, dtype=torch.int32) for _ in range(n_sem)]
+        frames.append(torch.full((1, 8), TA.semantic_eos + TA.audio_reason_card, dtype=torch.int32))
+        frames += [torch.randint(0, 100, (1, 8), generator=g, dtype=torch.int32) for _ in range(48)]
+        log = torch.zeros(len(frames), 9, dtype=torch.int32)
+        log[:, 1:] = torch.cat(frames)
+        streams.append(log); frames_list.append(frames)
+    model = _ScriptedPairModel(streams)
+    gen = Generator.__new__(Generator)
+    for k, v in vars(TA).items():
+        setattr(gen, k, v)
+    gen.empty_token, gen.is_cfg, gen._model, gen.device = 0, True, model, torch.device("cpu")
+    gen.special_token_dict = gen.get_special_token()
+    texts = [torch.arange(3 + i) for i in range(len(shapes))]
+    out = gen.generate_tts_batch(torch.tensor([128000, 1, 128001]), "tts", texts, topk=1)
+    # prompts went in as (conditional, unconditional) pairs of equal shape; the twin is all text padding
+    assert model.prompt_lens == [n for i in range(len(shapes)) for n in (3 + 2 + 3 + i, 3 + 2 + 3 + i)]
+    for p in range(len(shapes)):
+        assert bool((model.prompts[2 * p + 1][0][:, -1] == TA.text_pad_token).all()) and not bool((model.prompts[2 * p][0][:, -1] == TA.text_pad_token).all())
+    for (r, s), frames in zip(out, frames_list):
+        rr, rs = reference_loop(frames, TA.reason_eos, TA.semantic_eos, TA.audio_reason_card)
+        assert torch.equal(r, rr) and torch.equal(s, rs)
+    sizes = [b for _, b in model.calls]
+    assert sizes[0] == 6 and all(b % 2 == 0 for b in sizes) and sizes == sorted(sizes, reverse=True) and sizes[-1] < 6
+    assert sorted(b for group in model.retired for b in group) == [0, 1, 2, 3, 4, 5]
+    # a missing or mis-shaped twin is refused before anything runs
+    with pytest.raises(ValueError):
+        gen._generate_audio_tokens_batch([gen.prepare_tts_task(torch.tensor([128000, 1, 128001]), texts[0])], cfg_prompts=None)
