@@ -1,0 +1,112 @@
+"""Static checks on the compiled gfx950 code of the split-plane conv kernels (ua2_convtc.hip).
+
+The pipelined and big-tile kernels fill their LDS window images with LDS-DMA (global_load_lds_dwordx4), which the
+compiler's s_waitcnt bookkeeping does not see, and wait for it with hand-counted `s_waitcnt vmcnt(N)` in inline asm
+(N = the vector-memory loads the wave issues AFTER the DMA batch: vmcnt retires in order, so "at most N outstanding"
+means the batch has landed).  The count is an invariant of the generated code, not of the source: a compiler that
+hoists, sinks or drops one of the counted loads silently turns a wait into a race that a run-time test only catches
+by luck.  This test compiles the file to assembly and checks the invariant where it lives:
+
+  * every inline-asm `s_waitcnt vmcnt(N)` has at least N vector loads between the last LDS-DMA before it and itself
+    (fewer younger loads than N = the wait can return while the DMA is still in flight);
+  * every pipelined / big-tile kernel keeps at least one such wait with N > 0 (the pipeline has not collapsed into
+    a full drain per unit: the performance property the kernels exist for);
+  * no kernel of the file uses scratch memory (a register spill costs the fused kernels ~2x, round-4 notes §2).
+
+Needs hipcc (cross-compiles without a GPU); ~10 s.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "..", "uniaudio2_amd", "csrc", "ua2_convtc.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "convtc.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _kernels(asm_text):
+    """name -> list of (instruction, inside_inline_asm)"""
+    out = {}
+    for m in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)s_endpgm", asm_text, re.S | re.M):
+        ins, inasm = [], False
+        for line in m.group(2).splitlines():
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                inasm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                inasm = False
+                continue
+            t = t.split(";")[0].strip()
+            if t and not t.startswith("."):
+                ins.append((t, inasm))
+        out[m.group(1)] = ins
+    return out
+
+
+def _hand_waits(ins):
+    """[(N, vector loads issued after the last LDS-DMA before the wait, saw a DMA)] for the inline-asm waits"""
+    res = []
+    for i, (t, inasm) in enumerate(ins):
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+        if not (m and inasm):
+            continue
+        n, loads, saw, j = int(m.group(1)), 0, False, i - 1
+        while j >= 0:
+            u = ins[j][0]
+            if u.startswith("global_load_lds"):
+                saw = True
+                break
+            if u.startswith("s_barrier"):
+                break
+            if re.match(r"(global|buffer|flat)_load_", u):
+                loads += 1
+            j -= 1
+        res.append((n, loads, saw))
+    return res
+
+
+def test_hand_counted_waits_cover_the_dma(asm):
+    ks = _kernels(asm)
+    staged = {k: v for k, v in ks.items() if "convtc_pipe_kernel" in k or "convtc_big_kernel" in k}
+    assert len(staged) >= 10, sorted(ks)
+    for name, ins in staged.items():
+        waits = _hand_waits(ins)
+        assert waits, name
+        for n, loads, saw in waits:
+            if n > 0:
+                assert saw, f"{name}: vmcnt({n}) with no LDS-DMA in front of it"
+                assert loads >= n, f"{name}: vmcnt({n}) but only {loads} loads are younger than the DMA batch"
+        if "convtc_pipe_kernel" in name:
+            assert any(n > 0 for n, _, _ in waits), f"{name}: every unit drains the queue (pipeline collapsed)"
+
+
+def test_dma_is_issued_through_inline_asm(asm):
+    """The builtin makes the waitcnt pass treat every later dependency as vmcnt(0) lgkmcnt(0) (round-4 notes §2,
+    finding A); the kernels issue the DMA as inline asm so the compiler's own waits stay partial."""
+    for name, ins in _kernels(asm).items():
+        for t, inasm in ins:
+            if t.startswith("global_load_lds"):
+                assert inasm, f"{name}: LDS-DMA emitted by the compiler, not by lds_dma16"
+
+
+def test_no_scratch_and_registers_fit(asm):
+    names = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", asm)
+    vg = dict(re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", asm))
+    assert len(names) >= 20
+    for name, scratch in names:
+        assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
+        assert int(vg[name]) <= 256, name
