@@ -301,6 +301,100 @@ def test_scaled_norm_handover_is_kernel_and_row_count_invariant(linear_mode):
     assert torch.equal(gm[::9], g1[:8])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_staged_epilogue_equals_the_per_element_epilogue(dtype, linear_mode):
+    """Round 4: the tiled kernel's epilogues (STORE / RESIDUAL / SWIGLU / GELU) walk a wave's patch through LDS in 16-byte
+    pieces.  Same operations on every value as the per-element form (UA2_GEMM_OLD_EPI), so the same bits: every output of every
+    option the epilogues have (bias, LayerScale, both activations of each kind, packed operand hand-off, the scaled-norm
+    hand-over on both sides), on every tile size and both operand rings, at ragged row counts."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import (EPI_GELU, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, GATE_SIGMOID_SECOND, GELU_TANH, PRO_CAST, PRO_NORM)
+    PRO_SCALED = 4
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(77)
+    N, K = 1536, 1056
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=g)).to(dev)
+    p0, p1 = ops.pack_linear(mk(N, K, s=K ** -0.5), dtype), ops.pack_linear(mk(N, K, s=K ** -0.5), dtype)
+    bias, bias1, gate, nw_next, nw = mk(N, s=0.3), mk(N, s=0.3), mk(N, s=0.5), 1.0 + mk(N, s=0.2), 1.0 + mk(K, s=0.1)
+    Mmax = 1000
+    x, res = mk(Mmax, K), mk(Mmax, N, s=2.0)
+
+    def run(M, epi, old, **opt):
+        if old:
+            os.environ["UA2_GEMM_OLD_EPI"] = "1"
+        else:
+            os.environ.pop("UA2_GEMM_OLD_EPI", None)
+        outs = {}
+        kw = dict(dtype=dtype, M=M, N=N, K=K, w0=p0, epilogue=epi, workspace=ops.linear_workspace(dtype, M, K, dev))
+        if opt.get("scaled"):
+            xp, xs = scaled_operand(M)
+            kw.update(prologue=PRO_SCALED, x_ssq=xs, x_packed=xp, eps=1e-5)
+            kw.pop("workspace")
+        else:
+            kw.update(prologue=PRO_NORM, x=x[:M].contiguous(), norm_w=nw, eps=1e-5)
+        if opt.get("bias"):
+            kw.update(bias=bias, bias1=bias1 if epi == EPI_SWIGLU else None)
+        if epi == EPI_SWIGLU:
+            kw.update(w1=p1, act_kind=opt.get("act", 0))
+        if epi == EPI_GELU:
+            kw.update(act_kind=opt.get("act", 0))
+        if epi == EPI_RESIDUAL:
+            kw.update(resid=res[:M].contiguous(), out_scale=gate if opt.get("gate") else None)
+        if opt.get("y", True):
+            outs["y"] = torch.zeros(M, N, device=dev)
+            kw.update(y=outs["y"])
+        if opt.get("packed"):
+            outs["packed"] = torch.zeros((M + 15) // 16 * 16 * N, dtype=dtype, device=dev)
+            kw.update(y_packed=outs["packed"])
+        if opt.get("handover"):
+            outs["ssq"] = torch.zeros(M, N // 16, device=dev)
+            outs["h"] = torch.zeros(M, N, dtype=dtype, device=dev)
+            kw.update(y_norm_w=nw_next, y_ssq=outs["ssq"], y_h=outs["h"], ldh=N)
+        ops.linear(**kw)
+        torch.cuda.synchronize()
+        return outs
+
+    pk = ops.pack_linear(mk(K, K, s=K ** -0.5), dtype)
+    made = {}
+
+    def scaled_operand(M):
+        """operand of a UA2_PRO_SCALED launch as a producer hands it over: fragment order + per-16-column sums of squares"""
+        if M not in made:
+            os.environ["UA2_GEMM_OLD_EPI"] = "1"
+            linear_mode(5, 4, False)
+            xp = torch.zeros((M + 15) // 16 * 16 * K, dtype=dtype, device=dev)
+            xs = torch.zeros(M, K // 16, device=dev)
+            ops.linear(dtype=dtype, M=M, N=K, K=K, w0=pk, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x[:M].contiguous(),
+                       y=torch.empty(M, K, device=dev), resid=x[:M].contiguous(), y_norm_w=nw, y_ssq=xs, y_packed=xp,
+                       workspace=ops.linear_workspace(dtype, M, K, dev))
+            torch.cuda.synchronize()
+            made[M] = (xp, xs)
+        return made[M]
+
+    cases = [(EPI_STORE, dict()), (EPI_STORE, dict(bias=True)),
+             (EPI_RESIDUAL, dict()), (EPI_RESIDUAL, dict(bias=True, gate=True)),
+             (EPI_SWIGLU, dict()), (EPI_SWIGLU, dict(bias=True, act=GATE_SIGMOID_SECOND, packed=True)), (EPI_SWIGLU, dict(packed=True, y=False)),
+             (EPI_GELU, dict(bias=True)), (EPI_GELU, dict(act=GELU_TANH, packed=True, y=False))]
+    if dtype == torch.bfloat16:
+        cases += [(EPI_STORE, dict(handover=True)), (EPI_RESIDUAL, dict(handover=True, gate=True, packed=True)),
+                  (EPI_STORE, dict(scaled=True)), (EPI_SWIGLU, dict(scaled=True))]
+    try:
+        for epi, opt in cases:
+            for M in (1000, 200, 77):
+                for bmt, reg in ((8, False), (4, False), (2, False), (8, True), (2, True)):
+                    if opt.get("scaled"):
+                        scaled_operand(M)
+                    linear_mode(5, bmt, reg)
+                    want, got = run(M, epi, True, **opt), run(M, epi, False, **opt)
+                    assert want.keys() == got.keys() and len(want) > 0
+                    for k in want:
+                        assert torch.equal(want[k].view(torch.int16 if want[k].dtype == torch.bfloat16 else torch.int32),
+                                           got[k].view(torch.int16 if got[k].dtype == torch.bfloat16 else torch.int32)), (epi, opt, M, bmt, reg, k)
+                    assert any(t.float().abs().sum().item() > 0 for t in got.values())
+    finally:
+        os.environ.pop("UA2_GEMM_OLD_EPI", None)
+
+
 @pytest.mark.parametrize("M,N,K,bmt", [(6272, 1024, 3072, 8), (2048, 3072, 8192, 4), (1000, 1536, 6144, 2), (333, 384, 1056, 2)])
 def test_tiled_gemm_ring_is_repeatable(M, N, K, bmt, linear_mode):
     """Race screen for the LDS-DMA operand ring (hand-counted vmcnt + raw s_barrier): 25 launches of the same problem on a

@@ -39,8 +39,11 @@ for M in MS:
             if (mode == 2 and M > 512) or (mode == 4 and M > 1024):
                 out.append(float("nan")); continue
             lib.ua2_debug_force_general_linear(mode)
-            args = [ops.linear(dtype=dt, M=M, N=N, K=K, w0=a, w1=b, prologue=pro, epilogue=epi, x=x, norm_w=nw, y=y,
-                               resid=res if epi == EPI_RESIDUAL else None, workspace=ws, launch=False) for a, b in zip(w0, w1)]
+            if os.environ.get("UA2_PREPACKED"): pro = PRO_CAST
+            pre = os.environ.get("UA2_PREPACKED") and mode == 5   # operand already in fragment order: the GEMM launch alone
+            args = [ops.linear(dtype=dt, M=M, N=N, K=K, w0=a, w1=b, prologue=pro, epilogue=epi, x=None if pre else x, norm_w=nw, y=y,
+                               resid=res if epi == EPI_RESIDUAL else None, workspace=None if pre else ws, x_packed=ws if pre else None,
+                               launch=False) for a, b in zip(w0, w1)]
             ops.linear_chain_timed(args, 2)
             out.append(ops.linear_chain_timed(args, 5))
         lib.ua2_debug_force_general_linear(0)

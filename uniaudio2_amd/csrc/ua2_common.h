@@ -105,6 +105,34 @@ __device__ __forceinline__ void store_packed_operand(void* base, int m, int k, i
   store_elem<DT>(base, elem, v);
 }
 
+// four consecutive elements (row m, columns k .. k + 3, k % 4 == 0) of the same layout: one 8-byte (bf16) / 16-byte (fp32) store
+template <int DT>
+__device__ __forceinline__ void store_packed4(void* base, int m, int k, int nchunks, const float4& v) {
+  constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL;
+  const int c = k / KC, r = k - c * KC, g = r / EPL, e = r - g * EPL;
+  const size_t elem = (((size_t)(m >> 4) * nchunks + c) * 64 + g * 16 + (m & 15)) * EPL + e;
+  if constexpr (DT == UA2_BF16) {
+    uint2 p;
+    p.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    p.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = p;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
+  }
+}
+// four consecutive elements of a row-major array of the launch dtype
+template <int DT>
+__device__ __forceinline__ void store_row4(void* base, size_t i, const float4& v) {
+  if constexpr (DT == UA2_BF16) {
+    uint2 p;
+    p.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    p.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + i) = p;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + i) = v;
+  }
+}
+
 // Page-table column of position `pos`: linear caches index by pos / 64; ring caches (kv.ring_pages > 0: the streaming
 // transformers of the Moshi family, llm_modules/transformer.py:211-278) wrap over ring_pages pages.
 __device__ __forceinline__ int ua2_page_slot(const ua2_kv_geom& kv, int pos) {

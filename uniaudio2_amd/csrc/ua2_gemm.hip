@@ -99,12 +99,37 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
 constexpr int kKS = 2;      // chunks per LDS stage
 constexpr int kGroupM = 8;  // row-blocks per L2 patch
 
+// Slots of the LDS-DMA ring, per row-tile count.  A workgroup keeps slots - 1 chunks in flight; with an L2 round trip of
+// ~0.5 us under load the ring delivers (slots - 1) x TILES KiB per round trip, which is what bounds the small-M launches
+// (time per chunk flat at ~0.16 us = one round trip / 3 with four slots: tools/ubench/gemm_shapes.py, profiles/r4_notes.md §9).
+#ifndef UA2_GEMM_RING_2
+#define UA2_GEMM_RING_2 4
+#endif
+#ifndef UA2_GEMM_RING_4
+#define UA2_GEMM_RING_4 4
+#endif
+#ifndef UA2_GEMM_RING_8
+#define UA2_GEMM_RING_8 4
+#endif
+// Timing-only knock-outs of the LDS-DMA main loop (tools/ubench/build_alt.sh ... -DUA2_GEMM_DBG=<bits>; wrong results):
+// 1 no ring refills after the prologue, 2 no MFMAs, 4 no fragment reads, 8 no workgroup barrier per chunk, 16 no epilogue,
+// 32 no main loop at all (prologue fill, then straight to the epilogue).
+#ifndef UA2_GEMM_DBG
+#define UA2_GEMM_DBG 0
+#endif
+#if UA2_GEMM_DBG & 8
+#define UA2_GEMM_BAR "s_nop 0"
+#else
+#define UA2_GEMM_BAR "s_barrier"
+#endif
+constexpr int ring_slots(int bmt) { return bmt == 2 ? UA2_GEMM_RING_2 : (bmt == 4 ? UA2_GEMM_RING_4 : UA2_GEMM_RING_8); }
+
 // GL: the operand ring is filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight from L2 into the
 // ring) instead of global -> registers -> ds_write_b128: see the main loop.  !GL (register staging) serves the hand-over
 // instantiations (HO) and the UA2_GEMM_NO_GLDS experiment hook.
 template <int DT, int EPI, int kBMT, bool HO, bool GL>
 __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ? 3 : 2) void gemm_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int nw,
-                                                      const int mblocks, const int nblocks, const int group_m) {
+                                                      const int mblocks, const int nblocks, const int group_m, const int flags) {
   constexpr int KC = Elem<DT>::KC;
   constexpr int NWV = 4;                    // waves: 2 down the rows x 2 across the columns
   constexpr int kWM = kBMT / (NWV / 2);     // row tiles per wave
@@ -114,13 +139,16 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
   constexpr int TILES = kBMT + NT * BNT;            // fragment streams per chunk (16)
   constexpr int KS = GL ? 1 : kKS;          // chunks per ring slot
   constexpr int LOADS = (TILES * KS + NWV - 1) / NWV;   // 16-byte pieces per thread per stage; 10 blocks over 4 waves: the last two are requested twice (same bytes, same place)
-  constexpr int NBUF = GL ? 4 : 2;                  // ring slots of TILES x KS KiB
+  constexpr int NBUF = GL ? ring_slots(kBMT) : 2;   // ring slots of TILES x KS KiB
   extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
   u32x4 (*lds)[TILES][KS][64] = reinterpret_cast<u32x4 (*)[TILES][KS][64]>(gemm_smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nchunks = (a.K + KC - 1) / KC;
+  // K split (gridDim.y slabs): slab kz multiplies chunks [c_lo, c_hi) of K
+  const int nchunks_all = (a.K + KC - 1) / KC;
+  const int c_lo = (int)(((long)blockIdx.y * nchunks_all) / gridDim.y), c_hi = (int)(((long)(blockIdx.y + 1) * nchunks_all) / gridDim.y);
+  const int nchunks = c_hi - c_lo;
   const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
 
   // workgroup id -> (row-block pm, column-block pn): XCD x gets a contiguous id range (ids are dealt
@@ -142,11 +170,11 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
     const u32x4* p;
     if (tile < kBMT) {
       const int mt = min(pm * kBMT + tile, mtiles - 1);
-      p = apack + (size_t)mt * nchunks * 64;
+      p = apack + ((size_t)mt * nchunks_all + c_lo) * 64;
     } else {
       const int idx = tile - kBMT, mat = idx / BNT;
       const int nt = min(pn * BNT + idx % BNT, ntiles - 1);
-      p = reinterpret_cast<const u32x4*>(mat ? a.w1 : a.w0) + (size_t)nt * nchunks * 64;
+      p = reinterpret_cast<const u32x4*>(mat ? a.w1 : a.w0) + ((size_t)nt * nchunks_all + c_lo) * 64;
     }
     src[j] = p + (size_t)kc * 64 + lane;
   }
@@ -241,30 +269,34 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) f[kWM + t * WN + ni] = lds[slot][kBMT + t * BNT + wn * WN + ni][0][lane];
     };
+    int slot_c = 0;                               // c % NBUF, kept as a counter (NBUF need not be a power of two)
     auto step = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], int c) {
       // `cur` rides through the statement as in/out operands: the compiler then places its own wait for those reads HERE (they
       // were issued a chunk ago) instead of a conservative lgkmcnt(0) behind the next chunk's reads, in front of the first MFMA
       static_assert(NF == 8 || NF == 6 || NF == 5, "operand lists below");
       if constexpr (NF == 8) {
-        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
+        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\t" UA2_GEMM_BAR
                      : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7])
-                     : "n"(2 * LOADS)
+                     : "n"((UA2_GEMM_DBG & 1) ? 0 : (NBUF - 2) * LOADS)
                      : "memory");
       } else if constexpr (NF == 6) {
-        asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
+        asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\t" UA2_GEMM_BAR
                      : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5])
-                     : "n"(2 * LOADS)
+                     : "n"((UA2_GEMM_DBG & 1) ? 0 : (NBUF - 2) * LOADS)
                      : "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier"
+        asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\t" UA2_GEMM_BAR
                      : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4])
-                     : "n"(2 * LOADS)
+                     : "n"((UA2_GEMM_DBG & 1) ? 0 : (NBUF - 2) * LOADS)
                      : "memory");
       }
       retire_at(c);                              // in front of the reads: everything behind it is one block
-      read(nxt, (c + 1) & 3);
+      const int slot_n = slot_c + 1 == NBUF ? 0 : slot_c + 1;
+      if constexpr (!(UA2_GEMM_DBG & 4)) read(nxt, slot_n);
       __builtin_amdgcn_sched_barrier(0);
-      dma(c + 4, c & 3);
+      if constexpr (!(UA2_GEMM_DBG & 1)) dma(c + NBUF, slot_c);
+      slot_c = slot_n;
+      if constexpr (!(UA2_GEMM_DBG & 2)) {
 #pragma unroll
       for (int mi = 0; mi < kWM; ++mi) {
         AFrag<DT> af;
@@ -274,6 +306,7 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) af.mma(cur[kWM + t * WN + ni], chain[t][mi][ni]);
       }
+      }
       constexpr int MF = kWM * NT * WN;          // MFMAs of the chunk
 #pragma unroll
       for (int g = 0; g < LOADS; ++g) {
@@ -282,10 +315,11 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
       }
     };
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dma(t, t);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LOADS) : "memory");
+    for (int t = 0; t < NBUF; ++t) dma(t, t);
+    static_assert((NBUF - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 1) * LOADS) : "memory");
     read(fr[0], 0);
-    for (int c = 0; c < nchunks; c += 2) {
+    for (int c = 0; c < ((UA2_GEMM_DBG & 32) ? 0 : nchunks); c += 2) {
       step(fr[0], fr[1], c);
       if (c + 1 < nchunks) step(fr[1], fr[0], c + 1);
     }
@@ -342,6 +376,10 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
     }
   }
   while (seg <= nw) { retire(); ++seg; }         // the last range (and any empty ones after it)
+  if constexpr ((UA2_GEMM_DBG & 16) != 0) {
+    if (tot[0][0][0][0] == 1.2345f) a.y[0] = 0.f;   // keeps the loop alive
+    return;
+  }
 
   // ---- QKV epilogue, staged (half-split RoPE, head_size 128: the workgroup's 128 columns are exactly one head) ----
   // The generic epilogue below issues, per output element, two scalar loads of the RoPE table and one 4-byte (q) or
@@ -512,6 +550,111 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
       }
     }
     return;
+  }
+
+  // ---- staged epilogue (STORE / RESIDUAL / SWIGLU / GELU on whole wave patches) ----
+  // Fed from the accumulator registers, the per-element epilogue below stores 4 bytes per lane into 64-byte runs, loads the
+  // residual the same way and re-reads bias / out_scale / the following norm's weight once per element: 17-31 % of a launch at
+  // 6272 rows and 30-45 % at the DiT's 1000 (tools/ubench/gemm_knock2.sh, profiles/r4_notes.md §9).  Here every wave parks its
+  // patch (kWM x 16 rows x 64 columns, fp32) in the idle operand ring in natural order and walks it by rows: a lane owns 4
+  // consecutive columns, so results, residual, bias and scales move as 16-byte pieces in 256-byte runs (the packed operand
+  // hand-off as 8-byte pieces).  Every value goes through the same operations in the same order as linear_epilogue: same bits
+  // (tests/test_gpu_invariance.py compares the two forms and the decode kernel).  Launches with partial arg-max outputs or with
+  // N not a multiple of the wave's column span take the per-element form.
+  if constexpr (EPI != UA2_EPI_QKV_ROPE) {
+    constexpr int SPAN = WN * 16;                        // columns of one matrix a wave owns: 64 (32 for SWIGLU)
+    if ((flags & 1) && a.N % SPAN == 0 && !a.part_max) {
+      __syncthreads();                                   // every wave is done with the operand ring
+      float* patch = reinterpret_cast<float*>(gemm_smem) + (size_t)wave * (kWM * 16) * 64;
+      {
+        const int colq = lane & 15, gq = lane >> 4;
+#pragma unroll
+        for (int mi = 0; mi < kWM; ++mi)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) patch[(mi * 16 + 4 * gq + r) * 64 + (t * WN + ni) * 16 + colq] = tot[t][mi][ni][r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int LPR = SPAN / 4;                      // lanes per row: 16 (8 for SWIGLU: a 16-lane group walks two rows at once)
+      constexpr int RPI = 64 / LPR;                      // rows per iteration: 4 (8)
+      constexpr int ITERS = kWM * 16 / RPI;
+      const int j = lane & (LPR - 1), rsub = lane / LPR;
+      const int n0 = (pn * BNT + wn * WN) * 16 + 4 * j;  // this lane's 4 columns (of each matrix)
+      if (n0 >= a.N) return;                             // wave-uniform (N % SPAN == 0)
+      const int mbase = (pm * kBMT + wm * kWM) * 16;
+      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 b0 = zero4, b1 = zero4, os4 = make_float4(1.f, 1.f, 1.f, 1.f), nw4 = zero4;
+      if (a.bias) b0 = *reinterpret_cast<const float4*>(a.bias + n0);
+      if constexpr (NT == 2) { if (a.bias && a.bias1) b1 = *reinterpret_cast<const float4*>(a.bias1 + n0); }
+      if constexpr (EPI == UA2_EPI_RESIDUAL) { if (a.out_scale) os4 = *reinterpret_cast<const float4*>(a.out_scale + n0); }
+      if constexpr (HO) { if (a.y_norm_w) nw4 = *reinterpret_cast<const float4*>(a.y_norm_w + n0); }
+      float4 res[ITERS];
+      if constexpr (EPI == UA2_EPI_RESIDUAL) {           // every residual piece of the patch requested before the first store
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int m = mbase + it * RPI + rsub;
+          res[it] = *reinterpret_cast<const float4*>(a.resid + (size_t)min(m, a.M - 1) * a.ldr + n0);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int prow = it * RPI + rsub;
+        const int m = mbase + prow;
+        float rs = 1.f;
+        if (a.prologue == UA2_PRO_SCALED) {              // the row's scale, by the 16 lanes of a group together
+          if constexpr (NT == 1) {
+            rs = scaled_rstd_row(a, m, lane & 15);
+          } else {                                       // the group's two rows one after the other; each half keeps its own
+            const int mg = mbase + it * RPI + 2 * (lane >> 4);
+            const float ra = scaled_rstd_row(a, mg, lane & 15), rb = scaled_rstd_row(a, mg + 1, lane & 15);
+            rs = (rsub & 1) ? rb : ra;
+          }
+        }
+        if (m >= a.M) continue;
+        float4 v0 = *reinterpret_cast<const float4*>(patch + prow * 64 + 4 * j);
+        float4 v1 = zero4;
+        if constexpr (NT == 2) v1 = *reinterpret_cast<const float4*>(patch + prow * 64 + SPAN + 4 * j);
+        if (a.prologue == UA2_PRO_SCALED) {
+          v0.x = __fmul_rn(v0.x, rs); v0.y = __fmul_rn(v0.y, rs); v0.z = __fmul_rn(v0.z, rs); v0.w = __fmul_rn(v0.w, rs);
+          if constexpr (NT == 2) { v1.x = __fmul_rn(v1.x, rs); v1.y = __fmul_rn(v1.y, rs); v1.z = __fmul_rn(v1.z, rs); v1.w = __fmul_rn(v1.w, rs); }
+        }
+        if (a.bias) {
+          v0.x = __fadd_rn(v0.x, b0.x); v0.y = __fadd_rn(v0.y, b0.y); v0.z = __fadd_rn(v0.z, b0.z); v0.w = __fadd_rn(v0.w, b0.w);
+          if constexpr (NT == 2) { v1.x = __fadd_rn(v1.x, b1.x); v1.y = __fadd_rn(v1.y, b1.y); v1.z = __fadd_rn(v1.z, b1.z); v1.w = __fadd_rn(v1.w, b1.w); }
+        }
+        float4 out = v0;
+        if constexpr (EPI == UA2_EPI_RESIDUAL) {
+          if (a.out_scale) { out.x = __fmul_rn(os4.x, v0.x); out.y = __fmul_rn(os4.y, v0.y); out.z = __fmul_rn(os4.z, v0.z); out.w = __fmul_rn(os4.w, v0.w); }
+          out.x = __fadd_rn(out.x, res[it].x); out.y = __fadd_rn(out.y, res[it].y); out.z = __fadd_rn(out.z, res[it].z); out.w = __fadd_rn(out.w, res[it].w);
+        } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+          out.x = ua2_act_glu(a, v0.x, v1.x); out.y = ua2_act_glu(a, v0.y, v1.y); out.z = ua2_act_glu(a, v0.z, v1.z); out.w = ua2_act_glu(a, v0.w, v1.w);
+        } else if constexpr (EPI == UA2_EPI_GELU) {
+          out.x = ua2_act_gelu(a, v0.x); out.y = ua2_act_gelu(a, v0.y); out.z = ua2_act_gelu(a, v0.z); out.w = ua2_act_gelu(a, v0.w);
+        }
+        if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n0) = out;
+        if constexpr (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_GELU) {
+          if (a.y_packed) store_packed4<DT>(a.y_packed, m, n0, a.N / KC, out);
+        }
+        if constexpr (HO && (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL)) {
+          if (a.y_norm_w) {
+            // ssq_tile16's tree over the tile's 16 columns (xor 1, 2, 4, 8) with 4 columns per lane: two levels in registers, two across lanes
+            float s = __fadd_rn(__fmaf_rn(out.x, out.x, __fmul_rn(out.y, out.y)), __fmaf_rn(out.z, out.z, __fmul_rn(out.w, out.w)));   // first level fused, as ssq_tile16 spells it
+            s = __fadd_rn(s, __shfl_xor(s, 1));
+            s = __fadd_rn(s, __shfl_xor(s, 2));
+            if (a.y_ssq && (j & 3) == 0) a.y_ssq[(size_t)m * ((a.N + 15) >> 4) + (n0 >> 4)] = s;
+            const float4 h = make_float4(__fmul_rn(out.x, nw4.x), __fmul_rn(out.y, nw4.y), __fmul_rn(out.z, nw4.z), __fmul_rn(out.w, nw4.w));
+            if (a.y_h) store_row4<DT>(a.y_h, (size_t)m * a.ldh + n0, h);
+            if (a.y_packed) store_packed4<DT>(a.y_packed, m, n0, a.N / KC, h);
+          }
+        }
+      }
+      return;
+    }
   }
 
   // ---- epilogue: lane holds D[row = 4*(lane >> 4) + r][col = lane & 15] of each 16 x 16 tile ----
@@ -696,9 +839,12 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
     constexpr auto kern = gemm_kernel<DT, EPI, B, H, G>;
     ua2_allow_big_lds<kern>();
     const int mblocks = ua2_ceil_div(mtiles, B);
-    size_t smem = (size_t)(G ? 4 : 2 * kKS) * TILES * 1024;
-    if (EPI == UA2_EPI_QKV_ROPE) smem = std::max(smem, (size_t)4 * (B / 2) * 16 * 64 * sizeof(float));   // the staged epilogues park a 64-column patch per wave in the ring
-    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks), dim3(256), smem, s, a, ap, nw, mblocks, nblocks, group_m);
+    size_t smem = (size_t)(G ? ring_slots(B) : 2 * kKS) * TILES * 1024;
+    smem = std::max(smem, (size_t)4 * (B / 2) * 16 * 64 * sizeof(float));   // the staged epilogues park a 64-column patch per wave in the ring
+    const char* ks_env = getenv("UA2_GEMM_KSPLIT_HACK");   // timing experiment: every slab runs the full epilogue on its partial sums (wrong results)
+    const int ks = ks_env ? std::max(1, atoi(ks_env)) : 1;
+    const int flags = getenv("UA2_GEMM_OLD_EPI") ? 0 : 1;   // test hook: the per-element epilogue everywhere (same bits)
+    hipLaunchKernelGGL(kern, dim3(mblocks * nblocks, ks), dim3(256), smem, s, a, ap, ks > 1 ? 1 : nw, mblocks, nblocks, group_m, flags);
   };
   auto pick = [&](auto bmt_c) {
     if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}, std::false_type{}); return; } }

@@ -105,9 +105,14 @@ struct EpiPre {
 // The one summation tree every producer uses for a row's sum of squares over a 16-column tile (lanes of one 16-lane
 // group hold the 16 columns): butterfly xor 1, 2, 4, 8.  fp add is commutative, so every lane of the group ends with
 // the same bits, and a producer that holds several columns per thread (ua2_misc.hip) reproduces the tree in registers.
+// The first level is a FUSED multiply-add, spelled out: lane c holds fma(v_c, v_c, RN(v_{c^1}^2)) (so the two lanes of a pair
+// differ in the last bit; the tile's value is what lane 0 — an even column — ends with).  Written as RN(v^2) + shfl(RN(v^2))
+// hipcc contracted it to exactly this on its own (-ffp-contract=fast applies to __fmul_rn / __fadd_rn too: they are plain
+// operations), while a producer holding several columns per thread got separate roundings for the same source text: the
+// explicit form is what keeps the three spellings of the tree (here, ua2_misc.hip, the tiled GEMM's staged epilogue)
+// on the same bits by construction instead of by the compiler's choice of the day.
 __device__ __forceinline__ float ssq_tile16(float v) {
-  float s = __fmul_rn(v, v);
-  s = __fadd_rn(s, __shfl_xor(s, 1));
+  float s = __fmaf_rn(v, v, __shfl_xor(__fmul_rn(v, v), 1));
   s = __fadd_rn(s, __shfl_xor(s, 2));
   s = __fadd_rn(s, __shfl_xor(s, 4));
   s = __fadd_rn(s, __shfl_xor(s, 8));
@@ -220,6 +225,23 @@ __device__ __forceinline__ void handover_emit(const ua2_linear_args& a, float ou
   if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, h);
 }
 
+// The activations of the SWIGLU / GELU epilogues: one definition for every kernel and epilogue form (per-element and
+// staged), so the same value goes through the same instructions wherever it is computed.
+__device__ __forceinline__ float ua2_act_glu(const ua2_linear_args& a, float v0, float v1) {
+  if (a.act_kind == UA2_GATE_SIGMOID_SECOND)     // x-transformers GLU: x * sigmoid(gate), x = first half (w0), gate = second (w1)
+    return __fmul_rn(v0, 1.0f / (1.0f + expf(-v1)));
+  const float gte = v0;
+  const float sg = gte / (1.0f + expf(-gte));    // F.silu, lit_model.py:594
+  return __fmul_rn(sg, v1);
+}
+__device__ __forceinline__ float ua2_act_gelu(const ua2_linear_args& a, float x) {
+  if (a.act_kind == UA2_GELU_TANH) {             // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+  }
+  return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, erff(__fmul_rn(x, 0.70710678118654752440f))));
+}
+
 // NOTE: uses 16-lane shuffles: call with all 256 epilogue threads.
 // HO = false compiles the hand-over emission out: the tiled kernel's STORE / RESIDUAL instantiations sit at the register
 // limit (chain + total accumulators), and with the emission's shuffles in their epilogue the allocator moved the totals
@@ -269,28 +291,14 @@ __device__ __forceinline__ void linear_epilogue(const ua2_linear_args& a, const 
   } else if constexpr (EPI == UA2_EPI_SWIGLU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {
-      float out;
-      if (a.act_kind == UA2_GATE_SIGMOID_SECOND) {   // x-transformers GLU: x * sigmoid(gate), x = first half (w0), gate = second (w1)
-        out = __fmul_rn(v[0], 1.0f / (1.0f + expf(-v[1])));
-      } else {
-        const float gte = v[0];
-        const float sg = gte / (1.0f + expf(-gte));  // F.silu, lit_model.py:594
-        out = __fmul_rn(sg, v[1]);
-      }
+      const float out = ua2_act_glu(a, v[0], v[1]);
       if (a.y) a.y[(size_t)mr * a.ldy + n] = out;
       if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, out);
     }
   } else if constexpr (EPI == UA2_EPI_GELU) {
     const int n = tile[0] * 16 + col;
     if (rvalid && n < a.N) {
-      float out;
-      if (a.act_kind == UA2_GELU_TANH) {   // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-        const float x = v[0];
-        const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-        out = 0.5f * x * (1.0f + tanhf(inner));
-      } else {
-        out = __fmul_rn(__fmul_rn(0.5f, v[0]), __fadd_rn(1.0f, erff(__fmul_rn(v[0], 0.70710678118654752440f))));
-      }
+      const float out = ua2_act_gelu(a, v[0]);
       if (a.y) a.y[(size_t)mr * a.ldy + n] = out;
       if (a.y_packed) store_packed_operand<DT>(a.y_packed, mr, n, a.N / Elem<DT>::KC, out);
     }

@@ -36,12 +36,13 @@ namespace {
 // ---- producer half of the scaled-norm hand-over for row-wise kernels (include/ua2hip.h ua2_handover) ----------------
 // The sum of squares of a 16-column tile must be added in the tree the linear epilogues use (ua2_linear_common.h
 // ssq_tile16: butterfly xor 1, 2, 4, 8 over 16 lanes holding one column each).  A thread holding 8 (4) consecutive columns
-// does the first three (two) levels in registers — same operands, same pairing — and the rest by exchanging with its
-// neighbour thread(s); fp add is commutative, so the bits are those of the 16-lane butterfly.
+// does the first three (two) levels in registers — same operands, same pairing, the first level fused as ssq_tile16 spells it
+// — and the rest by exchanging with its neighbour thread(s): the bits are those lane 0 of the 16-lane butterfly ends with.
 __device__ __forceinline__ void handover_emit8(const ua2_handover& ho, const float (&v)[8], int m, int c, int C) {
-  const float q0 = __fmul_rn(v[0], v[0]), q1 = __fmul_rn(v[1], v[1]), q2 = __fmul_rn(v[2], v[2]), q3 = __fmul_rn(v[3], v[3]);
-  const float q4 = __fmul_rn(v[4], v[4]), q5 = __fmul_rn(v[5], v[5]), q6 = __fmul_rn(v[6], v[6]), q7 = __fmul_rn(v[7], v[7]);
-  const float b0 = __fadd_rn(__fadd_rn(q0, q1), __fadd_rn(q2, q3)), b1 = __fadd_rn(__fadd_rn(q4, q5), __fadd_rn(q6, q7));
+  // first level as ssq_tile16 spells it: the even column's fma(v, v, RN(odd neighbour^2))
+  const float p01 = __fmaf_rn(v[0], v[0], __fmul_rn(v[1], v[1])), p23 = __fmaf_rn(v[2], v[2], __fmul_rn(v[3], v[3]));
+  const float p45 = __fmaf_rn(v[4], v[4], __fmul_rn(v[5], v[5])), p67 = __fmaf_rn(v[6], v[6], __fmul_rn(v[7], v[7]));
+  const float b0 = __fadd_rn(p01, p23), b1 = __fadd_rn(p45, p67);
   float s = __fadd_rn(b0, b1);
   s = __fadd_rn(s, __shfl_xor(s, 1));                       // the other half of the tile lives in the neighbour thread
   if (((c >> 3) & 1) == 0) ho.ssq[(size_t)m * (C >> 4) + (c >> 4)] = s;
@@ -58,8 +59,7 @@ __device__ __forceinline__ void handover_emit8(const ua2_handover& ho, const flo
   }
 }
 __device__ __forceinline__ void handover_emit4(const ua2_handover& ho, const float4& v, int m, int c, int C) {
-  const float q0 = __fmul_rn(v.x, v.x), q1 = __fmul_rn(v.y, v.y), q2 = __fmul_rn(v.z, v.z), q3 = __fmul_rn(v.w, v.w);
-  float s = __fadd_rn(__fadd_rn(q0, q1), __fadd_rn(q2, q3));
+  float s = __fadd_rn(__fmaf_rn(v.x, v.x, __fmul_rn(v.y, v.y)), __fmaf_rn(v.z, v.z, __fmul_rn(v.w, v.w)));
   s = __fadd_rn(s, __shfl_xor(s, 1));                       // columns c ^ 4
   s = __fadd_rn(s, __shfl_xor(s, 2));                       // columns c ^ 8
   if ((c & 15) == 0) ho.ssq[(size_t)m * (C >> 4) + (c >> 4)] = s;
