@@ -302,6 +302,40 @@ def test_scaled_norm_handover_is_kernel_and_row_count_invariant(linear_mode):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N,K", [(1536, 1536), (256, 2048), (128, 3072), (64, 72), (192, 1056), (64, 4096)])
+def test_row_tile_prep_equals_the_per_row_prep(dtype, N, K, linear_mode):
+    """The operand prep of the many-row kernels, one 16-row tile per workgroup (round 4), against the per-row kernel
+    (UA2_GEMM_OLD_PREP): same statistics order, same rounding, so the GEMM behind it returns the same bits — cast, RMSNorm
+    (both flavours) and LayerNorm prologues, ragged row counts, K with a partial last chunk."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_STORE, PRO_CAST, PRO_NORM
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(K + N)
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dtype)
+    nw, nb = (1.0 + 0.2 * torch.randn(K, generator=g)).to(dev), (0.2 * torch.randn(K, generator=g)).to(dev)
+    x = (torch.randn(1000, K, generator=g) * 3.0 + 0.5).to(dev)
+    try:
+        for M in (1000, 17, 77):
+            for pro, nk in ((PRO_CAST, 0), (PRO_NORM, 0), (PRO_NORM, 1), (PRO_NORM, 2)):
+                outs = []
+                for old in (True, False):
+                    if old:
+                        os.environ["UA2_GEMM_OLD_PREP"] = "1"
+                    else:
+                        os.environ.pop("UA2_GEMM_OLD_PREP", None)
+                    linear_mode(5)
+                    y = torch.zeros(M, N, device=dev)
+                    ops.linear(dtype=dtype, M=M, N=N, K=K, w0=w, prologue=pro, epilogue=EPI_STORE, x=x[:M].contiguous(), y=y,
+                               norm_w=nw, norm_b=nb, norm_kind=nk, eps=1e-5, workspace=ops.linear_workspace(dtype, M, K, dev))
+                    torch.cuda.synchronize()
+                    outs.append(y)
+                assert torch.equal(outs[0], outs[1]), (M, pro, nk, (outs[0] - outs[1]).abs().max().item())
+                assert outs[1].abs().sum().item() > 0
+    finally:
+        os.environ.pop("UA2_GEMM_OLD_PREP", None)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_staged_epilogue_equals_the_per_element_epilogue(dtype, linear_mode):
     """Round 4: the tiled kernel's epilogues (STORE / RESIDUAL / SWIGLU / GELU) walk a wave's patch through LDS in 16-byte
     pieces.  Same operations on every value as the per-element form (UA2_GEMM_OLD_EPI), so the same bits: every output of every

@@ -26,9 +26,11 @@ DIT = (("dit ff1 1536->6144", 6144, 1536, PRO_CAST, EPI_STORE),      # UA2_SHAPE
        ("dit ff2 6144->1536", 1536, 6144, PRO_CAST, EPI_RESIDUAL),
        ("dit qkv 1536->4608", 4608, 1536, PRO_CAST, EPI_STORE),
        ("dit o 1536->1536", 1536, 1536, PRO_CAST, EPI_RESIDUAL))
+DITNORM = (("dit ff1 LN 1536->6144", 6144, 1536, PRO_NORM, EPI_STORE), ("dit qkv LN 1536->4608", 4608, 1536, PRO_NORM, EPI_STORE))
+SETS = {"dit": DIT, "ditnorm": DITNORM}
 for M in MS:
     ws = ops.linear_workspace(dt, M, 8192, dev)
-    for name, N, K, pro, epi in (DIT if os.environ.get("UA2_SHAPES") == "dit" else TRUNK):
+    for name, N, K, pro, epi in SETS.get(os.environ.get("UA2_SHAPES"), TRUNK):
         w0 = packed(N, K)
         w1 = packed(N, K) if epi == EPI_SWIGLU else [None] * L
         x = torch.randn(M, K, device=dev); nw = torch.ones(K, device=dev)

@@ -92,6 +92,116 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
   }
 }
 
+// ---- prep, one row TILE per workgroup (K <= 4096 bf16 / 2048 fp32) -------------------------------------------------
+// The per-row kernel above writes 16 bytes of every 1 KiB fragment block from 16 different workgroups (8-byte pieces, 256 bytes
+// apart) and spends a workgroup barrier on a row's statistics: 7.75 us for the DiT's 1000 x 1536 LayerNorm rows, two of them per
+// layer.  Here a workgroup owns the 16 rows of a fragment row-tile, one wave per row.  The wave holds its row in registers
+// (piece p = columns 4 * lane + 256 * p), reduces the statistics in the decode kernel's order — that kernel's thread
+// t = 64 * vw + lane owns pieces p = vw, vw + NVW, ..., so the wave keeps NVW partial chains per lane, butterflies each across the
+// lanes and adds them in vw order: the same operations on the same operands, no LDS, no barrier — and parks the normalised row
+// in an LDS image; then every wave writes whole fragment blocks, 1 KiB per wave-instruction.  Same bits as the per-row kernel.
+template <int DT, int PRO, int NVW, int MAXV>
+__global__ __launch_bounds__(1024) void gemm_prep16_kernel(const ua2_linear_args a, void* __restrict__ apack) {
+  constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
+  extern __shared__ __attribute__((aligned(16))) char prep_img[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nchunks = (a.K + KC - 1) / KC, kp = nchunks * KC;
+  const int rowbytes = kp * BYTES + 16;                 // + 16 B: rows start 4 banks apart
+  const int m = blockIdx.x * 16 + wave;
+  const bool live = m < a.M;
+  const float* xr = a.x + (size_t)(live ? m : 0) * a.ldx;
+  const bool ln = (PRO == UA2_PRO_NORM) && a.norm_kind == UA2_NORM_LAYERNORM;
+  float4 v[MAXV];
+#pragma unroll
+  for (int p = 0; p < MAXV; ++p) {
+    const int k = 4 * lane + 256 * p;
+    v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && k < a.K) v[p] = *reinterpret_cast<const float4*>(xr + k);
+  }
+  NormStat st{0.f, 1.f};
+  if constexpr (PRO == UA2_PRO_NORM) {
+    // chains 0 .. NVW-1: sums of squares, NVW .. 2 NVW - 1: sums
+    float ch[2 * NVW];
+#pragma unroll
+    for (int w = 0; w < 2 * NVW; ++w) ch[w] = 0.f;
+#pragma unroll
+    for (int p = 0; p < MAXV; ++p)                       // ascending p inside a chain = the decode kernel's ascending k
+      if (4 * lane + 256 * p < a.K) { ch[p % NVW] = sumsq4(ch[p % NVW], v[p]); ch[NVW + p % NVW] = sum4(ch[NVW + p % NVW], v[p]); }
+    // The decode kernel butterflies every chain over its 64 lanes (s += shfl_xor(s, 32), 16, ..., 1): 12 shuffles per virtual wave.
+    // Same adds with a sixth of the shuffles: at each level two chains share one exchange — the lanes whose bit is clear keep
+    // chain A (own + partner's A), the others chain B — so the registers halve per level and a chain's total ends up in the lanes
+    // its index selects (bit 0 -> lane bit 32, bit 1 -> 16, ...).  own + other, as the butterfly: the same bits.
+    constexpr int NCH = 2 * NVW;
+    int n = NCH;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const bool hi = (lane & o) != 0;
+      const int pairs = n / 2;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; ++i) {
+        if (i < pairs) {
+          const float send = hi ? ch[2 * i] : ch[2 * i + 1], keep = hi ? ch[2 * i + 1] : ch[2 * i];
+          ch[i] = keep + __shfl_xor(send, o);
+        }
+      }
+      if (n & 1) {                                       // the odd one out: a plain butterfly level
+        const float last = ch[n - 1];
+        ch[pairs] = last + __shfl_xor(last, o);
+      }
+      n = pairs + (n & 1);
+    }
+    // lane holding chain w's total after the six levels
+    auto lane_of = [](int w) {
+      int n2 = NCH, l = 0;
+      for (int o = 32; o >= 1; o >>= 1) {
+        const int pairs = n2 / 2;
+        if (w < 2 * pairs) { if (w & 1) l |= o; w >>= 1; } else { w = pairs; }
+        n2 = pairs + (n2 & 1);
+      }
+      return l;
+    };
+    float t = 0.f, u = 0.f;
+#pragma unroll
+    for (int w = 0; w < NVW; ++w) {
+      t += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ch[0]), lane_of(w)));
+      u += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ch[0]), lane_of(NVW + w)));
+    }
+    st = norm_stat(a, u, t);
+  }
+  char* row = prep_img + (size_t)wave * rowbytes;
+#pragma unroll
+  for (int p = 0; p < MAXV; ++p) {
+    const int k = 4 * lane + 256 * p;
+    if (k >= kp) continue;
+    float4 t = v[p];
+    if constexpr (PRO == UA2_PRO_NORM) {
+      if (live && k < a.K) {
+        const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ln) b = *reinterpret_cast<const float4*>(a.norm_b + k);
+        t.x = norm_apply(a, t.x, w.x, b.x, st);
+        t.y = norm_apply(a, t.y, w.y, b.y, st);
+        t.z = norm_apply(a, t.z, w.z, b.z, st);
+        t.w = norm_apply(a, t.w, w.w, b.w, st);
+      }
+    }
+    if constexpr (DT == UA2_BF16) {
+      uint2 pk;
+      pk.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
+      pk.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
+      *reinterpret_cast<uint2*>(row + (size_t)k * BYTES) = pk;
+    } else {
+      *reinterpret_cast<float4*>(row + (size_t)k * BYTES) = t;
+    }
+  }
+  __syncthreads();
+  // fragment block c of this row-tile = [64 lanes][16 B]: lane g * 16 + r holds columns c * KC + g * EPL .. + EPL of row r
+  const int g = lane >> 4, r = lane & 15;
+  u32x4* dst = reinterpret_cast<u32x4*>(apack) + (size_t)blockIdx.x * nchunks * 64 + lane;
+  for (int c = wave; c < nchunks; c += 16)
+    dst[(size_t)c * 64] = *reinterpret_cast<const u32x4*>(prep_img + (size_t)r * rowbytes + (size_t)(c * KC + g * EPL) * BYTES);
+}
+
 // ---- the GEMM ------------------------------------------------------------------------------------------
 // BMT 16-row tiles per workgroup: 8 (128 x 128 tile, 64 x 64 per wave) or 4 (64 x 128, 32 x 64 per wave — for launches
 // whose 128-row grid would leave most CUs idle: M ~ 1000 rows x N = 1536 is 96 workgroups on 256 CUs).  A row's bits do
@@ -810,8 +920,37 @@ void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t 
   hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace));
 }
 
+template <int DT, int PRO, int NVW, int MAXV>
+void launch_prep16(const ua2_linear_args& a, hipStream_t s) {
+  constexpr auto kern = gemm_prep16_kernel<DT, PRO, NVW, MAXV>;
+  ua2_allow_big_lds<kern>();
+  const int kc = Elem<DT>::KC, nchunks = ua2_ceil_div(a.K, kc);
+  const size_t smem = (size_t)16 * ((size_t)nchunks * kc * Elem<DT>::BYTES + 16);
+  hipLaunchKernelGGL(kern, dim3(ua2_ceil_div(a.M, 16)), dim3(1024), smem, s, a, a.workspace);
+}
+
 template <int DT, int PRO>
 void launch_prep(const ua2_linear_args& a, int nthreads, hipStream_t s) {
+  // the row-tile form where a row fits its registers / the tile its LDS image, for the decode kernel's usual wave counts
+  const int nvw = nthreads / 64;
+  const bool fits = a.K % 4 == 0 && a.K <= (DT == UA2_BF16 ? 4096 : 2048) && !getenv("UA2_GEMM_OLD_PREP");   // test hook: the per-row kernel (same bits)
+  if (fits) {
+    const bool small = a.K <= 2048;
+    auto go = [&](auto nvw_c) {
+      constexpr int W = decltype(nvw_c)::value;
+      if (small) launch_prep16<DT, PRO, W, 8>(a, s);
+      else launch_prep16<DT, PRO, W, 16>(a, s);
+    };
+    if constexpr (PRO == UA2_PRO_CAST) { go(std::integral_constant<int, 1>{}); return; }
+    switch (nvw) {
+      case 4: go(std::integral_constant<int, 4>{}); return;
+      case 6: go(std::integral_constant<int, 6>{}); return;
+      case 8: go(std::integral_constant<int, 8>{}); return;
+      case 12: go(std::integral_constant<int, 12>{}); return;
+      case 16: go(std::integral_constant<int, 16>{}); return;
+      default: break;
+    }
+  }
   hipLaunchKernelGGL((gemm_prep_kernel<DT, PRO>), dim3(ua2_ceil_div(a.M, 16) * 16), dim3(nthreads), 0, s, a, a.workspace);
 }
 
