@@ -1,4 +1,5 @@
-"""Static checks on the compiled gfx950 code of the split-plane conv kernels (ua2_convtc.hip).
+"""Static checks on the compiled gfx950 code of the kernels that wait for LDS-DMA by hand: the split-plane conv kernels
+(ua2_convtc.hip) and the tiled GEMM's operand ring (ua2_gemm.hip).
 
 The pipelined and big-tile kernels fill their LDS window images with LDS-DMA (global_load_lds_dwordx4), which the
 compiler's s_waitcnt bookkeeping does not see, and wait for it with hand-counted `s_waitcnt vmcnt(N)` in inline asm
@@ -13,7 +14,7 @@ by luck.  This test compiles the file to assembly and checks the invariant where
     a full drain per unit: the performance property the kernels exist for);
   * no kernel of the file uses scratch memory (a register spill costs the fused kernels ~2x, round-4 notes §2).
 
-Needs hipcc (cross-compiles without a GPU); ~10 s.
+Needs hipcc (cross-compiles without a GPU); ~10 s for the conv file, ~70 s for the GEMM file.
 """
 import os
 import re
@@ -23,7 +24,8 @@ import subprocess
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "..", "uniaudio2_amd", "csrc", "ua2_convtc.hip")
+CSRC = os.path.join(HERE, "..", "uniaudio2_amd", "csrc")
+SRC = os.path.join(CSRC, "ua2_convtc.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
@@ -110,3 +112,46 @@ def test_no_scratch_and_registers_fit(asm):
     for name, scratch in names:
         assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
         assert int(vg[name]) <= 256, name
+
+
+# ---- the tiled GEMM's LDS-DMA ring (ua2_gemm.hip) ---------------------------------------------------------------------
+# Per chunk a wave waits `s_waitcnt vmcnt((NBUF - 2) * LOADS)` in front of a raw s_barrier and then requests LOADS pieces of
+# chunk c + NBUF.  The count is right iff NOTHING else enters the wave's vector-memory queue between two waits and exactly
+# LOADS pieces do: then "at most (NBUF - 2) * LOADS outstanding" = chunks c + 2 .. c + NBUF - 1 may be in flight, chunk c + 1
+# has landed.  A run-time race screen (tests/test_gpu_invariance.py::test_tiled_gemm_ring_is_repeatable) can only sample
+# that; the compiled code states it.
+
+@pytest.fixture(scope="module")
+def gemm_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "gemm.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           os.path.join(CSRC, "ua2_gemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def test_gemm_ring_waits_match_the_requests_in_flight(gemm_asm):
+    ks = {k: v for k, v in _kernels(gemm_asm).items() if re.search(r"gemm_kernelILi\dELi\dELi\dELb\dELb1E", k)}   # GL = true: the LDS-DMA ring
+    assert len(ks) >= 20, sorted(_kernels(gemm_asm))
+    vmem = re.compile(r"(global|buffer|flat|scratch)_(load|store|atomic)")
+    for name, ins in ks.items():
+        hand = [(i, int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1))) for i, (t, inasm) in enumerate(ins)
+                if inasm and t.startswith("s_waitcnt vmcnt")]
+        counts = [n for _, n in hand]
+        # prologue fill, the two unrolled steps of the chunk loop, the drain in front of the epilogue
+        assert len(counts) == 4 and counts[1] == counts[2] and counts[3] == 0, (name, counts)
+        loads = counts[0] - counts[1]                       # (NBUF - 1) * LOADS - (NBUF - 2) * LOADS
+        assert loads > 0 and counts[1] % loads == 0, (name, counts)
+        nbuf = counts[1] // loads + 2
+        pre = sum(1 for t, _ in ins[:hand[0][0]] if t.startswith("global_load_lds"))
+        assert pre == nbuf * loads, f"{name}: {pre} requests in front of the first wait, ring of {nbuf} x {loads}"
+        for (i, _), (j, _) in zip(hand[:3], hand[1:]):
+            seg = [t for t, _ in ins[i + 1:j]]
+            dma = sum(1 for t in seg if t.startswith("global_load_lds"))
+            other = [t for t in seg if vmem.match(t) and not t.startswith("global_load_lds")]
+            drains = [t for t, inasm in ins[i + 1:j] if not inasm and t.startswith("s_waitcnt") and "vmcnt" in t]
+            if (i, j) == (hand[0][0], hand[1][0]):
+                assert dma == 0 and not other, (name, "between the prologue wait and the first step", dma, other)
+            else:
+                assert dma == loads, f"{name}: {dma} requests per step, the waits assume {loads}"
+                assert not other, f"{name}: other vector-memory traffic inside the ring loop: {other[:3]}"
+            assert not drains, f"{name}: the compiler drains the ring inside the loop: {drains[:2]}"
