@@ -59,6 +59,23 @@ def test_flash_attention_vs_torch_and_row_kernel(nh, nkv, hs, lens, causal):
     assert err < 2e-4 and float((y - y_row).abs().max()) < 2e-4
 
 
+def test_flash_attention_eight_query_tiles_equal_four():
+    """The dense (multi-head, head size 64) form the DiT uses takes 128 query rows per workgroup since round 4; a row's
+    bits do not depend on how many rows share its workgroup."""
+    from uniaudio2_amd import ops
+    s = _setup(24, 24, 64, [150, 150, 77], causal=False, seed=5)
+    R = s["q"].shape[0]
+    outs = []
+    for qt in (4, 8):
+        groups = ops.attn_groups(s["pos_h"].numpy(), s["seq_h"].numpy(), 24, 24, "cuda", q_tiles=qt)
+        assert groups[3] == qt and groups[0].shape[1] == qt * 16
+        y = torch.zeros_like(s["q"])
+        ops.attn(dtype=torch.bfloat16, R=R, q=s["q"], row_pos=s["pos"], row_seq=s["seq"], kv=s["geom"], y=y, groups=groups)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[1].cpu() - s["ref"]).abs().max()) < 2e-4
+
+
 def test_flash_attention_rows_do_not_depend_on_the_grouping():
     """Re-grouping the query rows (other tile compositions, padded groups, one row per group) leaves every row's bits
     unchanged: chunked prefill == one-pass prefill, a prompt alone == the same prompt inside a ragged batch."""

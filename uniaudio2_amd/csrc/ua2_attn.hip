@@ -470,6 +470,7 @@ int launch_flash(const ua2_attn_args& a, hipStream_t s) {
   if (hs == 128 && G == 3 && qt == 2) launch_flash_one<128, 3, 2>(a, s);
   else if (hs == 128 && G == 1 && qt == 4) launch_flash_one<128, 1, 4>(a, s);
   else if (hs == 64 && G == 1 && qt == 4) launch_flash_one<64, 1, 4>(a, s);
+  else if (hs == 64 && G == 1 && qt == 8) launch_flash_one<64, 1, 8>(a, s);
   else if (hs == 64 && G == 2 && qt == 2) launch_flash_one<64, 2, 2>(a, s);
   else if (hs == 64 && G == 4 && qt == 2) launch_flash_one<64, 4, 2>(a, s);
   else if (hs == 128 && G == 2 && qt == 2) launch_flash_one<128, 2, 2>(a, s);

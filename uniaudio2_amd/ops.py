@@ -4,6 +4,8 @@ csrc/*.hip.  Used by the parity tests and by the module mirrors in llm_models/.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -101,13 +103,16 @@ def linear_chain_timed(args_list, iters):
     return ms.value / (len(args_list) * iters)
 
 
-def attn_groups(pos, seq, n_head, n_kv, device):
+def attn_groups(pos, seq, n_head, n_kv, device, q_tiles=None):
     """Row groups for the MFMA flash form of ua2_attn: pos, seq = host int sequences (position and page-table row of every
     query row of the launch).  Rows of one sequence, ordered by position, are cut into groups of q_tiles * 16
-    (q_tiles = 2 with grouped-query heads, 4 otherwise).  -> (rows [n, q_tiles*16] int32, seq [n], nkeys [n], q_tiles), device."""
+    (q_tiles = 2 with grouped-query heads, 4 otherwise; a caller whose head size has the wider instantiation may ask for 8:
+    twice the query rows per staged K / V page).  -> (rows [n, q_tiles*16] int32, seq [n], nkeys [n], q_tiles), device."""
     import numpy as np
     pos, seq = np.asarray(pos, dtype=np.int64), np.asarray(seq, dtype=np.int64)
-    qt = 2 if n_head > n_kv else 4
+    qt = q_tiles or (2 if n_head > n_kv else 4)
+    if n_head == n_kv and os.environ.get("UA2_ATTN_QTILES"):   # experiment hook (a row's bits do not depend on the grouping)
+        qt = int(os.environ["UA2_ATTN_QTILES"])
     per = qt * 16
     order = np.lexsort((pos, seq))
     rows, gseq, nkeys = [], [], []
