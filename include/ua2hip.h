@@ -168,8 +168,8 @@ typedef struct ua2_linear_args {
   /* Scaled-norm hand-over (UA2_BF16).  Producer side — UA2_EPI_RESIDUAL / UA2_EPI_STORE with y_norm_w != NULL: besides
      y the launch writes, for the UA2_PRO_SCALED consumer that follows, RNE_bf16(y[m][n] * y_norm_w[n]) into y_h (row-major
      [M, ldh] bf16) and / or y_packed (fragment order, N % 32 == 0), and y_ssq[m][n / 16] = the sum of y[m][n]^2 over the
-     16-column tile, added in a fixed butterfly order (xor 1, 2, 4, 8) — the same tree in every kernel, so a row's
-     statistic does not depend on the row count.  N % 32 == 0 (the launcher enforces it: whole bf16 MFMA chunks of the consumer).
+     16-column tile, added in a fixed butterfly order (xor 1, 2, 4, 8; the first level fused: an even column c contributes
+     fma(y_c, y_c, RN(y_{c+1}^2))) — the same tree in every kernel, so a row's statistic does not depend on the row count.  N % 32 == 0 (the launcher enforces it: whole bf16 MFMA chunks of the consumer).
      Consumer side — UA2_PRO_SCALED: x_h (M <= the decode kernel's row tile) or x_packed, and x_ssq [M, K / 16]; eps as
      for UA2_PRO_NORM.  rstd[m] = rsqrt(sum_j x_ssq[m][j] / K + eps), j summed as 16 interleaved chains + butterfly. */
   const float* y_norm_w;
