@@ -323,6 +323,7 @@ def test_row_tile_prep_equals_the_per_row_prep(dtype, N, K, linear_mode):
                         os.environ["UA2_GEMM_OLD_PREP"] = "1"
                     else:
                         os.environ.pop("UA2_GEMM_OLD_PREP", None)
+                    os.environ["UA2_GEMM_PREP16_MIN_ROWS"] = "1"      # the launcher keeps the per-row kernel below 2048 rows (grid size)
                     linear_mode(5)
                     y = torch.zeros(M, N, device=dev)
                     ops.linear(dtype=dtype, M=M, N=N, K=K, w0=w, prologue=pro, epilogue=EPI_STORE, x=x[:M].contiguous(), y=y,
@@ -333,6 +334,7 @@ def test_row_tile_prep_equals_the_per_row_prep(dtype, N, K, linear_mode):
                 assert outs[1].abs().sum().item() > 0
     finally:
         os.environ.pop("UA2_GEMM_OLD_PREP", None)
+        os.environ.pop("UA2_GEMM_PREP16_MIN_ROWS", None)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

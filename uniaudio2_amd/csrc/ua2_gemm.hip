@@ -933,7 +933,12 @@ template <int DT, int PRO>
 void launch_prep(const ua2_linear_args& a, int nthreads, hipStream_t s) {
   // the row-tile form where a row fits its registers / the tile its LDS image, for the decode kernel's usual wave counts
   const int nvw = nthreads / 64;
-  const bool fits = a.K % 4 == 0 && a.K <= (DT == UA2_BF16 ? 4096 : 2048) && !getenv("UA2_GEMM_OLD_PREP");   // test hook: the per-row kernel (same bits)
+  // ... and from 128 row tiles up: below that the per-row kernel's grid (one workgroup per row) fills the CUs and the row-tile
+  // form does not (B = 256 decode with its 66 NORM preps per frame: 11.4 -> 12.4 ms/frame when it took the 16-workgroup launch).
+  // UA2_GEMM_PREP16_MIN_ROWS overrides the threshold (tests run the row-tile form at small M through it).
+  const char* mr_env = getenv("UA2_GEMM_PREP16_MIN_ROWS");   // read per call (launches are captured into graphs: not a per-frame cost)
+  const int min_rows = mr_env ? atoi(mr_env) : 2048;
+  const bool fits = a.K % 4 == 0 && a.K <= (DT == UA2_BF16 ? 4096 : 2048) && a.M >= min_rows && !getenv("UA2_GEMM_OLD_PREP");   // test hook: the per-row kernel (same bits)
   if (fits) {
     const bool small = a.K <= 2048;
     auto go = [&](auto nvw_c) {
