@@ -349,3 +349,29 @@ def test_batched_tts_with_classifier_free_guidance_keeps_row_pairs():
     # a missing or mis-shaped twin is refused before anything runs
     with pytest.raises(ValueError):
         gen._generate_audio_tokens_batch([gen.prepare_tts_task(torch.tensor([128000, 1, 128001]), texts[0])], cfg_prompts=None)
+
+
+def test_attention_row_groups_cover_every_row_once():
+    """ops.attn_groups (host logic of the MFMA flash attention): every query row appears in exactly one group slot, groups hold
+    rows of one sequence in position order, nkeys = 1 + the largest position of the group — for the default tile counts and for
+    the 8-tile grouping the DiT's dense attention asks for."""
+    import numpy as np
+    import torch
+    from uniaudio2_amd import ops
+    rng = np.random.default_rng(3)
+    lens = [150, 1, 77, 64, 129]
+    seq = np.concatenate([np.full(n, b) for b, n in enumerate(lens)])
+    pos = np.concatenate([rng.permutation(n) for n in lens])
+    perm = rng.permutation(len(seq))
+    seq, pos = seq[perm], pos[perm]
+    for n_head, n_kv, q_tiles, want in ((24, 8, None, 2), (24, 24, None, 4), (24, 24, 8, 8)):
+        rows, gseq, nkeys, qt = ops.attn_groups(pos, seq, n_head, n_kv, torch.device("cpu"), q_tiles=q_tiles)
+        assert qt == want and rows.shape[1] == 16 * want
+        rows, gseq, nkeys = rows.numpy(), gseq.numpy(), nkeys.numpy()
+        live = rows[rows >= 0]
+        assert sorted(live.tolist()) == list(range(len(seq)))
+        for g in range(rows.shape[0]):
+            r = rows[g][rows[g] >= 0]
+            assert len(r) > 0 and np.all(seq[r] == gseq[g])
+            assert np.all(np.diff(pos[r]) > 0) and nkeys[g] == pos[r].max() + 1
+            assert np.all(rows[g][len(r):] == -1)            # padding only behind the live rows
