@@ -318,23 +318,27 @@ def test_row_tile_prep_equals_the_per_row_prep(dtype, N, K, linear_mode):
         for M in (1000, 17, 77):
             for pro, nk in ((PRO_CAST, 0), (PRO_NORM, 0), (PRO_NORM, 1), (PRO_NORM, 2)):
                 outs = []
-                for old in (True, False):
+                # the per-row kernel, the 16-rows-per-workgroup form (taken from 2048 rows up) and the 4-rows form (below), each forced
+                for old, min_rows in ((True, "1"), (False, "1"), (False, "1000000")):
                     if old:
                         os.environ["UA2_GEMM_OLD_PREP"] = "1"
                     else:
                         os.environ.pop("UA2_GEMM_OLD_PREP", None)
-                    os.environ["UA2_GEMM_PREP16_MIN_ROWS"] = "1"      # the launcher keeps the per-row kernel below 2048 rows (grid size)
+                    os.environ["UA2_GEMM_PREP16_MIN_ROWS"] = min_rows
+                    os.environ["UA2_GEMM_PREP4_MIN_ROWS"] = "1"       # (the launcher keeps the per-row kernel below 960 rows)
                     linear_mode(5)
                     y = torch.zeros(M, N, device=dev)
                     ops.linear(dtype=dtype, M=M, N=N, K=K, w0=w, prologue=pro, epilogue=EPI_STORE, x=x[:M].contiguous(), y=y,
                                norm_w=nw, norm_b=nb, norm_kind=nk, eps=1e-5, workspace=ops.linear_workspace(dtype, M, K, dev))
                     torch.cuda.synchronize()
                     outs.append(y)
-                assert torch.equal(outs[0], outs[1]), (M, pro, nk, (outs[0] - outs[1]).abs().max().item())
+                assert torch.equal(outs[0], outs[1]), (M, pro, nk, "16-row form", (outs[0] - outs[1]).abs().max().item())
+                assert torch.equal(outs[0], outs[2]), (M, pro, nk, "4-row form", (outs[0] - outs[2]).abs().max().item())
                 assert outs[1].abs().sum().item() > 0
     finally:
         os.environ.pop("UA2_GEMM_OLD_PREP", None)
         os.environ.pop("UA2_GEMM_PREP16_MIN_ROWS", None)
+        os.environ.pop("UA2_GEMM_PREP4_MIN_ROWS", None)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

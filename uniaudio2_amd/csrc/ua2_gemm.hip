@@ -100,23 +100,40 @@ __global__ __launch_bounds__(1024) void gemm_prep_kernel(const ua2_linear_args a
 // t = 64 * vw + lane owns pieces p = vw, vw + NVW, ..., so the wave keeps NVW partial chains per lane, butterflies each across the
 // lanes and adds them in vw order: the same operations on the same operands, no LDS, no barrier — and parks the normalised row
 // in an LDS image; then every wave writes whole fragment blocks, 1 KiB per wave-instruction.  Same bits as the per-row kernel.
-template <int DT, int PRO, int NVW, int MAXV>
-__global__ __launch_bounds__(1024) void gemm_prep16_kernel(const ua2_linear_args a, void* __restrict__ apack) {
+// ROWS = 4 (launches of fewer than 128 row tiles: the 16-row form would leave most CUs idle): four rows per workgroup, no image —
+// a lane stores its 8-byte (bf16) pieces straight into the fragment blocks, as the per-row kernel does — and the norm's weight /
+// bias requested together with the row instead of behind its statistics (one memory trip less on the critical path).
+template <int DT, int PRO, int NVW, int MAXV, int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void gemm_prep16_kernel(const ua2_linear_args a, void* __restrict__ apack) {
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
+  constexpr bool IMG = ROWS == 16;                      // whole fragment tile in the workgroup: coalesce through an LDS image
+  constexpr bool PREW = (PRO == UA2_PRO_NORM) && !IMG && MAXV <= 8;
   extern __shared__ __attribute__((aligned(16))) char prep_img[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nchunks = (a.K + KC - 1) / KC, kp = nchunks * KC;
   const int rowbytes = kp * BYTES + 16;                 // + 16 B: rows start 4 banks apart
-  const int m = blockIdx.x * 16 + wave;
+  const int m = blockIdx.x * ROWS + wave;
   const bool live = m < a.M;
   const float* xr = a.x + (size_t)(live ? m : 0) * a.ldx;
   const bool ln = (PRO == UA2_PRO_NORM) && a.norm_kind == UA2_NORM_LAYERNORM;
   float4 v[MAXV];
+  float4 nwv[PREW ? MAXV : 1], nbv[PREW ? MAXV : 1];
 #pragma unroll
   for (int p = 0; p < MAXV; ++p) {
     const int k = 4 * lane + 256 * p;
     v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live && k < a.K) v[p] = *reinterpret_cast<const float4*>(xr + k);
+  }
+  if constexpr (PREW) {
+#pragma unroll
+    for (int p = 0; p < MAXV; ++p) {
+      const int k = 4 * lane + 256 * p;
+      nwv[p] = nbv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < a.K) {
+        nwv[p] = *reinterpret_cast<const float4*>(a.norm_w + k);
+        if (ln) nbv[p] = *reinterpret_cast<const float4*>(a.norm_b + k);
+      }
+    }
   }
   NormStat st{0.f, 1.f};
   if constexpr (PRO == UA2_PRO_NORM) {
@@ -168,7 +185,10 @@ __global__ __launch_bounds__(1024) void gemm_prep16_kernel(const ua2_linear_args
     }
     st = norm_stat(a, u, t);
   }
-  char* row = prep_img + (size_t)wave * rowbytes;
+  // image row (16-row form) or this row's 16-byte slot of fragment block 0 (4-row form: element k of row m lives in block
+  // k / KC at lane (k % KC) / EPL * 16 + (m & 15), as gemm_prep_kernel addresses it)
+  char* row = IMG ? prep_img + (size_t)wave * rowbytes
+                  : reinterpret_cast<char*>(apack) + (size_t)(m >> 4) * nchunks * 1024 + (size_t)(m & 15) * 16;
 #pragma unroll
   for (int p = 0; p < MAXV; ++p) {
     const int k = 4 * lane + 256 * p;
@@ -176,24 +196,33 @@ __global__ __launch_bounds__(1024) void gemm_prep16_kernel(const ua2_linear_args
     float4 t = v[p];
     if constexpr (PRO == UA2_PRO_NORM) {
       if (live && k < a.K) {
-        const float4 w = *reinterpret_cast<const float4*>(a.norm_w + k);
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ln) b = *reinterpret_cast<const float4*>(a.norm_b + k);
+        float4 w, b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (PREW) { w = nwv[p]; b = nbv[p]; }
+        else {
+          w = *reinterpret_cast<const float4*>(a.norm_w + k);
+          if (ln) b = *reinterpret_cast<const float4*>(a.norm_b + k);
+        }
         t.x = norm_apply(a, t.x, w.x, b.x, st);
         t.y = norm_apply(a, t.y, w.y, b.y, st);
         t.z = norm_apply(a, t.z, w.z, b.z, st);
         t.w = norm_apply(a, t.w, w.w, b.w, st);
       }
     }
+    size_t off = (size_t)k * BYTES;
+    if constexpr (!IMG) {
+      const int c = k / KC, r = k - c * KC, g = r / EPL, e = r - g * EPL;
+      off = (size_t)c * 1024 + (size_t)g * 256 + (size_t)e * BYTES;
+    }
     if constexpr (DT == UA2_BF16) {
       uint2 pk;
       pk.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
       pk.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
-      *reinterpret_cast<uint2*>(row + (size_t)k * BYTES) = pk;
+      *reinterpret_cast<uint2*>(row + off) = pk;
     } else {
-      *reinterpret_cast<float4*>(row + (size_t)k * BYTES) = t;
+      *reinterpret_cast<float4*>(row + off) = t;
     }
   }
+  if constexpr (!IMG) return;
   __syncthreads();
   // fragment block c of this row-tile = [64 lanes][16 B]: lane g * 16 + r holds columns c * KC + g * EPL .. + EPL of row r
   const int g = lane >> 4, r = lane & 15;
@@ -920,31 +949,39 @@ void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t 
   hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace));
 }
 
-template <int DT, int PRO, int NVW, int MAXV>
+template <int DT, int PRO, int NVW, int MAXV, int ROWS>
 void launch_prep16(const ua2_linear_args& a, hipStream_t s) {
-  constexpr auto kern = gemm_prep16_kernel<DT, PRO, NVW, MAXV>;
-  ua2_allow_big_lds<kern>();
+  constexpr auto kern = gemm_prep16_kernel<DT, PRO, NVW, MAXV, ROWS>;
   const int kc = Elem<DT>::KC, nchunks = ua2_ceil_div(a.K, kc);
-  const size_t smem = (size_t)16 * ((size_t)nchunks * kc * Elem<DT>::BYTES + 16);
-  hipLaunchKernelGGL(kern, dim3(ua2_ceil_div(a.M, 16)), dim3(1024), smem, s, a, a.workspace);
+  size_t smem = 0;
+  if constexpr (ROWS == 16) {
+    ua2_allow_big_lds<kern>();
+    smem = (size_t)16 * ((size_t)nchunks * kc * Elem<DT>::BYTES + 16);
+  }
+  // the grid covers whole row tiles: rows >= M of the last tile are zero-filled
+  hipLaunchKernelGGL(kern, dim3(ua2_ceil_div(a.M, 16) * (16 / ROWS)), dim3(64 * ROWS), smem, s, a, a.workspace);
 }
 
 template <int DT, int PRO>
 void launch_prep(const ua2_linear_args& a, int nthreads, hipStream_t s) {
-  // the row-tile form where a row fits its registers / the tile its LDS image, for the decode kernel's usual wave counts
+  // the wave-per-row forms where a row fits its registers (and, for the 16-row form, the tile its LDS image), for the decode
+  // kernel's usual wave counts: 16 rows per workgroup from 128 row tiles up (whole fragment blocks written), 4 rows per workgroup
+  // below (the 16-workgroup launch at 256 rows cost B = 256 decode 1 ms/frame with its 66 NORM preps).
+  // UA2_GEMM_PREP16_MIN_ROWS / UA2_GEMM_PREP4_MIN_ROWS override the thresholds; UA2_GEMM_OLD_PREP selects the per-row kernel (test hooks: same bits).
   const int nvw = nthreads / 64;
-  // ... and from 128 row tiles up: below that the per-row kernel's grid (one workgroup per row) fills the CUs and the row-tile
-  // form does not (B = 256 decode with its 66 NORM preps per frame: 11.4 -> 12.4 ms/frame when it took the 16-workgroup launch).
-  // UA2_GEMM_PREP16_MIN_ROWS overrides the threshold (tests run the row-tile form at small M through it).
   const char* mr_env = getenv("UA2_GEMM_PREP16_MIN_ROWS");   // read per call (launches are captured into graphs: not a per-frame cost)
   const int min_rows = mr_env ? atoi(mr_env) : 2048;
-  const bool fits = a.K % 4 == 0 && a.K <= (DT == UA2_BF16 ? 4096 : 2048) && a.M >= min_rows && !getenv("UA2_GEMM_OLD_PREP");   // test hook: the per-row kernel (same bits)
+  // ... and below ~1000 rows the per-row kernel (a workgroup of `waves` waves per row) still wins: at 256 rows the 4-row form's
+  // 64 workgroups cost B = 256 decode 0.8 ms/frame (12.2 against 11.5); at the DiT's 1000 rows it saves ~1 us per prep.
+  const char* m4_env = getenv("UA2_GEMM_PREP4_MIN_ROWS");
+  const int min_rows4 = m4_env ? atoi(m4_env) : 960;
+  const bool fits = a.K % 4 == 0 && a.K <= (DT == UA2_BF16 ? 4096 : 2048) && !getenv("UA2_GEMM_OLD_PREP") && (a.M >= min_rows || a.M >= min_rows4);
   if (fits) {
-    const bool small = a.K <= 2048;
+    const bool small = a.K <= 2048, tile16 = a.M >= min_rows;
     auto go = [&](auto nvw_c) {
       constexpr int W = decltype(nvw_c)::value;
-      if (small) launch_prep16<DT, PRO, W, 8>(a, s);
-      else launch_prep16<DT, PRO, W, 16>(a, s);
+      if (tile16) { if (small) launch_prep16<DT, PRO, W, 8, 16>(a, s); else launch_prep16<DT, PRO, W, 16, 16>(a, s); }
+      else { if (small) launch_prep16<DT, PRO, W, 8, 4>(a, s); else launch_prep16<DT, PRO, W, 16, 4>(a, s); }
     };
     if constexpr (PRO == UA2_PRO_CAST) { go(std::integral_constant<int, 1>{}); return; }
     switch (nvw) {
