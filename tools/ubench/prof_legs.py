@@ -24,6 +24,8 @@ elif leg == "batched":
     print(bench.batched_leg(model, dev))
 elif leg == "batched256":
     print(bench.batched_leg(model, dev, B=256, frames=12, max_seq=128))
+elif leg == "batched1024":
+    print(bench.batched_leg(model, dev, B=1024, frames=6, max_seq=64))
 elif leg == "batched_both":
     print(bench.batched_leg(model, dev))
     print(bench.batched_leg(model, dev, B=256, frames=12, max_seq=128))

@@ -1011,7 +1011,14 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
   constexpr bool kCanHo = (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL);
   const bool ho = kCanHo && a.y_norm_w != nullptr;
   const bool no_glds = getenv("UA2_GEMM_NO_GLDS") != nullptr;                                                          // experiment hook: register staging everywhere
-  const int bmt = force_bmt ? force_bmt : (g8 >= 512 ? 8 : (g4 >= 256 ? 4 : 2));
+  // 64-row tiles already from 192 workgroups (was 256): measured INSIDE the DiT step, where every launch starts on weights
+  // that are in no cache — FF2 (1000 x 1536, K = 6144: 192 workgroups of 64 rows against 384 of 32) 57 -> 43 us, the
+  // O-projection likewise: 6.50 -> 6.05 ms per step.  (On MALL-warm weights, tools/ubench/gemm_shapes.py, the two tiles are
+  // within 3 us of each other — profiles/r4_notes.md §12.)  UA2_GEMM_G8_MIN / UA2_GEMM_G4_MIN: sweep hooks for the two thresholds.
+  const char* g8e = getenv("UA2_GEMM_G8_MIN");
+  const char* g4e = getenv("UA2_GEMM_G4_MIN");
+  const int64_t g8_min = g8e ? atoi(g8e) : 512, g4_min = g4e ? atoi(g4e) : 192;
+  const int bmt = force_bmt ? force_bmt : (g8 >= g8_min ? 8 : (g4 >= g4_min ? 4 : 2));
   const u32x4* ap = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
   auto go = [&](auto bmt_c, auto ho_c, auto gl_c) {
     constexpr int B = decltype(bmt_c)::value;
