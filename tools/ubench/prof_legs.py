@@ -18,6 +18,9 @@ if leg == "stage2":
     print(bench.stage2_leg(dev))
     sys.exit(0)
 model = bench.build_model(dev)
+if os.environ.get("UA2_FORCE_LINEAR_MODE"):      # A/B: 4 = weights-stationary forms wherever they exist, 5 = the tiled GEMM everywhere (same bits)
+    from uniaudio2_amd._lib import lib
+    lib.ua2_debug_force_general_linear(int(os.environ["UA2_FORCE_LINEAR_MODE"]))
 if leg == "config3":
     print(bench.config3_leg(model, dev))
 elif leg == "batched":
