@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 6
+#define UA2_VERSION 7
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -178,6 +178,15 @@ typedef struct ua2_linear_args {
   float* y_ssq;
   const void* x_h;
   const float* x_ssq;
+  /* [v7] Optional scratch for a K split of UA2_EPI_RESIDUAL launches that take the tiled many-row kernel with a long K and a
+     grid too small for the device (the codec DiT's FF2: 1000 x 1536, K = 6144 on 192 workgroups).  When given (and N % 64 == 0,
+     no hand-over outputs, K >= 4096), the launcher may cut K into S <= 4 slabs — S a function of (M, N, K) only — whose
+     workgroups run side by side and write fp32 partial sums [S][M][N] here; a second launch forms
+     y = resid + out_scale (.) ((((s0 + s1) + s2) + s3) + bias) in that fixed order.  Deterministic, but the last bits differ
+     from the unsplit launch (one chain per slab instead of the decode kernel's ranges): callers that rely on the row-count
+     invariance of ua2_linear (every launch of the LM) leave it NULL.  Needs S * M * N * 4 bytes (4 * M * N * 4 always suffices). */
+  float* split_ws;
+  size_t split_ws_bytes;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);

@@ -435,6 +435,59 @@ def test_staged_epilogue_equals_the_per_element_epilogue(dtype, linear_mode):
         os.environ.pop("UA2_GEMM_OLD_EPI", None)
 
 
+def test_k_split_of_long_k_residual_launches(linear_mode):
+    """ua2hip.h split_ws (ABI v7): a RESIDUAL launch with a long K and a small grid may run its K range as up to four slabs side
+    by side and combine them in index order.  Opt-in (scratch given), deterministic, equal to the unsplit launch up to the
+    rounding of a different summation order; without scratch, with too little scratch, with the hook UA2_GEMM_NO_KSPLIT or on
+    shapes outside the rule nothing changes."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 1000, 1536, 6144
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt)
+    x, res = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    bias, gate = (0.3 * torch.randn(N, generator=g)).to(dev), (0.5 * torch.randn(N, generator=g)).to(dev)
+
+    def run(split_elems, **env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            linear_mode(5)
+            y = torch.zeros(M, N, device=dev)
+            sw = torch.full((split_elems,), float("nan"), device=dev) if split_elems else None
+            ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x, y=y, resid=res, bias=bias, out_scale=gate,
+                       workspace=ops.linear_workspace(dt, M, K, dev), split_ws=sw)
+            torch.cuda.synchronize()
+            return y
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+    base = run(0)
+    split4, again = run(4 * M * N), run(4 * M * N)
+    assert torch.equal(split4, again)                                   # deterministic
+    assert not torch.isnan(split4).any()
+    err = (split4 - base).abs().max().item()
+    assert 0 < err < 2e-5 * K ** 0.5, err                              # another summation order, nothing more
+    split2 = run(2 * M * N + 7)                                         # scratch for two slabs only
+    assert torch.equal(split2, run(2 * M * N + 7)) and (split2 - base).abs().max().item() < 2e-5 * K ** 0.5
+    assert torch.equal(run(M * N), base)                                # not even two slabs fit: the unsplit launch
+    assert torch.equal(run(4 * M * N, UA2_GEMM_NO_KSPLIT="1"), base)
+    # outside the rule (short K): scratch or not, the same bits
+    K2 = 1536
+    w2 = ops.pack_linear((torch.randn(N, K2, generator=g) * K2 ** -0.5).to(dev), dt)
+    outs = []
+    for sw in (None, torch.empty(4 * M * N, device=dev)):
+        linear_mode(5)
+        y = torch.zeros(M, N, device=dev)
+        ops.linear(dtype=dt, M=M, N=N, K=K2, w0=w2, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x[:, :K2].contiguous(), y=y, resid=res,
+                   workspace=ops.linear_workspace(dt, M, K2, dev), split_ws=sw)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K,bmt", [(6272, 1024, 3072, 8), (2048, 3072, 8192, 4), (1000, 1536, 6144, 2), (333, 384, 1056, 2)])
 def test_tiled_gemm_ring_is_repeatable(M, N, K, bmt, linear_mode):
     """Race screen for the LDS-DMA operand ring (hand-counted vmcnt + raw s_barrier): 25 launches of the same problem on a

@@ -41,7 +41,8 @@ class LinearArgs(C.Structure):
                 ("norm_b", vp), ("norm_kind", i32), ("out_scale", vp), ("rope_mode", i32),
                 ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp),
                 ("bias", vp), ("bias1", vp), ("act_kind", i32),
-                ("y_norm_w", vp), ("y_h", vp), ("ldh", i32), ("y_ssq", vp), ("x_h", vp), ("x_ssq", vp)]
+                ("y_norm_w", vp), ("y_h", vp), ("ldh", i32), ("y_ssq", vp), ("x_h", vp), ("x_ssq", vp),
+                ("split_ws", vp), ("split_ws_bytes", C.c_size_t)]
 
 
 class AttnArgs(C.Structure):

@@ -702,6 +702,7 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
   // N not a multiple of the wave's column span take the per-element form.
   if constexpr (EPI != UA2_EPI_QKV_ROPE) {
     constexpr int SPAN = WN * 16;                        // columns of one matrix a wave owns: 64 (32 for SWIGLU)
+    const bool slab = (flags & 2) != 0;                  // K split (ua2hip.h split_ws): this workgroup's partial sums, raw, into its slab
     if ((flags & 1) && a.N % SPAN == 0 && !a.part_max) {
       __syncthreads();                                   // every wave is done with the operand ring
       float* patch = reinterpret_cast<float*>(gemm_smem) + (size_t)wave * (kWM * 16) * 64;
@@ -734,10 +735,12 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
       if constexpr (HO) { if (a.y_norm_w) nw4 = *reinterpret_cast<const float4*>(a.y_norm_w + n0); }
       float4 res[ITERS];
       if constexpr (EPI == UA2_EPI_RESIDUAL) {           // every residual piece of the patch requested before the first store
+        if (!slab) {
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-          const int m = mbase + it * RPI + rsub;
-          res[it] = *reinterpret_cast<const float4*>(a.resid + (size_t)min(m, a.M - 1) * a.ldr + n0);
+          for (int it = 0; it < ITERS; ++it) {
+            const int m = mbase + it * RPI + rsub;
+            res[it] = *reinterpret_cast<const float4*>(a.resid + (size_t)min(m, a.M - 1) * a.ldr + n0);
+          }
         }
       }
 #pragma unroll
@@ -756,6 +759,12 @@ __global__ __launch_bounds__(256, (EPI == UA2_EPI_QKV_ROPE && kBMT <= 4 && GL) ?
         }
         if (m >= a.M) continue;
         float4 v0 = *reinterpret_cast<const float4*>(patch + prow * 64 + 4 * j);
+        if constexpr (EPI == UA2_EPI_RESIDUAL) {
+          if (slab) {
+            *reinterpret_cast<float4*>(a.split_ws + ((size_t)blockIdx.y * a.M + m) * a.N + n0) = v0;
+            continue;
+          }
+        }
         float4 v1 = zero4;
         if constexpr (NT == 2) v1 = *reinterpret_cast<const float4*>(patch + prow * 64 + SPAN + 4 * j);
         if (a.prologue == UA2_PRO_SCALED) {
@@ -949,6 +958,33 @@ void launch_skinny(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t 
   hipLaunchKernelGGL(kern, grid, dim3(geo.waves * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace));
 }
 
+// ---- K split (ua2hip.h split_ws): y = resid + out_scale (.) ((((s0 + s1) + s2) + s3) + bias), the slabs in index order ----
+// Same operations as linear_epilogue's RESIDUAL branch on the combined sum.
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const ua2_linear_args a, const int slabs) {
+  const int n4 = a.N >> 2;
+  const size_t total = (size_t)a.M * n4, slab_elems = (size_t)a.M * a.N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+    const float* p = a.split_ws + (size_t)m * a.N + n;
+    float4 t = *reinterpret_cast<const float4*>(p);
+    for (int k = 1; k < slabs; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (size_t)k * slab_elems);
+      t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
+    }
+    if (a.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      t.x = __fadd_rn(t.x, b.x); t.y = __fadd_rn(t.y, b.y); t.z = __fadd_rn(t.z, b.z); t.w = __fadd_rn(t.w, b.w);
+    }
+    if (a.out_scale) {
+      const float4 g = *reinterpret_cast<const float4*>(a.out_scale + n);
+      t.x = __fmul_rn(g.x, t.x); t.y = __fmul_rn(g.y, t.y); t.z = __fmul_rn(g.z, t.z); t.w = __fmul_rn(g.w, t.w);
+    }
+    const float4 r = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n);
+    t.x = __fadd_rn(t.x, r.x); t.y = __fadd_rn(t.y, r.y); t.z = __fadd_rn(t.z, r.z); t.w = __fadd_rn(t.w, r.w);
+    *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = t;
+  }
+}
+
 template <int DT, int PRO, int NVW, int MAXV, int ROWS>
 void launch_prep16(const ua2_linear_args& a, hipStream_t s) {
   constexpr auto kern = gemm_prep16_kernel<DT, PRO, NVW, MAXV, ROWS>;
@@ -1030,9 +1066,28 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
     size_t smem = (size_t)(G ? ring_slots(B) : 2 * kKS) * TILES * 1024;
     smem = std::max(smem, (size_t)4 * (B / 2) * 16 * 64 * sizeof(float));   // the staged epilogues park a 64-column patch per wave in the ring
     const char* ks_env = getenv("UA2_GEMM_KSPLIT_HACK");   // timing experiment: every slab runs the full epilogue on its partial sums (wrong results)
-    const int ks = ks_env ? std::max(1, atoi(ks_env)) : 1;
-    const int flags = getenv("UA2_GEMM_OLD_EPI") ? 0 : 1;   // test hook: the per-element epilogue everywhere (same bits)
+    int ks = ks_env ? std::max(1, atoi(ks_env)) : 1;
+    int split_flags = 0;
+    if constexpr (EPI == UA2_EPI_RESIDUAL && !H) {
+      // K split proper (ua2hip.h split_ws): long K, a grid that leaves the device short of work, scratch for the slabs.  S depends on
+      // the shape only.  Measured inside the DiT step (FF2, 1000 x 1536, K = 6144, 192 workgroups): 6.06 -> 5.49 ms per step
+      // with 4 slabs before the combine launch, 5.74 with 2 (timing-only hook UA2_GEMM_KSPLIT_LONGK, profiles/r4_notes.md §12).
+      const int64_t grid1 = (int64_t)mblocks * nblocks;
+      if (a.split_ws && a.prologue != UA2_PRO_SCALED && !a.part_max && a.N % 64 == 0 && a.ldr % 4 == 0 && a.ldy % 4 == 0 &&
+          ua2_ceil_div(a.K, Elem<DT>::KC) >= 128 && grid1 < 512 && !getenv("UA2_GEMM_NO_KSPLIT")) {
+        const int want = (int)std::min<int64_t>(4, (768 + grid1 - 1) / grid1);
+        const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
+        if (std::min(want, fit) > 1) { ks = std::min(want, fit); split_flags = 2; }
+      }
+    }
+    if (const char* e2 = getenv("UA2_GEMM_KSPLIT_LONGK"))   // the same, only for RESIDUAL launches with K >= 4096 (the DiT's FF2 inside the step)
+      if (EPI == UA2_EPI_RESIDUAL && ua2_ceil_div(a.K, Elem<DT>::KC) >= 128) ks = std::max(1, atoi(e2));
+    const int flags = (getenv("UA2_GEMM_OLD_EPI") && !split_flags ? 0 : 1) | split_flags;   // test hook: the per-element epilogue everywhere (same bits)
     hipLaunchKernelGGL(kern, dim3(mblocks * nblocks, ks), dim3(256), smem, s, a, ap, ks > 1 ? 1 : nw, mblocks, nblocks, group_m, flags);
+    if (split_flags) {
+      const size_t total4 = (size_t)a.M * (a.N / 4);
+      hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
+    }
   };
   auto pick = [&](auto bmt_c) {
     if constexpr (kCanHo) { if (ho) { go(bmt_c, std::true_type{}, std::false_type{}); return; } }

@@ -115,6 +115,10 @@ class BasicTransformerBlock(nn.Module):
         p["qkv"](h, epilogue=EPI_QKV_ROPE, norm=(w_a, sh_a, self.eps), rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq,
                  q_out=q, kv=kv.geom)
         M = h.shape[0]
+        # scratch for the K split of FF2 (ua2hip.h split_ws: K = 4 D on a 1000-row problem leaves 3/4 of the device's workgroup slots
+        # empty; four slabs side by side + a combine launch, fixed order).  One buffer per K/V plan, shared by the blocks.
+        if getattr(kv, "split_ws", None) is None or kv.split_ws.numel() < 4 * M * D:
+            kv.split_ws = torch.empty(4 * M * D, dtype=torch.float32, device=h.device)
         if self.packed_handoff and kv.groups is not None and M > 16 and D % 32 == 0:
             # bf16 plan at many rows: attention and GELU write their consumer's operand in fragment order (same rounding as
             # the consumer's own prep launch would apply: identical bits, two launches less per layer)
@@ -122,12 +126,12 @@ class BasicTransformerBlock(nn.Module):
             kv.attend(q, y_packed=ws_o)
             p["out"](None, M=M, x_packed=ws_o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
             p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH, y_packed=ws_f)
-            p["ff2"](None, M=M, x_packed=ws_f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h)
+            p["ff2"](None, M=M, x_packed=ws_f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h, split_ws=kv.split_ws)
             return h
         o = kv.attend(q)
         p["out"](o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
         f = p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH)
-        p["ff2"](f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h)
+        p["ff2"](f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h, split_ws=kv.split_ws)
         return h
 
 
