@@ -1074,7 +1074,8 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
       // with 4 slabs before the combine launch, 5.74 with 2 (timing-only hook UA2_GEMM_KSPLIT_LONGK, profiles/r4_notes.md §12).
       const int64_t grid1 = (int64_t)mblocks * nblocks;
       if (a.split_ws && a.prologue != UA2_PRO_SCALED && !a.part_max && a.N % 64 == 0 && a.ldr % 4 == 0 && a.ldy % 4 == 0 &&
-          ua2_ceil_div(a.K, Elem<DT>::KC) >= 128 && grid1 < 512 && !getenv("UA2_GEMM_NO_KSPLIT")) {
+          ua2_ceil_div(a.K, Elem<DT>::KC) >= (getenv("UA2_GEMM_KSPLIT_MIN_CHUNKS") ? atoi(getenv("UA2_GEMM_KSPLIT_MIN_CHUNKS")) : 128) &&
+          grid1 < 512 && !getenv("UA2_GEMM_NO_KSPLIT")) {
         const int want = (int)std::min<int64_t>(4, (768 + grid1 - 1) / grid1);
         const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
         if (std::min(want, fit) > 1) { ks = std::min(want, fit); split_flags = 2; }
