@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 7
+#define UA2_VERSION 8
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -68,6 +68,9 @@ enum ua2_act_kind {
   UA2_GATE_SIGMOID_SECOND = 2   /* SWIGLU: (xW0^T + b0) * sigmoid(xW1^T + b1)  — the GLU of ReasoningCodec_film/
                                    modules/transformer.py:208-243 under power_normalized (proj output chunked x | gate) */
 };
+
+/* ua2_linear_args.sum_order */
+enum ua2_sum_order { UA2_SUM_ORDER_INVARIANT = 0, UA2_SUM_ORDER_FREE = 1 };
 
 /* flavours of UA2_PRO_NORM */
 enum ua2_norm_kind {
@@ -187,6 +190,14 @@ typedef struct ua2_linear_args {
      invariance of ua2_linear (every launch of the LM) leave it NULL.  Needs S * M * N * 4 bytes (4 * M * N * 4 always suffices). */
   float* split_ws;
   size_t split_ws_bytes;
+  /* [v8] Summation-order contract of the K sum (enum ua2_sum_order).  UA2_SUM_ORDER_INVARIANT (0, the default): a row's bits are
+     those of the decode kernel whatever the row count or the kernel (`waves` partial chains over fixed K ranges, added in wave
+     order) — every launch of the LM's fp32 plan and of its bf16 plan below 2048 rows.  UA2_SUM_ORDER_FREE: the order is the
+     launcher's choice (one chain over K per slab on the 256-row-tile kernel of csrc/ua2_gemm2.hip; S slabs with split_ws) —
+     deterministic for a given (M, N, K, scratch), fp32 rounding noise (~1e-6 relative) against the invariant form; for callers
+     outside the LM's row-invariance contract (codec DiT, AudioThinking, Mimi) and, as a plan option, LM launches of >= 2048
+     rows.  bf16 only; launches outside the fast kernel's forms silently take the invariant kernels. */
+  int32_t sum_order;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);

@@ -1,0 +1,214 @@
+"""The order-free many-row GEMM (csrc/ua2_gemm2.hip, ua2hip.h `sum_order = UA2_SUM_ORDER_FREE`) against the row-invariant
+kernels of ua2_gemm.hip on the same launches.
+
+Contract under test: same function, same per-value epilogue operations, another order of the K sum (one MFMA chain per K slab
+instead of the decode kernel's wave ranges) — so fp32 outputs agree to fp32 summation noise (bounded here by 2e-5 sqrt(K) on
+unit-scale sums, the bar of the K-split test), bf16 outputs (packed operand hand-offs, K/V pages) to one bf16 rounding of that
+noise, and the launch is deterministic (same bits every time: the race screen of the two-group phase structure).  The invariant
+kernels themselves are pinned on the decode kernel, which is pinned on the oracle (tests/test_gpu_invariance.py,
+tests/test_gpu_lm.py)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, K, what):
+    if a.dtype == torch.bfloat16:
+        a, b = a.float(), b.float()
+        tol = 2e-5 * K ** 0.5 + 2.0 ** -7 * b.abs()            # the fp32 noise can flip one bf16 rounding
+        bad = (a - b).abs() > tol
+        assert not bad.any(), (what, int(bad.sum()), float((a - b).abs().max()))
+        assert (a != b).float().mean().item() < 0.02, (what, "more than 2 % of the bf16 values differ")
+    else:
+        err = (a - b).abs().max().item()
+        assert err < 2e-5 * K ** 0.5, (what, err)
+
+
+@pytest.fixture
+def g2env():
+    keys = ("UA2_GEMM2_BMT", "UA2_GEMM2_OFF", "UA2_GEMM2_MIN_ROWS", "UA2_GEMM2_FORCE", "UA2_GEMM_NO_KSPLIT")
+    saved = {k: os.environ.get(k) for k in keys}
+
+    def set_(**kw):
+        for k in keys:
+            os.environ.pop(k, None)
+        for k, v in kw.items():
+            os.environ[k] = str(v)
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("bmt", [16, 8])
+def test_every_epilogue_agrees_with_the_invariant_kernels(bmt, g2env):
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import (EPI_GELU, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, GATE_SIGMOID_SECOND, GELU_TANH, NORM_LAYERNORM, PRO_CAST,
+                                    PRO_NORM, SUM_ORDER_FREE)
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(5 + bmt)
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=g)).to(dev)
+    for (N, K) in ((1536, 1056), (512, 3072), (4608, 1536)):
+        p0, p1 = ops.pack_linear(mk(N, K, s=K ** -0.5), dt), ops.pack_linear(mk(N, K, s=K ** -0.5), dt)
+        bias, bias1, gate, nw, nb = mk(N, s=0.3), mk(N, s=0.3), mk(N, s=0.5), 1.0 + mk(K, s=0.1), mk(K, s=0.1)
+        Mmax = 1300
+        x, res = mk(Mmax, K), mk(Mmax, N, s=2.0)
+
+        def run(M, epi, order, **opt):
+            outs = {}
+            kw = dict(dtype=dt, M=M, N=N, K=K, w0=p0, epilogue=epi, workspace=ops.linear_workspace(dt, M, K, dev), sum_order=order)
+            if opt.get("ln"):
+                kw.update(prologue=PRO_NORM, x=x[:M].contiguous(), norm_w=nw, norm_b=nb, eps=1e-6, norm_kind=NORM_LAYERNORM)
+            elif opt.get("cast"):
+                kw.update(prologue=PRO_CAST, x=x[:M].contiguous())
+            else:
+                kw.update(prologue=PRO_NORM, x=x[:M].contiguous(), norm_w=nw, eps=1e-5)
+            if opt.get("bias"):
+                kw.update(bias=bias, bias1=bias1 if epi == EPI_SWIGLU else None)
+            if epi == EPI_SWIGLU:
+                kw.update(w1=p1, act_kind=opt.get("act", 0))
+            if epi == EPI_GELU:
+                kw.update(act_kind=opt.get("act", 0))
+            if epi == EPI_RESIDUAL:
+                kw.update(resid=res[:M].contiguous(), out_scale=gate if opt.get("gate") else None)
+            if opt.get("y", True):
+                outs["y"] = torch.zeros(M, N, device=dev)
+                kw.update(y=outs["y"])
+            if opt.get("packed"):
+                outs["packed"] = torch.zeros((M + 15) // 16 * 16 * N, dtype=dt, device=dev)
+                kw.update(y_packed=outs["packed"])
+            ops.linear(**kw)
+            torch.cuda.synchronize()
+            return outs
+
+        cases = [(EPI_STORE, dict()), (EPI_STORE, dict(bias=True, cast=True)),
+                 (EPI_RESIDUAL, dict(cast=True)), (EPI_RESIDUAL, dict(bias=True, gate=True, ln=True)),
+                 (EPI_SWIGLU, dict()), (EPI_SWIGLU, dict(bias=True, act=GATE_SIGMOID_SECOND, packed=True)), (EPI_SWIGLU, dict(packed=True, y=False)),
+                 (EPI_GELU, dict(bias=True)), (EPI_GELU, dict(act=GELU_TANH, packed=True, y=False, ln=True))]
+        for epi, opt in cases:
+            for M in (1300, 1000, 257):
+                g2env(UA2_GEMM2_OFF=1)
+                want = run(M, epi, SUM_ORDER_FREE, **opt)              # the switch-off hook: the invariant kernels
+                g2env()
+                assert all(torch.equal(want[k], v) for k, v in run(M, epi, 0, **opt).items())   # ... which the default contract always takes
+                g2env(UA2_GEMM2_BMT=bmt)
+                got, again = run(M, epi, SUM_ORDER_FREE, **opt), run(M, epi, SUM_ORDER_FREE, **opt)
+                assert want.keys() == got.keys() and len(want) > 0
+                differs = False
+                for k in want:
+                    assert torch.equal(got[k], again[k]), (N, K, epi, opt, M, k, "not deterministic")
+                    _close(got[k], want[k], K, (N, K, epi, opt, M, k))
+                    differs |= not torch.equal(got[k], want[k])
+                    assert got[k].float().abs().sum().item() > 0
+                if K >= 1536:
+                    assert differs, (N, K, epi, opt, M, "bit-identical to the invariant kernel: the order-free kernel did not run")
+
+
+@pytest.mark.parametrize("bmt", [16, 8])
+@pytest.mark.parametrize("nh,nkv,hs,C,M", [(24, 8, 128, 3072, 700), (24, 24, 64, 1536, 1000)])
+def test_qkv_epilogues_agree(nh, nkv, hs, C, M, bmt, g2env):
+    """Fused norm + q|k|v + (RoPE) + paged K/V append: the LM's form (half-split rotation, head size 128) and the DiT's (no
+    rotation, bias, head size 64).  Rows of three sequences at scattered positions."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_QKV_ROPE, PRO_NORM, ROPE_NONE, SUM_ORDER_FREE
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(hs + bmt)
+    nq = (nh + 2 * nkv) * hs
+    dit = nh == nkv
+    extra = dict(rope_mode=ROPE_NONE, bias=(0.1 * torch.randn(nq, generator=g)).to(dev)) if dit else {}
+    w = ops.pack_linear((torch.randn(nq, C, generator=g) * C ** -0.5).to(dev), dt, **({} if dit else dict(rope_head_size=hs)))
+    x = torch.randn(M, C, generator=g).to(dev)
+    nw = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    nseq = 3
+    per = (M + nseq - 1) // nseq
+    pos = torch.cat([torch.arange(per) for _ in range(nseq)])[:M].to(torch.int32).to(dev)
+    seq = torch.arange(nseq).repeat_interleave(per)[:M].to(torch.int32).to(dev)
+    npg = (per + 63) // 64
+    ang = torch.rand(2048, hs // 2, generator=g) * 6.28
+    cos, sin = ang.cos().to(dev), ang.sin().to(dev)
+    pt = torch.randperm(nseq * npg, generator=g).to(torch.int32).view(nseq, npg).to(dev)
+    outs = []
+    for order, env in ((0, {}), (SUM_ORDER_FREE, dict(UA2_GEMM2_BMT=bmt)), (SUM_ORDER_FREE, dict(UA2_GEMM2_BMT=bmt))):
+        g2env(**env)
+        kp = torch.zeros(nseq * npg, nkv, 64, hs, dtype=dt, device=dev)
+        vp = torch.zeros_like(kp)
+        q = torch.zeros(M, nh * hs, device=dev)
+        ops.linear(dtype=dt, M=M, N=nq, K=C, w0=w, prologue=PRO_NORM, epilogue=EPI_QKV_ROPE, x=x, norm_w=nw, row_pos=pos, row_seq=seq,
+                   rope_cos=cos, rope_sin=sin, q_out=q, kv=ops.kv_geom(kp, vp, pt, nh, nkv, hs), workspace=ops.linear_workspace(dt, M, C, dev),
+                   sum_order=order, **extra)
+        torch.cuda.synchronize()
+        outs.append((q, kp, vp))
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+    for name, a, b in zip(("q", "k", "v"), outs[1], outs[0]):
+        _close(a, b, C, (name, nh, hs, bmt))
+    assert not torch.equal(outs[1][0], outs[0][0])
+    assert outs[1][1].float().abs().sum() > 0 and outs[1][2].float().abs().sum() > 0
+
+
+def test_k_slabs_on_small_grids(g2env):
+    """A long-K RESIDUAL launch on a grid too small for the device runs as K slabs + the fixed-order combine (split_ws)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST, SUM_ORDER_FREE
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 1000, 1536, 6144
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt)
+    x, res = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    bias, gate = (0.3 * torch.randn(N, generator=g)).to(dev), (0.5 * torch.randn(N, generator=g)).to(dev)
+
+    def run(order, split_elems, **env):
+        g2env(**env)
+        y = torch.zeros(M, N, device=dev)
+        sw = torch.full((split_elems,), float("nan"), device=dev) if split_elems else None
+        ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x, y=y, resid=res, bias=bias, out_scale=gate,
+                   workspace=ops.linear_workspace(dt, M, K, dev), split_ws=sw, sum_order=order)
+        torch.cuda.synchronize()
+        return y
+
+    base = run(0, 0)
+    one = run(SUM_ORDER_FREE, 0)
+    four, again = run(SUM_ORDER_FREE, 4 * M * N), run(SUM_ORDER_FREE, 4 * M * N)
+    assert torch.equal(four, again) and not torch.isnan(four).any()
+    for y in (one, four, run(SUM_ORDER_FREE, 2 * M * N + 3), run(SUM_ORDER_FREE, 4 * M * N, UA2_GEMM_NO_KSPLIT=1)):
+        assert 0 < (y - base).abs().max().item() < 2e-5 * K ** 0.5
+    assert not torch.equal(one, four)
+
+
+@pytest.mark.parametrize("M,N,K,bmt", [(6272, 1024, 3072, 16), (8000, 1536, 1536, 16), (1000, 1536, 6144, 8), (333, 512, 1056, 8), (2048, 3072, 8192, 16)])
+def test_phase_structure_is_repeatable(M, N, K, bmt, g2env):
+    """Race screen for the two-group phase loop (hand-counted vmcnt, raw s_barrier, LDS-DMA into slots another group has just
+    read): 25 launches on a busy device give the same bits, with a second stream streaming memory beside them, and those bits
+    agree with the invariant kernel's to summation noise in EVERY element (a stale or early fragment is an O(1) error)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST, SUM_ORDER_FREE
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt)
+    x, res = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    ws = ops.linear_workspace(dt, M, K, dev)
+
+    def run(order):
+        y = torch.zeros(M, N, device=dev)
+        ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x, y=y, resid=res, workspace=ws, sum_order=order)
+        return y
+
+    g2env()
+    base = run(0)
+    g2env(UA2_GEMM2_BMT=bmt)
+    first = run(SUM_ORDER_FREE)
+    torch.cuda.synchronize()
+    assert (first - base).abs().max().item() < 2e-5 * K ** 0.5
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=dev)
+    for i in range(25):
+        with torch.cuda.stream(side):
+            junk.add_(1.0)
+        y = run(SUM_ORDER_FREE)
+        torch.cuda.synchronize()
+        assert torch.equal(y, first), (i, (y - first).abs().max().item())

@@ -155,3 +155,93 @@ def test_gemm_ring_waits_match_the_requests_in_flight(gemm_asm):
                 assert dma == loads, f"{name}: {dma} requests per step, the waits assume {loads}"
                 assert not other, f"{name}: other vector-memory traffic inside the ring loop: {other[:3]}"
             assert not drains, f"{name}: the compiler drains the ring inside the loop: {drains[:2]}"
+
+
+def test_compiler_never_touches_m0_around_the_dma(asm):
+    """lds_dma16 overwrites M0 (the LDS-DMA's destination base) without declaring it — the compiler ignores a clobber of that
+    reserved register and says so once per call site.  The overwrite is safe as long as hipcc itself keeps nothing in M0:
+    no instruction outside the inline-asm blocks of any kernel of the file may read or write it."""
+    m0 = re.compile(r"\bm0\b")
+    for name, ins in _kernels(asm).items():
+        for t, inasm in ins:
+            if not inasm:
+                assert not m0.search(t), f"{name}: compiler-emitted use of m0: {t}"
+    # ... and the build is free of the 'clobber list contains reserved registers' warning (one per call site before)
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", os.devnull],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    assert "reserved registers" not in out, out[:400]
+
+
+# ---- the order-free GEMM (ua2_gemm2.hip): two wave groups in opposite phases over an LDS-DMA ring ---------------------------
+# Per chunk a wave (i) reads its fragments, (ii) issues LOADS requests of chunk c + NB - 1, (iii) waits — group 1 behind the
+# requests, group 0 behind its MFMAs — with `s_waitcnt vmcnt((NB - 2) * LOADS)`: right iff exactly LOADS requests and nothing else
+# enter the wave's vector-memory queue per chunk step, M0 is restored by the statement that sets it, and the compiler adds no
+# vmcnt drain of its own inside the loop.
+
+@pytest.fixture(scope="module")
+def gemm2_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "gemm2.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           os.path.join(CSRC, "ua2_gemm2.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def test_gemm2_phase_loop_requests_and_waits(gemm2_asm):
+    ks = {k: v for k, v in _kernels(gemm2_asm).items() if "gemm2_kernel" in k}
+    assert len(ks) >= 10, sorted(_kernels(gemm2_asm))
+    vmem = re.compile(r"(global|buffer|flat|scratch)_(load|store|atomic)")
+    m0 = re.compile(r"\bm0\b")
+    for name, ins in ks.items():
+        bmt, nb = (int(x) for x in re.search(r"gemm2_kernelILi\d+ELi(\d+)ELi(\d+)E", name).groups())
+        loads = (bmt + 16) // 8
+        first_mfma = next(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
+        last_mfma = max(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
+        # prologue: NB - 1 chunks requested, then the wait that leaves NB - 2 in flight
+        pre = [t for t, _ in ins[:first_mfma]]
+        hand_pre = [int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1)) for t, inasm in ins[:first_mfma] if inasm and t.startswith("s_waitcnt vmcnt")]
+        assert hand_pre and hand_pre[0] == (nb - 2) * loads, (name, hand_pre)
+        n_pre_dma = 0
+        for t in pre:
+            if t.startswith("s_waitcnt vmcnt"):
+                break
+            n_pre_dma += t.startswith("global_load_lds")
+        assert n_pre_dma == (nb - 1) * loads, (name, n_pre_dma)
+        # the loop: split at the hand-written barriers; every L phase carries exactly LOADS requests, C phases none
+        loop = ins[first_mfma - 200 if first_mfma > 200 else 0:last_mfma + 1]
+        seg_dma, seg_mfma, seg = [], [], [0, 0]
+        for t, inasm in ins[:last_mfma + 40]:
+            if t.startswith("global_load_lds"):
+                assert inasm, f"{name}: compiler-emitted LDS-DMA"
+                seg[0] += 1
+            elif t.startswith("v_mfma"):
+                seg[1] += 1
+            elif t.startswith("s_barrier"):
+                assert inasm, f"{name}: compiler-emitted s_barrier inside the phase loop"
+                seg_dma.append(seg[0]); seg_mfma.append(seg[1]); seg = [0, 0]
+            elif not inasm:
+                assert not (t.startswith("s_waitcnt") and "vmcnt" in t), f"{name}: compiler vmcnt wait in the phase loop: {t}"
+                assert not vmem.match(t), f"{name}: other vector-memory traffic in the phase loop: {t}"
+                assert not m0.search(t), f"{name}: compiler-emitted use of m0: {t}"
+        phases = [(d, m) for d, m in zip(seg_dma, seg_mfma) if d or m]
+        l_phases = [p for p in phases if p[0] and not p[1]]
+        c_phases = [p for p in phases if p[1]]
+        assert len(c_phases) == nb, (name, phases)                       # the loop is unrolled over the ring
+        assert all(m == 4 * bmt // 2 and d == 0 for d, m in c_phases), (name, phases)
+        assert sum(1 for d, _ in l_phases if d == loads) == nb, (name, phases)
+        # hand waits inside the loop all leave NB - 2 chunks in flight; the one in front of the epilogue drains
+        hand = [int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1)) for t, inasm in ins if inasm and t.startswith("s_waitcnt vmcnt")]
+        assert hand[-1] == 0 and set(hand[:-1]) == {(nb - 2) * loads}, (name, hand)
+        assert len(hand) == 1 + 2 * nb + 1, (name, hand)                 # prologue + (group 1 in L, group 0 in C) per unrolled step + drain
+        # M0 saved before and restored after every request batch
+        text = [t for t, inasm in ins if inasm]
+        assert sum(1 for t in text if re.match(r"s_mov_b32 s\d+, m0", t)) == sum(1 for t in text if re.match(r"s_mov_b32 m0, s\d+", t)) - sum(
+            1 for t in text if t.startswith("global_load_lds")), name
+
+
+def test_gemm2_no_scratch(gemm2_asm):
+    names = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", gemm2_asm)
+    vg = dict(re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", gemm2_asm))
+    assert len(names) >= 10
+    for name, scratch in names:
+        assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
+        assert int(vg[name]) <= 256, name

@@ -22,6 +22,7 @@ EPI_STORE, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV_ROPE, EPI_GELU = 0, 1, 2, 3, 4
 NORM_RMS_LIT, NORM_RMS_MOSHI, NORM_LAYERNORM = 0, 1, 2
 ROPE_HALF_SPLIT, ROPE_INTERLEAVED, ROPE_NONE = 0, 1, 2
 ACT_KIND_DEFAULT, GELU_TANH, GATE_SIGMOID_SECOND = 0, 1, 2
+SUM_ORDER_INVARIANT, SUM_ORDER_FREE = 0, 1
 UA2_PAGE = 64
 
 vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
@@ -42,7 +43,7 @@ class LinearArgs(C.Structure):
                 ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp),
                 ("bias", vp), ("bias1", vp), ("act_kind", i32),
                 ("y_norm_w", vp), ("y_h", vp), ("ldh", i32), ("y_ssq", vp), ("x_h", vp), ("x_ssq", vp),
-                ("split_ws", vp), ("split_ws_bytes", C.c_size_t)]
+                ("split_ws", vp), ("split_ws_bytes", C.c_size_t), ("sum_order", i32)]
 
 
 class AttnArgs(C.Structure):

@@ -1143,6 +1143,10 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
     launch_prep<DT, UA2_PRO_CAST>(a, geo.waves * 64, s);
   }
   UA2_LAUNCH_CHECK();
+  // callers outside the row-invariance contract (ua2hip.h sum_order): the 256-row-tile kernel with one chain over K.
+  // UA2_GEMM2_FORCE: experiment hook — every eligible bf16 launch, whatever its contract (in-situ timing of LM prefill / big batches).
+  if (a.sum_order == UA2_SUM_ORDER_FREE || getenv("UA2_GEMM2_FORCE"))
+    if (const int rc = ua2_gemm2_try_launch(a, s); rc <= 0) return rc;
   const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
   // The weights-stationary form (ua2_skinny.hip) serves the model's bf16 shapes up to a few hundred rows: measured against
   // the tiled kernel it wins up to 256 rows everywhere except the 128k-column lm_head (profiles/r3_skinny_sweep.txt).

@@ -1,0 +1,511 @@
+// Many-row form of ua2_linear under the ORDER-FREE contract (ua2hip.h: ua2_linear_args.sum_order = UA2_SUM_ORDER_FREE).
+//
+// Replaces the same reference code as ua2_gemm.hip — nn.Linear call sites with the op before and after fused — for the callers that
+// are NOT under the LM's row-invariance contract: the codec's flow-matching DiT (transformer_1d_flow.py:162-386, attention.py:97-420:
+// q|k|v, to_out, ff.net.0 / ff.net.2), the AudioThinking encoder, the Mimi transformers, and — as a plan option — LM launches of
+// >= 2048 rows (lit_model.py:424,511,591-595: prefill of batches, config 3; decode frames of > 1000 sequences).
+//
+// Why a second kernel.  ua2_gemm.hip reproduces the decode kernel's summation order (a row = `waves` partial MFMA chains added in
+// wave order) by retiring a running chain into a second accumulator set: 2 x the accumulator registers, which caps the wave tile at
+// 64 x 64 inside 256 VGPRs and the workgroup at 4 waves x 128 x 128 — the regime MI355X runs at ~0.25-0.35 of its bf16 peak, with
+// the LDS-DMA issue time of a wave ADDING to its MFMA time (profiles/r4_notes.md §9).  Here a row's dot product is ONE chain over K
+// in chunk order (per K slab, when a launch is cut into slabs), so:
+//   * one accumulator set: a wave owns 128 x 64 (8 x 4 tiles of 16 x 16 = 128 accumulator registers),
+//   * the workgroup is 8 waves = 256 x 256 (BMT = 16) or 128 x 256 (BMT = 8), one workgroup per CU,
+//   * the two waves of every SIMD run in OPPOSITE phases: while one multiplies chunk c (32 MFMAs, s_setprio 1) its partner reads
+//     the fragments of its next chunk from LDS and issues its LDS-DMA requests, then they swap — the structure the guide's 256^2
+//     8-phase template measures at 1.3-1.5 PFLOP/s (cdna_hip_programming.md §5; MI355X_MICROARCH.md "Two waves per SIMD").
+//
+// Operands: both in MFMA fragment order [tile of 16][K / 32][64 lanes][16 B] (ua2_pack_linear for the weights, the prep launch or
+// the producer's y_packed for the activations) — the LDS image of a fragment block IS its global image, so an LDS-DMA request is
+// one 1 KiB block (lane i's 16 bytes land at base + 16 i) and every fragment read is a conflict-free lane-linear ds_read_b128; no
+// swizzle on either side.
+//
+// Ring: NB slots of one chunk (BMT + 16 fragment blocks).  Phases are separated by raw s_barriers; group 0 = waves 0-3 (rows
+// 0 .. 8 BMT - 1 of the tile), group 1 = waves 4-7 (the other half), wave w and w + 4 share a SIMD:
+//     phase        2c        2c + 1      2c + 2      2c + 3
+//     group 0      L(c)      C(c)        L(c + 1)    C(c + 1)
+//     group 1      C(c - 1)  L(c)        C(c)        L(c + 1)
+//   L(c): read the wave's WM + 4 fragments of chunk c from slot c % NB (ds_read_b128), request the wave's LOADS blocks of chunk
+//         c + NB - 1 into slot (c - 1) % NB — both groups have read chunk c - 1 by then: group 1 in phase 2c - 1 — and wait
+//         lgkmcnt(0) in front of the barrier (the slot's next writer is a DMA two phases on).
+//   C(c): 8 WM MFMAs.
+//   landing: chunk c + 1 must be in LDS when phase 2c + 2 starts; every wave waits for ITS pieces of it — hand-counted
+//         `s_waitcnt vmcnt((NB - 2) LOADS)`: the NB - 2 younger chunks stay in flight, vmcnt retires in order — at the end of phase
+//         2c + 1 (group 0: behind C(c); group 1: behind L(c)), in front of the barrier every reader passes.
+// The DMA is issued through inline asm (the builtin makes hipcc drain vmcnt / lgkmcnt at every later dependency:
+// profiles/r4_notes.md §2) and the waits are hand-counted; tests/test_isa_waits.py checks the compiled code for exactly that.
+//
+// Epilogues: the staged forms of ua2_gemm.hip — a wave parks PM x 16 rows x 64 columns of its patch (fp32) in its share of the idle
+// ring and walks it by rows, 4 consecutive columns per lane — with the same operations per value, so a launch differs from
+// ua2_gemm.hip's only by the order of the K sum (fp32 rounding noise, ~1e-6 relative).  STORE, RESIDUAL (+ bias, out_scale, K slabs),
+// SWIGLU, GELU (+ packed hand-off), q|k|v with half-split RoPE at head size 128 (the LM) or no rotation + bias at head size 64 (the
+// DiT).  Anything else (partial arg-max outputs, scaled-norm hand-over, other head sizes) stays on ua2_gemm.hip.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "ua2_common.h"
+#include "ua2_linear_common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned g2_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+
+// LOADS LDS-DMA requests of 1 KiB (16 B per lane) in one statement: block j comes from the wave-uniform base s_j + the lane's
+// `voff` and lands at LDS address d_j + 16 lane.  M0 (the DMA's LDS base) is saved and restored inside the statement: it is
+// compiler-reserved and a clobber would be ignored (cdna_hip_programming.md §5.7).  `s_nop 4`: the bases are fresh SALU results,
+// and nothing inside an asm string is padded by the compiler (SALU write -> VMEM read of the SGPR).
+__device__ __forceinline__ void g2_dma(const char* s0, const char* s1, const char* s2, const char* s3, unsigned voff, unsigned d0,
+                                       unsigned d1, unsigned d2, unsigned d3) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %2\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %3\n\t"
+      "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %4\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "v"(voff), "s"(d0), "s"(d1), "s"(d2), "s"(d3)
+      : "memory");
+}
+__device__ __forceinline__ void g2_dma(const char* s0, const char* s1, const char* s2, unsigned voff, unsigned d0, unsigned d1,
+                                       unsigned d2) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\ts_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(s0), "s"(s1), "s"(s2), "v"(voff), "s"(d0), "s"(d1), "s"(d2)
+      : "memory");
+}
+
+// Timing-only knock-outs (tools/ubench/build_alt.sh ... -DUA2_G2_DBG=<bits>; wrong results): 1 no ring refills after the prologue,
+// 2 no MFMAs, 4 no fragment reads.
+#ifndef UA2_G2_DBG
+#define UA2_G2_DBG 0
+#endif
+
+template <int EPI, int BMT, int NB>
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, const char* __restrict__ apack, const int mblocks,
+                                                       const int nblocks, const int group_m, const int flags) {
+  constexpr int KC = 32;
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  constexpr int WM = BMT / 2;            // row tiles per wave (two groups of four waves split the rows)
+  constexpr int WNT = 4 / NT;            // column tiles per wave, per matrix
+  constexpr int BNM = 16 / NT;           // column tiles per workgroup, per matrix
+  constexpr int TILES = BMT + 16;        // fragment blocks per chunk
+  constexpr int LOADS = TILES / 8;       // LDS-DMA requests per wave and chunk
+  constexpr int NF = WM + 4;             // fragments a wave reads per chunk
+  static_assert(TILES % 8 == 0 && (LOADS == 3 || LOADS == 4), "request lists below");
+  static_assert((NB - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char g2_smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int nchunks_all = (a.K + KC - 1) / KC;
+  const int c_lo = (int)(((long)blockIdx.y * nchunks_all) / gridDim.y), c_hi = (int)(((long)(blockIdx.y + 1) * nchunks_all) / gridDim.y);
+  const int nchunks = c_hi - c_lo;
+  const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
+
+  // workgroup id -> (row-block pm, column-block pn), as ua2_gemm.hip: an XCD gets a contiguous id range, row-blocks fastest inside
+  // patches of group_m
+  int pid = blockIdx.x;
+  const int total = gridDim.x;
+  if (total % 8 == 0) pid = (pid & 7) * (total >> 3) + (pid >> 3);
+  const int per_group = group_m * nblocks;
+  const int group = pid / per_group, first_m = group * group_m;
+  const int gsz = min(mblocks - first_m, group_m);
+  const int pm = first_m + (pid % per_group) % gsz;
+  const int pn = (pid % per_group) / gsz;
+
+  // this wave's LOADS fragment streams: block j * 8 + wave of the chunk
+  const char* tb[LOADS];
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) {
+    const int tile = j * 8 + wave;
+    if (tile < BMT) {
+      const int mt = min(pm * BMT + tile, mtiles - 1);
+      tb[j] = apack + ((size_t)mt * nchunks_all + c_lo) * 1024;
+    } else {
+      const int idx = tile - BMT, mat = idx / BNM;
+      const int nt = min(pn * BNM + idx % BNM, ntiles - 1);
+      tb[j] = reinterpret_cast<const char*>(mat ? a.w1 : a.w0) + ((size_t)nt * nchunks_all + c_lo) * 1024;
+    }
+  }
+  const unsigned voff = (unsigned)lane * 16u;
+  const unsigned lds0 = g2_lds_addr(g2_smem) + (unsigned)wave * 1024u;
+  auto dma = [&](int c_req, int slot) {
+    const size_t co = (size_t)min(c_req, nchunks - 1) * 1024;        // past the end: the last chunk again, into a slot nobody reads
+    const unsigned d = lds0 + (unsigned)(slot * TILES) * 1024u;
+    if constexpr (LOADS == 4) g2_dma(tb[0] + co, tb[1] + co, tb[2] + co, tb[3] + co, voff, d, d + 8192u, d + 16384u, d + 24576u);
+    else g2_dma(tb[0] + co, tb[1] + co, tb[2] + co, voff, d, d + 8192u, d + 16384u);
+  };
+
+  const u32x4* lfa = reinterpret_cast<const u32x4*>(g2_smem) + (size_t)(grp * WM) * 64 + lane;          // this wave's A blocks of slot 0
+  const u32x4* lfb = reinterpret_cast<const u32x4*>(g2_smem) + (size_t)(BMT + wn * WNT) * 64 + lane;    // ... and B blocks (matrix 0)
+
+  f32x4 acc[WM][4];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) acc[mi][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fr[NF];
+
+  // prologue: chunks 0 .. NB - 2 requested, chunk 0 landed
+#pragma unroll
+  for (int t = 0; t < NB - 1; ++t) dma(t, t);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * LOADS) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (grp == 1) {                                    // group 1 runs one phase behind
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  for (int c0 = 0; c0 < nchunks; c0 += NB) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int c = c0 + u;
+      if (c >= nchunks) break;
+      // ---- L(c) ----
+      if constexpr (!(UA2_G2_DBG & 4)) {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fr[mi] = lfa[(size_t)(u * TILES + mi) * 64];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int ni = 0; ni < WNT; ++ni) fr[WM + t * WNT + ni] = lfb[(size_t)(u * TILES + t * BNM + ni) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(UA2_G2_DBG & 1)) dma(c + NB - 1, (u + NB - 1) % NB);
+      if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (NB - 2) * LOADS) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C(c) ----
+      if constexpr (!(UA2_G2_DBG & 2)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci)
+            acc[mi][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[mi]), __builtin_bit_cast(bf16x8, fr[WM + ci]),
+                                                                  acc[mi][ci], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (NB - 2) * LOADS) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (grp == 0) {                                    // group 1's last C phase
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail requests: nothing may land once the epilogue reuses the ring
+  __syncthreads();
+
+  // ---- epilogues: the wave's patch goes through its share of the ring PM row tiles at a time ----
+  constexpr int SHARE = NB * TILES * 1024 / 8;                       // bytes of LDS per wave
+  constexpr int PM = (SHARE / 4096 >= WM) ? WM : ((SHARE / 4096 >= WM / 2) ? WM / 2 : WM / 4);
+  static_assert(PM >= 1 && WM % PM == 0 && PM * 4096 <= SHARE, "patch does not fit the wave's share of the ring");
+  float* patch = reinterpret_cast<float*>(g2_smem + (size_t)wave * SHARE);
+  const int colq = lane & 15, gq = lane >> 4;
+  const int mwave = (pm * BMT + grp * WM) * 16;                      // first row of this wave's patch
+
+  auto park = [&](int p0, auto colmap) {                             // rows of tiles p0 .. p0 + PM - 1 into the patch
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+      if (mi < p0 || mi >= p0 + PM) continue;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[((mi - p0) * 16 + 4 * gq + r) * 64 + colmap(ci)] = acc[mi][ci][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto done = [&]() {                                                // the patch is re-used by the next pass: reads before writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  if constexpr (EPI == UA2_EPI_QKV_ROPE) {
+    if (a.rope_mode == UA2_ROPE_HALF_SPLIT) {
+      // head size 128, no bias (the LM): the workgroup's 256 columns are two heads, a wave holds half a head in the packed
+      // (permuted) order — tile r of a head carries dims [8r, 8r + 8) and their rotation partners [64 + 8r, ..).  Parked in natural
+      // dim order ([0, 32): dims 32 half + .., [32, 64): 64 + 32 half + ..) a lane owns 4 consecutive dims of a row and finds its
+      // rotation partner 32 columns away.  Same operations as ua2_gemm.hip's staged form.
+      const int h = pn * 2 + (wn >> 1), half_id = wn & 1;
+      const int hs = 128, half = 64;
+      const bool is_q = h < a.kv.n_head, is_k = !is_q && h < a.kv.n_head + a.kv.n_kv;
+      const bool rot = is_q || is_k;
+      const int kvh = is_q ? 0 : (is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv);
+      const int j = lane & 15, jj = j & 7;
+      const bool hi = j >= 8;
+      const int d0 = 32 * half_id + 4 * jj;
+      const bool live = h < a.kv.n_head + 2 * a.kv.n_kv;
+#pragma unroll 1
+      for (int p0 = 0; p0 < WM; p0 += PM) {
+        park(p0, [&](int ci) { return (colq < 8) ? ci * 8 + colq : 32 + ci * 8 + (colq - 8); });
+        if (live) {
+          for (int it = 0; it < PM * 4; ++it) {
+            const int prow = it * 4 + gq;
+            const int m = mwave + p0 * 16 + prow;
+            if (m >= a.M) continue;
+            const float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
+            const float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
+            const int pos = a.row_pos[m];
+            float4 out = own;
+            if (rot) {
+              const float4 cs = *reinterpret_cast<const float4*>(a.rope_cos + (size_t)pos * half + d0);
+              const float4 sn = *reinterpret_cast<const float4*>(a.rope_sin + (size_t)pos * half + d0);
+              if (!hi) {
+                out.x = __fadd_rn(__fmul_rn(own.x, cs.x), __fmul_rn(-oth.x, sn.x)); out.y = __fadd_rn(__fmul_rn(own.y, cs.y), __fmul_rn(-oth.y, sn.y));
+                out.z = __fadd_rn(__fmul_rn(own.z, cs.z), __fmul_rn(-oth.z, sn.z)); out.w = __fadd_rn(__fmul_rn(own.w, cs.w), __fmul_rn(-oth.w, sn.w));
+              } else {
+                out.x = __fadd_rn(__fmul_rn(own.x, cs.x), __fmul_rn(oth.x, sn.x)); out.y = __fadd_rn(__fmul_rn(own.y, cs.y), __fmul_rn(oth.y, sn.y));
+                out.z = __fadd_rn(__fmul_rn(own.z, cs.z), __fmul_rn(oth.z, sn.z)); out.w = __fadd_rn(__fmul_rn(own.w, cs.w), __fmul_rn(oth.w, sn.w));
+              }
+            }
+            const int dd = (hi ? half : 0) + d0;
+            if (is_q) {
+              *reinterpret_cast<float4*>(a.q_out + (size_t)m * a.kv.n_head * hs + (size_t)h * hs + dd) = out;
+            } else {
+              const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages + ua2_page_slot(a.kv, pos)];
+              const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs + dd;
+              uint2 pk;
+              pk.x = (unsigned)f2bf(out.x) | ((unsigned)f2bf(out.y) << 16);
+              pk.y = (unsigned)f2bf(out.z) | ((unsigned)f2bf(out.w) << 16);
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(is_k ? a.kv.k_pool : a.kv.v_pool) + base) = pk;
+            }
+          }
+        }
+        done();
+      }
+      return;
+    } else {
+      // no rotation, head size 64, optional bias (the DiT's fused q|k|v): a wave's 64 columns are one head
+      const int hs = 64;
+      const int h = pn * 4 + wn;
+      const bool live = h * hs < a.N;
+      const bool is_q = h < a.kv.n_head, is_k = !is_q && h < a.kv.n_head + a.kv.n_kv;
+      const int kvh = is_q ? 0 : (is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv);
+      const int d0 = 4 * colq;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias && live) b4 = *reinterpret_cast<const float4*>(a.bias + (size_t)h * hs + d0);
+#pragma unroll 1
+      for (int p0 = 0; p0 < WM; p0 += PM) {
+        park(p0, [&](int ci) { return ci * 16 + colq; });
+        if (live) {
+          for (int it = 0; it < PM * 4; ++it) {
+            const int prow = it * 4 + gq;
+            const int m = mwave + p0 * 16 + prow;
+            if (m >= a.M) continue;
+            float4 out = *reinterpret_cast<const float4*>(patch + prow * 64 + d0);
+            if (a.bias) { out.x = __fadd_rn(out.x, b4.x); out.y = __fadd_rn(out.y, b4.y); out.z = __fadd_rn(out.z, b4.z); out.w = __fadd_rn(out.w, b4.w); }
+            if (is_q) {
+              *reinterpret_cast<float4*>(a.q_out + (size_t)m * a.kv.n_head * hs + (size_t)h * hs + d0) = out;
+            } else {
+              const int pos = a.row_pos[m];
+              const int page = a.kv.page_table[(size_t)kv_table_row(a, m) * a.kv.max_pages + ua2_page_slot(a.kv, pos)];
+              const size_t base = (((size_t)page * a.kv.n_kv + kvh) * UA2_PAGE + (pos % UA2_PAGE)) * hs + d0;
+              uint2 pk;
+              pk.x = (unsigned)f2bf(out.x) | ((unsigned)f2bf(out.y) << 16);
+              pk.y = (unsigned)f2bf(out.z) | ((unsigned)f2bf(out.w) << 16);
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(is_k ? a.kv.k_pool : a.kv.v_pool) + base) = pk;
+            }
+          }
+        }
+        done();
+      }
+      return;
+    }
+  } else {
+    // STORE / RESIDUAL / SWIGLU / GELU
+    constexpr int SPAN = WNT * 16;                       // output columns of a wave: 64 (32 for SWIGLU)
+    constexpr int LPR = SPAN / 4;                        // lanes per row
+    constexpr int RPI = 64 / LPR;                        // rows per iteration
+    constexpr int ITERS = PM * 16 / RPI;
+    const bool slab = (flags & 2) != 0;                  // K split: raw partial sums into this slab of split_ws
+    const int j = lane & (LPR - 1), rsub = lane / LPR;
+    const int n0 = (pn * BNM + wn * WNT) * 16 + 4 * j;   // this lane's 4 columns (of each matrix)
+    const bool live = n0 < a.N;                          // wave-uniform (N % SPAN == 0)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b0 = zero4, b1 = zero4, os4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (live) {
+      if (a.bias) b0 = *reinterpret_cast<const float4*>(a.bias + n0);
+      if constexpr (NT == 2) { if (a.bias && a.bias1) b1 = *reinterpret_cast<const float4*>(a.bias1 + n0); }
+      if constexpr (EPI == UA2_EPI_RESIDUAL) { if (a.out_scale) os4 = *reinterpret_cast<const float4*>(a.out_scale + n0); }
+    }
+#pragma unroll 1
+    for (int p0 = 0; p0 < WM; p0 += PM) {
+      park(p0, [&](int ci) { return ci * 16 + colq; });
+      if (live) {
+        const int mbase = mwave + p0 * 16;
+        float4 res[ITERS];
+        if constexpr (EPI == UA2_EPI_RESIDUAL) {         // every residual piece of the pass requested before the first store
+          if (!slab) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+              const int m = mbase + it * RPI + rsub;
+              res[it] = *reinterpret_cast<const float4*>(a.resid + (size_t)min(m, a.M - 1) * a.ldr + n0);
+            }
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int prow = it * RPI + rsub;
+          const int m = mbase + prow;
+          if (m >= a.M) continue;
+          float4 v0 = *reinterpret_cast<const float4*>(patch + prow * 64 + 4 * j);
+          if constexpr (EPI == UA2_EPI_RESIDUAL) {
+            if (slab) {
+              *reinterpret_cast<float4*>(a.split_ws + ((size_t)blockIdx.y * a.M + m) * a.N + n0) = v0;
+              continue;
+            }
+          }
+          float4 v1 = zero4;
+          if constexpr (NT == 2) v1 = *reinterpret_cast<const float4*>(patch + prow * 64 + SPAN + 4 * j);
+          if (a.bias) {
+            v0.x = __fadd_rn(v0.x, b0.x); v0.y = __fadd_rn(v0.y, b0.y); v0.z = __fadd_rn(v0.z, b0.z); v0.w = __fadd_rn(v0.w, b0.w);
+            if constexpr (NT == 2) { v1.x = __fadd_rn(v1.x, b1.x); v1.y = __fadd_rn(v1.y, b1.y); v1.z = __fadd_rn(v1.z, b1.z); v1.w = __fadd_rn(v1.w, b1.w); }
+          }
+          float4 out = v0;
+          if constexpr (EPI == UA2_EPI_RESIDUAL) {
+            if (a.out_scale) { out.x = __fmul_rn(os4.x, v0.x); out.y = __fmul_rn(os4.y, v0.y); out.z = __fmul_rn(os4.z, v0.z); out.w = __fmul_rn(os4.w, v0.w); }
+            out.x = __fadd_rn(out.x, res[it].x); out.y = __fadd_rn(out.y, res[it].y); out.z = __fadd_rn(out.z, res[it].z); out.w = __fadd_rn(out.w, res[it].w);
+          } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+            out.x = ua2_act_glu(a, v0.x, v1.x); out.y = ua2_act_glu(a, v0.y, v1.y); out.z = ua2_act_glu(a, v0.z, v1.z); out.w = ua2_act_glu(a, v0.w, v1.w);
+          } else if constexpr (EPI == UA2_EPI_GELU) {
+            out.x = ua2_act_gelu(a, v0.x); out.y = ua2_act_gelu(a, v0.y); out.z = ua2_act_gelu(a, v0.z); out.w = ua2_act_gelu(a, v0.w);
+          }
+          if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n0) = out;
+          if constexpr (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_GELU) {
+            if (a.y_packed) store_packed4<UA2_BF16>(a.y_packed, m, n0, a.N / KC, out);
+          }
+        }
+      }
+      done();
+    }
+  }
+}
+
+// y = resid + out_scale (.) ((((s0 + s1) + s2) + s3) + bias): the slabs of a K split in index order (as ua2_gemm.hip's combine)
+__global__ __launch_bounds__(256) void gemm2_combine_kernel(const ua2_linear_args a, const int slabs) {
+  const int n4 = a.N >> 2;
+  const size_t total = (size_t)a.M * n4, slab_elems = (size_t)a.M * a.N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+    const float* p = a.split_ws + (size_t)m * a.N + n;
+    float4 t = *reinterpret_cast<const float4*>(p);
+    for (int k = 1; k < slabs; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (size_t)k * slab_elems);
+      t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
+    }
+    if (a.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      t.x = __fadd_rn(t.x, b.x); t.y = __fadd_rn(t.y, b.y); t.z = __fadd_rn(t.z, b.z); t.w = __fadd_rn(t.w, b.w);
+    }
+    if (a.out_scale) {
+      const float4 g = *reinterpret_cast<const float4*>(a.out_scale + n);
+      t.x = __fmul_rn(g.x, t.x); t.y = __fmul_rn(g.y, t.y); t.z = __fmul_rn(g.z, t.z); t.w = __fmul_rn(g.w, t.w);
+    }
+    const float4 r = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n);
+    t.x = __fadd_rn(t.x, r.x); t.y = __fadd_rn(t.y, r.y); t.z = __fadd_rn(t.z, r.z); t.w = __fadd_rn(t.w, r.w);
+    *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = t;
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
+template <int EPI>
+int launch2(const ua2_linear_args& a, hipStream_t s) {
+  constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
+  constexpr int BNM = 16 / NT;
+  const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16), nblocks = ua2_ceil_div(ntiles, BNM);
+  const int nchunks = ua2_ceil_div(a.K, 32);
+  const int group_m = std::max(1, env_int("UA2_GEMM2_GROUP_M", 8));
+  // 256-row tiles when they give most CUs a workgroup; 128-row tiles below (the DiT's single window: 1000 rows)
+  const int64_t g16 = (int64_t)ua2_ceil_div(mtiles, 16) * nblocks;
+  const int force = env_int("UA2_GEMM2_BMT", 0);
+  const int bmt = force ? force : (g16 >= env_int("UA2_GEMM2_G16_MIN", 160) ? 16 : 8);
+  const int mblocks = ua2_ceil_div(mtiles, bmt);
+  const int64_t grid1 = (int64_t)mblocks * nblocks;
+  // K slabs (ua2hip.h split_ws): long K on a grid that leaves most of the device idle
+  int ks = 1, flags = 0;
+  if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    if (a.split_ws && nchunks >= env_int("UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96) && grid1 <= env_int("UA2_GEMM2_KSPLIT_MAX_GRID", 128) && !getenv("UA2_GEMM_NO_KSPLIT")) {
+      const int want = (int)std::min<int64_t>(4, (256 + grid1 - 1) / grid1);
+      const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
+      if (std::min(want, fit) > 1) { ks = std::min(want, fit); flags = 2; }
+    }
+  }
+  const char* ap = reinterpret_cast<const char*>(a.x_packed ? a.x_packed : a.workspace);
+  auto go = [&](auto kern, int nb, int tiles) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid1, ks), dim3(512), (size_t)nb * tiles * 1024, s, a, ap, mblocks, nblocks, group_m, flags);
+  };
+  if (bmt == 16) {
+    constexpr auto kern = gemm2_kernel<EPI, 16, 4>;
+    ua2_allow_big_lds<kern>();
+    go(kern, 4, 32);
+  } else {
+    constexpr auto kern = gemm2_kernel<EPI, 8, 6>;
+    ua2_allow_big_lds<kern>();
+    go(kern, 6, 24);
+  }
+  if (flags & 2) {
+    const size_t total4 = (size_t)a.M * (a.N / 4);
+    hipLaunchKernelGGL(gemm2_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
+  }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// 0 = launched, 1 = this launch is outside the kernel's forms (the caller goes on to ua2_gemm.hip's kernels).  The operand is
+// already packed (x_packed, or the prep launch into workspace).
+int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
+  if (a.dtype != UA2_BF16 || getenv("UA2_GEMM2_OFF")) return 1;
+  if (a.prologue == UA2_PRO_SCALED || a.part_max || a.y_norm_w) return 1;
+  if (a.M < env_int("UA2_GEMM2_MIN_ROWS", 256) || a.K % 32 != 0) return 1;
+  const bool glu = a.epilogue == UA2_EPI_SWIGLU;
+  if (a.N % (glu ? 32 : 64) != 0) return 1;
+  if (a.bias && !aligned16(a.bias)) return 1;
+  if (glu && a.bias1 && !aligned16(a.bias1)) return 1;
+  switch (a.epilogue) {
+    case UA2_EPI_QKV_ROPE: {
+      const bool lm = a.rope_mode == UA2_ROPE_HALF_SPLIT && a.kv.head_size == 128 && !a.bias;
+      const bool dit = a.rope_mode == UA2_ROPE_NONE && a.kv.head_size == 64;
+      if (!(lm || dit) || !aligned16(a.q_out) || !aligned16(a.kv.k_pool) || !aligned16(a.kv.v_pool)) return 1;
+      if (lm && (!aligned16(a.rope_cos) || !aligned16(a.rope_sin))) return 1;
+      return launch2<UA2_EPI_QKV_ROPE>(a, s);
+    }
+    case UA2_EPI_STORE:
+      if (!a.y || a.ldy % 4 || !aligned16(a.y)) return 1;
+      return launch2<UA2_EPI_STORE>(a, s);
+    case UA2_EPI_RESIDUAL:
+      if (a.ldy % 4 || a.ldr % 4 || !aligned16(a.y) || !aligned16(a.resid) || (a.out_scale && !aligned16(a.out_scale))) return 1;
+      return launch2<UA2_EPI_RESIDUAL>(a, s);
+    case UA2_EPI_SWIGLU:
+    case UA2_EPI_GELU:
+      if (a.y && (a.ldy % 4 || !aligned16(a.y))) return 1;
+      if (a.y_packed && !aligned16(a.y_packed)) return 1;
+      return glu ? launch2<UA2_EPI_SWIGLU>(a, s) : launch2<UA2_EPI_GELU>(a, s);
+    default: return 1;
+  }
+}

@@ -16,6 +16,8 @@ int ua2_gemv_rows_per_tile(int dtype, int K);
 int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force);
 // batched-decode form (ua2_skinny.hip): 0 = launched, 1 = shape outside its table (the older skinny kernel serves it)
 int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t s);
+// order-free form (ua2_gemm2.hip: 256-row tiles, one chain over K): 0 = launched, 1 = launch outside its forms; operand already packed
+int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s);
 
 // ---- fragments ----------------------------------------------------------------------------
 

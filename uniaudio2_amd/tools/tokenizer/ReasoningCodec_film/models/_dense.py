@@ -30,6 +30,7 @@ class PackedLinear:
         self.dtype = dtype
         self.w = ops.pack_linear(w.contiguous(), dtype)
         self.b = b.contiguous() if b is not None else None
+        self.sum_order = 0          # ua2hip.h sum_order: callers outside every row-invariance contract (the DiT) set UA2_SUM_ORDER_FREE
 
     def __call__(self, x, *, epilogue=EPI_STORE, norm=None, resid=None, out_scale=None, act_kind=0, w1=None, y=None, M=None, **kw):
         """x [M, K] fp32 contiguous rows.  norm = (w, b, eps) -> LayerNorm prologue (F.layer_norm then * w + b)."""
@@ -44,6 +45,7 @@ class PackedLinear:
             extra = dict(prologue=PRO_NORM, norm_w=norm[0], norm_b=norm[1], eps=norm[2], norm_kind=NORM_LAYERNORM)
         if w1 is not None:
             extra.update(w1=w1.w, bias1=w1.b)
+        kw.setdefault("sum_order", self.sum_order)
         ops.linear(dtype=self.dtype, M=M, N=self.N, K=self.K, w0=self.w, epilogue=epilogue, x=x, ldx=self.K, y=y, ldy=(self.N if y is not None else 0), resid=resid,
                    ldr=(self.N if resid is not None else None), out_scale=out_scale, bias=self.b, act_kind=act_kind, workspace=ws, **extra, **kw)
         return y if y is not None else kw.get("q_out")

@@ -18,6 +18,7 @@ Per layer on the device (6 GEMM launches + 1 attention + 3 tiny vector ops; the 
   ff.net.2 + bias, * gate, + residual                   ua2_linear CAST / RESIDUAL(scale)  :401-405
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -182,6 +183,13 @@ RELEASED_CONFIG = dict(num_attention_heads=24, attention_head_dim=64, in_channel
 
 
 class Transformer1DModel(nn.Module):
+    # Summation-order contract of the DiT's GEMMs (include/ua2hip.h, ua2_linear_args.sum_order).  Nothing downstream relies on a row
+    # of the velocity field having the same bits at every row count — the reference's own SDPA / cuBLAS calls do not have that
+    # property either — so the bf16 plan takes the order-free 256-row-tile kernel (csrc/ua2_gemm2.hip).  0 (or env UA2_DIT_SUM_ORDER=0)
+    # restores the row-invariant kernels: with them a window's latent has the same bits alone and inside a batch of windows
+    # (tests/test_gpu_codec_model.py uses that to prove the batching logic exactly).
+    sum_order = 1
+
     def __init__(self, num_attention_heads=24, attention_head_dim=64, in_channels=1040, out_channels=136, num_layers=32,
                  attention_bias=True, norm_eps=1e-6, num_positional_embeddings=3000, **unused_config):
         super().__init__()
@@ -212,6 +220,12 @@ class Transformer1DModel(nn.Module):
         self.proj_in.prepare(dtype); self.proj_out.prepare(dtype); self.adaln_single.prepare(dtype)
         for b in self.transformer_blocks:
             b.prepare(dtype)
+        order = int(os.environ.get("UA2_DIT_SUM_ORDER", self.sum_order)) if dtype == torch.bfloat16 else 0
+        for b in self.transformer_blocks:
+            for k in ("qkv", "out", "ff1", "ff2"):
+                b._p[k].sum_order = order
+        for lin in (*self.proj_in._taps, self.proj_in._lin, *self.proj_out._taps, self.proj_out._lin):
+            lin.sum_order = order
         self._table_all = torch.cat([b._p["table"] for b in self.transformer_blocks]).contiguous()
         D = self.inner_dim
         pos = torch.arange(self.max_pos).unsqueeze(1).float()                 # diffusers SinusoidalPositionalEmbedding (:232)
