@@ -192,24 +192,23 @@ def test_gemm2_phase_loop_requests_and_waits(gemm2_asm):
     vmem = re.compile(r"(global|buffer|flat|scratch)_(load|store|atomic)")
     m0 = re.compile(r"\bm0\b")
     for name, ins in ks.items():
-        bmt, nb = (int(x) for x in re.search(r"gemm2_kernelILi\d+ELi(\d+)ELi(\d+)E", name).groups())
+        bmt, nb, var = (int(x) for x in re.search(r"gemm2_kernelILi\d+ELi(\d+)ELi(\d+)ELi(\d+)E", name).groups())
+        late = bool(var & 1)                                           # requests issued inside the C phase
         loads = (bmt + 16) // 8
         first_mfma = next(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
         last_mfma = max(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
         # prologue: NB - 1 chunks requested, then the wait that leaves NB - 2 in flight
-        pre = [t for t, _ in ins[:first_mfma]]
         hand_pre = [int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1)) for t, inasm in ins[:first_mfma] if inasm and t.startswith("s_waitcnt vmcnt")]
         assert hand_pre and hand_pre[0] == (nb - 2) * loads, (name, hand_pre)
         n_pre_dma = 0
-        for t in pre:
+        for t, _ in ins[:first_mfma]:
             if t.startswith("s_waitcnt vmcnt"):
                 break
             n_pre_dma += t.startswith("global_load_lds")
         assert n_pre_dma == (nb - 1) * loads, (name, n_pre_dma)
-        # the loop: split at the hand-written barriers; every L phase carries exactly LOADS requests, C phases none
-        loop = ins[first_mfma - 200 if first_mfma > 200 else 0:last_mfma + 1]
+        # the loop: split at the hand-written barriers
         seg_dma, seg_mfma, seg = [], [], [0, 0]
-        for t, inasm in ins[:last_mfma + 40]:
+        for t, inasm in ins[:last_mfma + 60]:
             if t.startswith("global_load_lds"):
                 assert inasm, f"{name}: compiler-emitted LDS-DMA"
                 seg[0] += 1
@@ -220,17 +219,19 @@ def test_gemm2_phase_loop_requests_and_waits(gemm2_asm):
                 seg_dma.append(seg[0]); seg_mfma.append(seg[1]); seg = [0, 0]
             elif not inasm:
                 assert not (t.startswith("s_waitcnt") and "vmcnt" in t), f"{name}: compiler vmcnt wait in the phase loop: {t}"
-                assert not vmem.match(t), f"{name}: other vector-memory traffic in the phase loop: {t}"
+                assert not (vmem.match(t) and not t.startswith("scratch")), f"{name}: other vector-memory traffic in the phase loop: {t}"
                 assert not m0.search(t), f"{name}: compiler-emitted use of m0: {t}"
-        phases = [(d, m) for d, m in zip(seg_dma, seg_mfma) if d or m]
-        l_phases = [p for p in phases if p[0] and not p[1]]
+        phases = [(d, m) for d, m in zip(seg_dma, seg_mfma)][1:]          # [0] = the prologue's requests
         c_phases = [p for p in phases if p[1]]
+        l_phases = [p for p in phases if not p[1]][:nb + 1]
         assert len(c_phases) == nb, (name, phases)                       # the loop is unrolled over the ring
-        assert all(m == 4 * bmt // 2 and d == 0 for d, m in c_phases), (name, phases)
-        assert sum(1 for d, _ in l_phases if d == loads) == nb, (name, phases)
-        # hand waits inside the loop all leave NB - 2 chunks in flight; the one in front of the epilogue drains
+        assert all(m == 4 * bmt // 2 and d == (loads if late else 0) for d, m in c_phases), (name, phases)
+        assert sum(1 for d, _ in l_phases if d == (0 if late else loads)) >= nb, (name, phases)
+        # hand waits inside the loop leave NB - 2 chunks in flight (NB - 3 behind an L phase of the late-request form); the one in
+        # front of the epilogue drains
         hand = [int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1)) for t, inasm in ins if inasm and t.startswith("s_waitcnt vmcnt")]
-        assert hand[-1] == 0 and set(hand[:-1]) == {(nb - 2) * loads}, (name, hand)
+        want = {(nb - 2) * loads} | ({(nb - 3) * loads} if late else set())
+        assert hand[-1] == 0 and set(hand[1:-1]) == want, (name, hand)
         assert len(hand) == 1 + 2 * nb + 1, (name, hand)                 # prologue + (group 1 in L, group 0 in C) per unrolled step + drain
         # M0 saved before and restored after every request batch
         text = [t for t, inasm in ins if inasm]
@@ -238,10 +239,18 @@ def test_gemm2_phase_loop_requests_and_waits(gemm2_asm):
             1 for t in text if t.startswith("global_load_lds")), name
 
 
-def test_gemm2_no_scratch(gemm2_asm):
+def test_gemm2_no_scratch_in_the_phase_loop(gemm2_asm):
+    """No kernel spills inside its phase loop; the production instantiations (one workgroup per CU) do not spill at all."""
     names = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", gemm2_asm)
     vg = dict(re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", gemm2_asm))
     assert len(names) >= 10
     for name, scratch in names:
-        assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
         assert int(vg[name]) <= 256, name
+        if not re.search(r"gemm2_kernelILi\d+ELi8ELi3E", name):           # the two-workgroups-per-CU experiment form may spill in its epilogue
+            assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
+    for name, ins in _kernels(gemm2_asm).items():
+        if "gemm2_kernel" not in name:
+            continue
+        first = next(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
+        last = max(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
+        assert not any(t.startswith("scratch_") for t, _ in ins[first:last]), name

@@ -11,8 +11,8 @@
 // the LDS-DMA issue time of a wave ADDING to its MFMA time (profiles/r4_notes.md §9).  Here a row's dot product is ONE chain over K
 // in chunk order (per K slab, when a launch is cut into slabs), so:
 //   * one accumulator set: a wave owns 128 x 64 (8 x 4 tiles of 16 x 16 = 128 accumulator registers),
-//   * the workgroup is 8 waves = 256 x 256 (BMT = 16) or 128 x 256 (BMT = 8), one workgroup per CU,
-//   * the two waves of every SIMD run in OPPOSITE phases: while one multiplies chunk c (32 MFMAs, s_setprio 1) its partner reads
+//   * the workgroup is 8 waves = 256 x 256 (BMT = 16, one workgroup per CU) or 128 x 256 (BMT = 8, two per CU),
+//   * the two waves of every SIMD run in OPPOSITE phases: while one multiplies chunk c (32 MFMAs) its partner reads
 //     the fragments of its next chunk from LDS and issues its LDS-DMA requests, then they swap — the structure the guide's 256^2
 //     8-phase template measures at 1.3-1.5 PFLOP/s (cdna_hip_programming.md §5; MI355X_MICROARCH.md "Two waves per SIMD").
 //
@@ -44,6 +44,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "ua2_common.h"
 #include "ua2_linear_common.h"
@@ -86,14 +87,26 @@ __device__ __forceinline__ void g2_dma(const char* s0, const char* s1, const cha
       : "memory");
 }
 
+__device__ __forceinline__ void g2_dma1(const char* s0, unsigned voff, unsigned d0) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(s0), "v"(voff), "s"(d0)
+               : "memory");
+}
+
 // Timing-only knock-outs (tools/ubench/build_alt.sh ... -DUA2_G2_DBG=<bits>; wrong results): 1 no ring refills after the prologue,
 // 2 no MFMAs, 4 no fragment reads.
 #ifndef UA2_G2_DBG
 #define UA2_G2_DBG 0
 #endif
 
-template <int EPI, int BMT, int NB>
-__global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, const char* __restrict__ apack, const int mblocks,
+// VAR (same bits, a cost choice): bit 0 = the requests of chunk c + NB - 1 are issued inside C(c), spread among its MFMAs, instead
+// of in L(c) (a request costs a wave ~60 issue cycles among bare MFMAs and 100-185 beside its fragment reads:
+// MI355X_MICROARCH.md "LDS-DMA piece issue cost"); group 1 then waits `vmcnt((NB - 3) LOADS)` behind L(c) — it has not yet
+// requested chunk c + NB - 1 there.  bit 1 = no s_setprio around the MFMAs.
+template <int EPI, int BMT, int NB, int VAR>
+__global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kernel(const ua2_linear_args a, const char* __restrict__ apack, const int mblocks,
                                                        const int nblocks, const int group_m, const int flags) {
   constexpr int KC = 32;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
@@ -103,6 +116,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
   constexpr int TILES = BMT + 16;        // fragment blocks per chunk
   constexpr int LOADS = TILES / 8;       // LDS-DMA requests per wave and chunk
   constexpr int NF = WM + 4;             // fragments a wave reads per chunk
+  constexpr bool DMA_C = (VAR & 1) != 0, PRIO = (VAR & 2) == 0;
+  static_assert(!DMA_C || NB >= 3, "the late-request form needs three slots");
   static_assert(TILES % 8 == 0 && (LOADS == 3 || LOADS == 4), "request lists below");
   static_assert((NB - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char g2_smem[];
@@ -147,6 +162,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
     if constexpr (LOADS == 4) g2_dma(tb[0] + co, tb[1] + co, tb[2] + co, tb[3] + co, voff, d, d + 8192u, d + 16384u, d + 24576u);
     else g2_dma(tb[0] + co, tb[1] + co, tb[2] + co, voff, d, d + 8192u, d + 16384u);
   };
+  auto dma_piece = [&](int c_req, int slot, int j) {
+    const size_t co = (size_t)min(c_req, nchunks - 1) * 1024;
+    g2_dma1(tb[j] + co, voff, lds0 + (unsigned)(slot * TILES + j * 8) * 1024u);
+  };
 
   const u32x4* lfa = reinterpret_cast<const u32x4*>(g2_smem) + (size_t)(grp * WM) * 64 + lane;          // this wave's A blocks of slot 0
   const u32x4* lfb = reinterpret_cast<const u32x4*>(g2_smem) + (size_t)(BMT + wn * WNT) * 64 + lane;    // ... and B blocks (matrix 0)
@@ -183,20 +202,32 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
           for (int ni = 0; ni < WNT; ++ni) fr[WM + t * WNT + ni] = lfb[(size_t)(u * TILES + t * BNM + ni) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(UA2_G2_DBG & 1)) dma(c + NB - 1, (u + NB - 1) % NB);
-      if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (NB - 2) * LOADS) : "memory");
+      if constexpr (!(UA2_G2_DBG & 1) && !DMA_C) dma(c + NB - 1, (u + NB - 1) % NB);
+      if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (DMA_C ? NB - 3 : NB - 2) * LOADS) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       // ---- C(c) ----
       if constexpr (!(UA2_G2_DBG & 2)) {
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi)
+        for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
           for (int ci = 0; ci < 4; ++ci)
             acc[mi][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[mi]), __builtin_bit_cast(bf16x8, fr[WM + ci]),
                                                                   acc[mi][ci], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+          if constexpr (DMA_C && !(UA2_G2_DBG & 1)) {
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j)
+              if (mi == (j + 1) * WM / (LOADS + 1) - 1) {            // request j behind row tile mi: spread over the first 3/4 of the phase
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(c + NB - 1, (u + NB - 1) % NB, j);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+        }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+      } else if constexpr (DMA_C && !(UA2_G2_DBG & 1)) {
+        dma(c + NB - 1, (u + NB - 1) % NB);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (NB - 2) * LOADS) : "memory");
@@ -257,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
       for (int p0 = 0; p0 < WM; p0 += PM) {
         park(p0, [&](int ci) { return (colq < 8) ? ci * 8 + colq : 32 + ci * 8 + (colq - 8); });
         if (live) {
+#pragma unroll 1
           for (int it = 0; it < PM * 4; ++it) {
             const int prow = it * 4 + gq;
             const int m = mwave + p0 * 16 + prow;
@@ -306,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
       for (int p0 = 0; p0 < WM; p0 += PM) {
         park(p0, [&](int ci) { return ci * 16 + colq; });
         if (live) {
+#pragma unroll 1
           for (int it = 0; it < PM * 4; ++it) {
             const int prow = it * 4 + gq;
             const int m = mwave + p0 * 16 + prow;
@@ -351,8 +384,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
       park(p0, [&](int ci) { return ci * 16 + colq; });
       if (live) {
         const int mbase = mwave + p0 * 16;
-        float4 res[ITERS];
-        if constexpr (EPI == UA2_EPI_RESIDUAL) {         // every residual piece of the pass requested before the first store
+        constexpr bool PRE = !(BMT == 8 && NB <= 3);     // the two-workgroups-per-CU form has 128 registers: request per row instead
+        float4 res[PRE ? ITERS : 1];
+        if constexpr (EPI == UA2_EPI_RESIDUAL && PRE) {  // every residual piece of the pass requested before the first store
           if (!slab) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
@@ -382,7 +416,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const ua2_linear_args a, 
           float4 out = v0;
           if constexpr (EPI == UA2_EPI_RESIDUAL) {
             if (a.out_scale) { out.x = __fmul_rn(os4.x, v0.x); out.y = __fmul_rn(os4.y, v0.y); out.z = __fmul_rn(os4.z, v0.z); out.w = __fmul_rn(os4.w, v0.w); }
-            out.x = __fadd_rn(out.x, res[it].x); out.y = __fadd_rn(out.y, res[it].y); out.z = __fadd_rn(out.z, res[it].z); out.w = __fadd_rn(out.w, res[it].w);
+            float4 r4;
+            if constexpr (PRE) r4 = res[it];
+            else r4 = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n0);
+            out.x = __fadd_rn(out.x, r4.x); out.y = __fadd_rn(out.y, r4.y); out.z = __fadd_rn(out.z, r4.z); out.w = __fadd_rn(out.w, r4.w);
           } else if constexpr (EPI == UA2_EPI_SWIGLU) {
             out.x = ua2_act_glu(a, v0.x, v1.x); out.y = ua2_act_glu(a, v0.y, v1.y); out.z = ua2_act_glu(a, v0.z, v1.z); out.w = ua2_act_glu(a, v0.w, v1.w);
           } else if constexpr (EPI == UA2_EPI_GELU) {
@@ -432,6 +469,10 @@ int env_int(const char* name, int dflt) {
   return e && *e ? atoi(e) : dflt;
 }
 
+// Instantiations: the production forms are BMT = 16 / four slots (one workgroup per CU) and BMT = 8 / three slots (two per CU, 128
+// registers), both without s_setprio (VAR = 2: measured 1-3 % ahead of VAR = 0, the late-request form VAR = 1 10 % behind —
+// profiles/r5_notes.md §1).  -DUA2_G2_EXPERIMENTS adds the other variants and the six-slot 128-row form behind the UA2_GEMM2_VAR /
+// UA2_GEMM2_NB hooks (tools/ubench/gemm2_variants.py).
 template <int EPI>
 int launch2(const ua2_linear_args& a, hipStream_t s) {
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
@@ -439,34 +480,56 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16), nblocks = ua2_ceil_div(ntiles, BNM);
   const int nchunks = ua2_ceil_div(a.K, 32);
   const int group_m = std::max(1, env_int("UA2_GEMM2_GROUP_M", 8));
-  // 256-row tiles when they give most CUs a workgroup; 128-row tiles below (the DiT's single window: 1000 rows)
-  const int64_t g16 = (int64_t)ua2_ceil_div(mtiles, 16) * nblocks;
-  const int force = env_int("UA2_GEMM2_BMT", 0);
-  const int bmt = force ? force : (g16 >= env_int("UA2_GEMM2_G16_MIN", 160) ? 16 : 8);
+  // Tile choice (a cost model fitted on tools/ubench/gemm2_variants.py, profiles/r5_gemm2_variants.txt): 256-row tiles when they
+  // keep >= 70 % of the CU slots of their last round busy (and fill half the device at all); else 128-row tiles, two workgroups per
+  // CU, when there are >= 128 of them (K slabs included); else the launch is too small for either and goes back to ua2_gemm.hip
+  // (M = 1000 x N = 1536: 48 tiles).
+  const int64_t t16 = (int64_t)ua2_ceil_div(mtiles, 16) * nblocks, t8 = (int64_t)ua2_ceil_div(mtiles, 8) * nblocks;
+  auto slabs_for = [&](int64_t grid) {
+    if constexpr (EPI == UA2_EPI_RESIDUAL) {
+      if (a.split_ws && nchunks >= env_int("UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96) && grid <= env_int("UA2_GEMM2_KSPLIT_MAX_GRID", 128) && !getenv("UA2_GEMM_NO_KSPLIT")) {
+        const int want = (int)std::min<int64_t>(4, (256 + grid - 1) / grid);
+        const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
+        return std::max(1, std::min(want, fit));
+      }
+    }
+    return 1;
+  };
+  int bmt = env_int("UA2_GEMM2_BMT", 0);
+  if (!bmt) {
+    const double e16 = (double)t16 / (double)(((t16 + 255) / 256) * 256);
+    if (t16 >= 128 && e16 >= 0.70) bmt = 16;
+    else if (t8 * slabs_for(t8) >= 128) bmt = 8;
+    else return 1;
+  }
   const int mblocks = ua2_ceil_div(mtiles, bmt);
   const int64_t grid1 = (int64_t)mblocks * nblocks;
-  // K slabs (ua2hip.h split_ws): long K on a grid that leaves most of the device idle
-  int ks = 1, flags = 0;
-  if constexpr (EPI == UA2_EPI_RESIDUAL) {
-    if (a.split_ws && nchunks >= env_int("UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96) && grid1 <= env_int("UA2_GEMM2_KSPLIT_MAX_GRID", 128) && !getenv("UA2_GEMM_NO_KSPLIT")) {
-      const int want = (int)std::min<int64_t>(4, (256 + grid1 - 1) / grid1);
-      const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
-      if (std::min(want, fit) > 1) { ks = std::min(want, fit); flags = 2; }
-    }
-  }
+  const int ks = slabs_for(grid1), flags = ks > 1 ? 2 : 0;
   const char* ap = reinterpret_cast<const char*>(a.x_packed ? a.x_packed : a.workspace);
-  auto go = [&](auto kern, int nb, int tiles) {
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid1, ks), dim3(512), (size_t)nb * tiles * 1024, s, a, ap, mblocks, nblocks, group_m, flags);
+  auto go = [&](auto bmt_c, auto nb_c, auto var_c) {
+    constexpr int B = decltype(bmt_c)::value, NBUF = decltype(nb_c)::value, V = decltype(var_c)::value;
+    constexpr auto kern = gemm2_kernel<EPI, B, NBUF, V>;
+    ua2_allow_big_lds<kern>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid1, ks), dim3(512), (size_t)NBUF * (B + 16) * 1024, s, a, ap, mblocks, nblocks, group_m, flags);
   };
-  if (bmt == 16) {
-    constexpr auto kern = gemm2_kernel<EPI, 16, 4>;
-    ua2_allow_big_lds<kern>();
-    go(kern, 4, 32);
-  } else {
-    constexpr auto kern = gemm2_kernel<EPI, 8, 6>;
-    ua2_allow_big_lds<kern>();
-    go(kern, 6, 24);
-  }
+  using std::integral_constant;
+#ifdef UA2_G2_EXPERIMENTS
+  const int var = env_int("UA2_GEMM2_VAR", 2), nb6 = env_int("UA2_GEMM2_NB", 0) == 6;
+  auto pick_var = [&](auto bmt_c, auto nb_c) {
+    switch (var) {
+      case 0: go(bmt_c, nb_c, integral_constant<int, 0>{}); break;
+      case 1: go(bmt_c, nb_c, integral_constant<int, 1>{}); break;
+      case 3: go(bmt_c, nb_c, integral_constant<int, 3>{}); break;
+      default: go(bmt_c, nb_c, integral_constant<int, 2>{}); break;
+    }
+  };
+  if (bmt == 16) pick_var(integral_constant<int, 16>{}, integral_constant<int, 4>{});
+  else if (nb6) pick_var(integral_constant<int, 8>{}, integral_constant<int, 6>{});
+  else pick_var(integral_constant<int, 8>{}, integral_constant<int, 3>{});
+#else
+  if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 2>{});
+  else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+#endif
   if (flags & 2) {
     const size_t total4 = (size_t)a.M * (a.N / 4);
     hipLaunchKernelGGL(gemm2_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
