@@ -370,7 +370,40 @@ def stage2_leg(dev, steps=10):
         enc.update({"config3_encode_post_ssl_ms_per_batch32": round(ms32, 2), "config3_encode_post_ssl_clips_per_s": round(32e3 / ms32, 1)})
     except Exception as e:  # noqa: BLE001
         enc["config3_encode_post_ssl_error"] = repr(e)[:200]
-    return {**enc, "euler_steps": steps, "window_s": 20.0, "ms_per_window_passes": [round(p_ * 1e3, 1) for p_ in passes],
+    # stage 2 batched over utterances (multi_task_inference.py:540-548's loop as `--codec_batch 8`): window k of 8
+    # utterances in one flow-matching solve (2 x 8 x 500 rows per DiT launch: the 256-row-tile order-free GEMM) + one SQ-Codec
+    # decode of 8 latents; the solve is one recorded graph.  ms_per_window = the pass / 8.
+    bat = {}
+    try:
+        P = 8
+        codes8 = [torch.randint(0, 8192, (8, 250)) for _ in range(P)]
+        tok.detokenize_no_reason_batch(codes8, steps=steps, max_batch=P)          # warm: records the (P, steps) solve and the batch decode
+        bp = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            wavs = tok.detokenize_no_reason_batch(codes8, steps=steps, max_batch=P)
+            torch.cuda.synchronize()
+            bp.append(time.perf_counter() - t0)
+        x16 = torch.randn(2 * P, 500, RELEASED_CONFIG["in_channels"], device=dev)
+        est(x16, 0.5); torch.cuda.synchronize()
+        sp = []
+        for _ in range(3):
+            e0.record()
+            for _ in range(3):
+                est(x16, 0.5)
+            e1.record(); torch.cuda.synchronize()
+            sp.append(e0.elapsed_time(e1) / 3)
+        med = sorted(bp)[1]
+        bat = {"stage2_batched8": {"utterances": P, "ms_per_window_passes": [round(p_ * 1e3 / P, 2) for p_ in bp], "ms_per_window": round(med * 1e3 / P, 2),
+                                   "ms_per_window_min": round(min(bp) * 1e3 / P, 2), "rtf": round(med / (P * wavs[0].shape[-1] / 24000.0), 5),
+                                   "dit_ms_per_guided_step_8_windows_passes": [round(v, 2) for v in sp], "dit_ms_per_guided_step_per_window": round(sorted(sp)[1] / P, 3),
+                                   "dit_tflops": round(P * flop / (sorted(sp)[1] * 1e-3) / 1e12, 1), "dit_frac_bf16_mfma_peak": round(P * flop / (sorted(sp)[1] * 1e-3) / 2.5e15, 4),
+                                   "gemm": "order-free 256-row tiles (csrc/ua2_gemm2.hip), sum_order = UA2_SUM_ORDER_FREE"}}
+    except Exception as e:  # noqa: BLE001
+        bat = {"stage2_batched8": {"error": repr(e)[:300]}}
+    return {**enc, **bat, "euler_steps": steps, "window_s": 20.0, "ms_per_window_passes": [round(p_ * 1e3, 1) for p_ in passes],
+            "ms_per_window_median": round(sorted(passes)[1] * 1e3, 1), "dit_ms_per_guided_step_median": round(sorted(step_passes)[1], 2),
             "dit_ms_per_guided_step_passes": [round(p_, 2) for p_ in step_passes], "ms_per_window": round(total * 1e3, 1), "rtf": round(total / (wav.shape[-1] / 24000.0), 5),
             "dit_ms_per_guided_step": round(step_ms, 2), "dit_tflops": round(flop / (step_ms * 1e-3) / 1e12, 1),
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}

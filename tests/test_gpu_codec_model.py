@@ -209,6 +209,88 @@ def test_stage_all_decode_runs_at_real_dit_size():
     print(f"stage-2 of one 20-s window, 2 Euler steps: {dt * 1e3:.1f} ms -> {dt * 1e3 / 2:.1f} ms per guided step + decode")
 
 
+def _stage2_tokenizer(dit_cfg, sum_order):
+    """ReasoningTokenizer over a seeded AudioDiffusion1D (DiT of `dit_cfg`) + the bench-size ScalarModel."""
+    from test_gpu_codec import BENCH_SCALAR_CFG
+    from make_golden_codec import codec_state_dict
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.AudioDiffusion1D import AudioDiffusion1D
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.scalar24k import ScalarModel
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.transformer_1d_flow import Transformer1DModel
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.reason_tokenizer import ReasoningTokenizer
+    torch.manual_seed(0)
+    model = AudioDiffusion1D(unet_model_config_path=dict(dit_cfg), encoder_depth=1, device="cuda")
+    with torch.no_grad():
+        for _, p_ in model.named_parameters():
+            if p_.dim() > 1:
+                p_.normal_(0, 0.02)
+        for n_, b_ in model.named_buffers():
+            if n_.endswith("_codebook.embed"):
+                b_.normal_(0, 0.5)
+    saved = Transformer1DModel.sum_order
+    Transformer1DModel.sum_order = sum_order
+    try:
+        model = model.cuda().prepare()
+    finally:
+        Transformer1DModel.sum_order = saved
+    sq = ScalarModel(**BENCH_SCALAR_CFG)
+    sq.load_state_dict(codec_state_dict({k: tuple(v.shape) for k, v in sq.state_dict().items()}, 77))
+    return ReasoningTokenizer(sq_codec=sq.cuda().prepare(), model=model, device="cuda")
+
+
+def test_batched_stage2_equals_one_by_one_under_the_invariant_contract(monkeypatch):
+    """detokenize_no_reason_batch (window k of several utterances in one DiT solve + one SQ-Codec decode, the whole solve one
+    recorded graph) against a loop over detokenize_no_reason, same seed: with the row-invariant GEMM contract and no K slabs every
+    kernel of the path gives a row the same bits whatever shares its launch, so the waves must be EQUAL — which proves the
+    batching logic (window grid per utterance, in-context hand-over, the draw order of both generators, the estimator-row order
+    of the guided step, the flat ProjectLayer) exactly.  Utterances of 1, 2 and 3 windows, batches of 2 (so groups change from
+    window to window)."""
+    monkeypatch.setenv("UA2_GEMM_NO_KSPLIT", "1")
+    L = 136
+    dit = dict(num_attention_heads=4, attention_head_dim=64, in_channels=2 * L + 768, out_channels=L, num_layers=2)
+    tok = _stage2_tokenizer(dit, sum_order=0)
+    g = torch.Generator().manual_seed(11)
+    codes = [torch.randint(0, 8192, (8, T), generator=g) for T in (437, 100, 250, 600)]
+    torch.manual_seed(123)
+    single = [tok.detokenize_no_reason(c, steps=3) for c in codes]
+    torch.manual_seed(123)
+    batch = tok.detokenize_no_reason_batch(codes, steps=3, max_batch=2)
+    torch.manual_seed(123)
+    batch4 = tok.detokenize_no_reason_batch(codes, steps=3, max_batch=8)
+    for c, a, b, b4 in zip(codes, single, batch, batch4):
+        assert a.shape == b.shape == (1, int(c.shape[-1] / 12.5 * 24000)) and torch.isfinite(a).all() and a.abs().max() > 0
+        assert torch.equal(a, b), (c.shape, float((a - b).abs().max()))
+        assert torch.equal(a, b4), (c.shape, float((a - b4).abs().max()))
+    # the graph of the solve replays: a second seeded pass gives the same waves
+    torch.manual_seed(123)
+    again = tok.detokenize_no_reason_batch(codes, steps=3, max_batch=2)
+    assert all(torch.equal(a, b) for a, b in zip(batch, again))
+    # ... and equals the eager (un-recorded) solve
+    monkeypatch.setenv("UA2_EULER_NO_GRAPH", "1")
+    torch.manual_seed(123)
+    eager = tok.detokenize_no_reason_batch(codes, steps=3, max_batch=2)
+    assert all(torch.equal(a, b) for a, b in zip(batch, eager))
+
+
+def test_batched_stage2_at_the_released_dit_size_order_free():
+    """The default plan at the released DiT's shape: order-free GEMMs (2 x P x 500 rows on the 256-row tiles for P = 4, the
+    invariant kernels for P = 1).  Same seed: the batched waves agree with the one-by-one ones to the DiT's own bf16 noise
+    (another summation order can flip bf16 roundings of a GEMM operand; DESIGN.md §2: 5.6e-3 on the velocity field against the
+    fp32 oracle, bar 2e-2)."""
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.transformer_1d_flow import RELEASED_CONFIG
+    tok = _stage2_tokenizer(RELEASED_CONFIG, sum_order=1)
+    g = torch.Generator().manual_seed(12)
+    codes = [torch.randint(0, 8192, (8, T), generator=g) for T in (250, 250, 437, 120)]
+    torch.manual_seed(5)
+    single = [tok.detokenize_no_reason(c, steps=2) for c in codes]
+    torch.manual_seed(5)
+    batch = tok.detokenize_no_reason_batch(codes, steps=2, max_batch=4)
+    for a, b in zip(single, batch):
+        assert a.shape == b.shape and torch.isfinite(b).all()
+        rel = float(((a - b).double().pow(2).mean().sqrt()) / a.double().pow(2).mean().sqrt().clamp_min(1e-9))
+        print(f"batched vs one-by-one wave, released DiT size: relative rms {rel:.2e}")
+        assert rel < 2e-2, rel
+
+
 def test_config1_codec_plumbing_p225(tmp_path):
     """BASELINE.json config 1: samples/p225_002.wav (fixture: its 86 848 samples at 22 050 Hz) -> load ->
     resample to 24 kHz (94 529 samples) -> ScalarModel.encode -> latent (1, 136, 99); synthetic features (1, 50, 768) seed 0

@@ -169,3 +169,70 @@ def test_fatal_error_on_one_rank_raises_on_every_rank_world2():
             assert len(ret[r]) == 2
             for msg in ret[r]:
                 assert "aborted" in msg and "status -3" in msg and "rank" in msg, ret[r]
+
+
+class _FakeCodec:
+    """Stand-in for the ReasoningTokenizer in stage 2's driver: a wave that encodes its codes (so a file proves which codes
+    produced it), and a log of how the driver called it."""
+    sample_rate = 24000
+
+    def __init__(self):
+        self.calls = []
+
+    def _wave(self, c):
+        n = int(c.shape[-1] / 12.5 * 24000)
+        return (torch.arange(n, dtype=torch.float32)[None] % 7) / 70.0 + float(c.sum() % 5) / 50.0
+
+    def detokenize_no_reason(self, c, return_reasoning_text=False, steps=50):
+        self.calls.append(1)
+        return self._wave(c)
+
+    def detokenize_no_reason_batch(self, cs, steps=50, max_batch=8):
+        self.calls.append(len(cs))
+        return [self._wave(c) for c in cs]
+
+
+def _worker_stage2(rank, world, port, tok_dir, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    from uniaudio2_amd.multi_task_inference import decode_token_dir
+    codec = _FakeCodec()
+    args = argparse.Namespace(token_dir=tok_dir, output_dir=tok_dir, wav_dir=os.path.join(tok_dir, f"wavs_rank{rank}"), codec_steps=2, codec_batch=3)
+    decode_token_dir(codec, args, torch.device("cpu"))
+    wrote = sorted(f[:-4] for f in os.listdir(args.wav_dir))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, wrote)
+    ret[rank] = (wrote, everyone, codec.calls)
+    dist.destroy_process_group()
+
+
+def test_stage2_shards_utterances_over_ranks_world2(tmp_path):
+    """stage 2 shards by utterance.  Two ranks decode one token directory (a stand-in codec, CPU): the union of
+    what they wrote is every utterance with both token files, the shards are disjoint and balanced, the orphan is skipped, and
+    each rank walked its shard --codec_batch utterances at a time."""
+    names = [f"utt_{i:02d}" for i in range(9)]
+    for i, n in enumerate(names):
+        torch.save(torch.randint(0, 4096, (8, 5 + i), dtype=torch.int32), tmp_path / f"{n}_reason.pt")
+        torch.save(torch.randint(0, 8192, (8, 20 + 3 * i), dtype=torch.int32), tmp_path / f"{n}_semantic.pt")
+    torch.save(torch.zeros(8, 3, dtype=torch.int32), tmp_path / "orphan_reason.pt")
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_stage2, args=(world, 29597, str(tmp_path), ret), nprocs=world, join=True)
+        a, b = ret[0][0], ret[1][0]
+        assert sorted(a + b) == names and not set(a) & set(b)
+        assert abs(len(a) - len(b)) <= 1
+        assert ret[0][1] == [a, b] == ret[1][1]                 # both ranks saw the same picture through the collective
+        for r in range(world):
+            assert all(c <= 3 for c in ret[r][2]) and sum(ret[r][2]) == len(ret[r][0])
+
+
+def test_stage2_shard_is_a_partition():
+    from uniaudio2_amd.multi_task_inference import stage2_shard
+    names = [f"n{i}" for i in range(23)]
+    for world in (1, 2, 4, 8):
+        shards = [stage2_shard(names, world, r) for r in range(world)]
+        assert sorted(sum(shards, [])) == sorted(names)
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1

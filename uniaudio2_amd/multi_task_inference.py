@@ -265,12 +265,14 @@ def _write_results(args, items, results, tag):
     e.g. the model never produced the semantic phase) is reported after everything else was saved."""
     from . import parallel
     failed = []
-    if int(os.environ.get("RANK", "0")) == 0:
-        for i, (name, _) in enumerate(items):
-            if isinstance(results[i], parallel.Failed):
-                failed.append(name)
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    for i, (name, _) in enumerate(items):                       # every rank holds every result (the all-gather): all of them raise
+        if isinstance(results[i], parallel.Failed):             # together, none is left waiting in stage 2's barrier
+            failed.append(name)
+            if rank0:
                 print(f"[Fail] {name}: {results[i].message}")
-                continue
+            continue
+        if rank0:
             reason, semantic = results[i]
             _save_tokens(args, name, reason, semantic)
             print(f"{tag} {name} -> {name}_reason.pt, {name}_semantic.pt")
@@ -325,30 +327,53 @@ def save_wav(path, wave, sample_rate):
     wavfile.write(path, int(sample_rate), np.round(x.T * 32767.0).astype(np.int16))
 
 
+def stage2_shard(names, world, rank):
+    """Utterances of stage 2 this rank decodes: names[rank::world] of the sorted list (SURVEY.md §8e: "codec stage 2 shards the
+    same way ... by utterance"; the reference loops over all of them on one GPU, multi_task_inference.py:540-548).  The outputs
+    are files, so the stage needs no collective: the union over ranks is every name, the shards are disjoint."""
+    return list(names[rank::max(1, world)])
+
+
 def run_generation_stage2(args):
     """multi_task_inference.py:529-549: every `*_semantic.pt` of --token_dir (default: --output_dir) -> `{wav_dir}/{name}.wav`
     through ReasoningTokenizer.detokenize_no_reason (RVQ look-ups -> flow-matching DiT + guided Euler ODE -> SQ-Codec decode ->
-    cross-faded 20-s windows)."""
+    cross-faded 20-s windows).  Under torchrun every rank decodes its shard of the utterances (stage2_shard), --codec_batch of them
+    at a time (detokenize_no_reason_batch: window k of the batch in one DiT solve)."""
     if not torch.cuda.is_available():
         raise RuntimeError("uniaudio2_amd needs a ROCm GPU (no CPU fallback)")
     rank = int(os.environ.get("LOCAL_RANK", getattr(args, "rank", 0)))
     device = torch.device(f"cuda:{rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
-    codec = _load_codec(args, device)
+    return decode_token_dir(_load_codec(args, device), args, device)
+
+
+def decode_token_dir(codec, args, device):
+    """Stage 2 proper, on a loaded codec (anything with detokenize_no_reason / detokenize_no_reason_batch / sample_rate): this
+    rank's shard of the token files -> wav files.  RANK / WORLD_SIZE as torchrun sets them."""
     token_dir = args.token_dir or args.output_dir
     names = [os.path.basename(p).replace("_reason.pt", "") for p in sorted(glob.glob(os.path.join(token_dir, "*_reason.pt")))]
     wav_dir = args.wav_dir or os.path.join(token_dir, "wavs")
     os.makedirs(wav_dir, exist_ok=True)
-    for name in names:
+    world, grank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    mine = []
+    for name in stage2_shard(names, world, grank):
         sp = os.path.join(token_dir, f"{name}_semantic.pt")
         if not os.path.isfile(sp):
             print(f"[Skip] {name}: missing {sp}")
             continue
-        rec_codec = torch.load(sp, map_location=device)
-        wave = codec.detokenize_no_reason(rec_codec.long(), return_reasoning_text=False, steps=args.codec_steps)
-        wav_path = os.path.join(wav_dir, f"{name}.wav")
-        save_wav(wav_path, wave, codec.sample_rate)
-        print(f"[Stage2] {name} -> {wav_path}")
+        mine.append((name, sp))
+    bs = max(1, int(getattr(args, "codec_batch", 1) or 1))
+    for b0 in range(0, len(mine), bs):
+        chunk = mine[b0:b0 + bs]
+        codes = [torch.load(sp, map_location=device).long() for _, sp in chunk]
+        if len(chunk) == 1:
+            waves = [codec.detokenize_no_reason(codes[0], return_reasoning_text=False, steps=args.codec_steps)]
+        else:
+            waves = codec.detokenize_no_reason_batch(codes, steps=args.codec_steps, max_batch=bs)
+        for (name, _), wave in zip(chunk, waves):
+            wav_path = os.path.join(wav_dir, f"{name}.wav")
+            save_wav(wav_path, wave, codec.sample_rate)
+            print(f"[Stage2] {name} -> {wav_path}")
     return wav_dir
 
 
@@ -374,6 +399,8 @@ def get_parser():
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="kernel precision (extension; the reference runs fp32)")
     p.add_argument("--save_safetensors", action="store_true",
                    help="also write {name}_tokens.safetensors next to the reference's two .pt files (extension)")
+    p.add_argument("--codec_batch", type=int, default=8,
+                   help="utterances whose k-th windows share one DiT solve / SQ-Codec decode in stage 2 (extension; 1 = one by one as the reference)")
     p.add_argument("--batch_size", type=int, default=1,
                    help="utterances decoded together per GPU (extension; TTS / Yue_TTS with --text_file; 1 = one by one as the reference)")
     return p
@@ -410,8 +437,11 @@ def main(argv=None):
             if args.stage == "1":
                 print("[Done] Stage 1 only. Run with --stage 2 --token_dir ... to decode to wav.")
                 return
-        if int(os.environ.get("RANK", "0")) == 0:          # stage 2 decodes what rank 0 wrote
-            run_generation_stage2(args)
+        # stage 2 decodes the token files rank 0 wrote, every rank its shard of the utterances (stage2_shard): the files must be
+        # complete before any rank lists them
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+        run_generation_stage2(args)
         return
     raise ValueError(f"Unsupported task: {task}. Understanding: {UNDERSTANDING_TASKS}. Generation: {GENERATION_TASKS}.")
 

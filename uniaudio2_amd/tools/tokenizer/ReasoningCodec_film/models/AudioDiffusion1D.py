@@ -21,6 +21,7 @@ residuals fused (ua2_linear), the encoder's transformer blocks (modules/transfor
 (ua2_rvq_*), nearest-neighbour interpolation as a row gather, the DiT (transformer_1d_flow.py) and the Euler update
 (ua2_ew_fma).
 """
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -59,38 +60,82 @@ class BASECFM(nn.Module):
         super().__init__()
         self.sigma_min = 1e-4
         self.estimator = estimator
+        self._graphs, self._pool = {}, None
 
-    @torch.inference_mode()
-    def solve_euler(self, x, incontext_x, incontext_length, t_span, mu, added_cond_kwargs=None, guidance_scale=1.5, estimator=None):
-        """x (1, T, L) noise, incontext_x (1, T, L), mu (1, T, D), t_span host tensor of times.  `estimator(x_cat, t)` defaults
-        to the DiT; tests inject a stand-in to pin the solver against the reference's own solve_euler."""
-        if guidance_scale <= 1.0:
-            raise NotImplementedError("the un-guided branch of the reference concatenates on the wrong axis (SURVEY A.10) and is unreachable: "
-                                      "every caller passes guidance_scale = 1.5")
-        if x.shape[0] != 1:
-            raise NotImplementedError("one utterance per call: the reference's guided step builds a 2-entry timestep for a 2B batch (:113)")
-        est = estimator or (lambda inp, t: self.estimator(inp, t))
-        ts = [float(v) for v in t_span]
-        t, dt = ts[0], ts[1] - ts[0]
-        x = x.float().contiguous().clone()
-        noise = x.clone()
-        inc = incontext_x.float().contiguous()
-        n = int(incontext_length)
+    def _euler_steps(self, x, noise, inc, n, ts, mu, guidance_scale, est):
+        """The guided Euler loop proper (:99-127) for P utterances at once: rows [0, P) of the estimator batch are the
+        unconditional halves, [P, 2P) the conditional ones (P = 1: the reference's two rows)."""
+        P, _, L = x.shape
         zeros = torch.zeros_like(mu)
-        L = x.shape[-1]
+        t, dt = ts[0], ts[1] - ts[0]
         for step in range(1, len(ts)):
             if n > 0:                                                    # :104 in-context frames follow the known latent
                 blend = ops.ew_fma(noise[:, :n].contiguous(), alpha=1 - (1 - self.sigma_min) * t)
                 x[:, :n] = ops.ew_fma(inc[:, :n].contiguous(), c=blend, alpha=t)
             inp = torch.cat([torch.cat([x, x], 0), torch.cat([inc, inc], 0), torch.cat([zeros, mu], 0)], 2)      # :107-112
-            d = est(inp, t).float().contiguous()                         # (2, T, L): [unconditional, conditional]
-            g = ops.ew_fma(d[1], alpha=guidance_scale)                   # u + s (c - u) = s c + (1 - s) u   :115-116
-            g = ops.ew_fma(d[0], c=g, alpha=1.0 - guidance_scale)
-            x = ops.ew_fma(g, c=x.view(-1), alpha=dt).view(1, -1, L)     # :123
+            d = est(inp, t).float().contiguous()                         # (2P, T, L): [unconditional | conditional]
+            g = ops.ew_fma(d[P:].reshape(-1), alpha=guidance_scale)      # u + s (c - u) = s c + (1 - s) u   :115-116
+            g = ops.ew_fma(d[:P].reshape(-1), c=g, alpha=1.0 - guidance_scale)
+            x = ops.ew_fma(g, c=x.reshape(-1), alpha=dt).view(P, -1, L)  # :123
             t = t + dt
             if step < len(ts) - 1:
                 dt = ts[step + 1] - t
         return x
+
+    @torch.inference_mode()
+    def solve_euler(self, x, incontext_x, incontext_length, t_span, mu, added_cond_kwargs=None, guidance_scale=1.5, estimator=None,
+                    use_graph=None):
+        """x (P, T, L) noise, incontext_x (P, T, L), mu (P, T, D), t_span host tensor of times; P = 1 in the reference (its guided
+        step builds a 2-entry timestep for a 2-row batch, :113), P utterances here share one timestep per step, which is what that
+        line means for each of them.  `estimator(x_cat, t)` defaults to the DiT; tests inject a stand-in to pin the solver against
+        the reference's own solve_euler.
+        use_graph (default: on with the DiT): the whole solve — every step's in-context blend, concatenation, DiT forward,
+        guidance and Euler update — is captured ONCE per (P, T, in-context length, schedule) into a HIP graph and replayed per
+        window (the times of the schedule are host constants, so they become kernel arguments of the recording).  Before, a
+        window was 10 graph replays + ~30 small launches per step issued from Python: one pass in three ran 1.5x longer on a
+        busy host (round-4 bench: 60.4 / 60.8 / 92.8 ms)."""
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("the un-guided branch of the reference concatenates on the wrong axis (SURVEY A.10) and is unreachable: "
+                                      "every caller passes guidance_scale = 1.5")
+        ts = [float(v) for v in t_span]
+        n = int(incontext_length)
+        x = x.float().contiguous().clone()
+        inc = incontext_x.float().contiguous()
+        mu = mu.float().contiguous()
+        if use_graph is None:
+            use_graph = estimator is None and os.environ.get("UA2_EULER_NO_GRAPH") is None
+        if estimator is not None or not use_graph or torch.cuda.is_current_stream_capturing():
+            est = estimator or (lambda inp, t: self.estimator(inp, t))
+            return self._euler_steps(x, x.clone(), inc, n, ts, mu, guidance_scale, est)
+        key = (tuple(x.shape), tuple(mu.shape), n, tuple(ts), float(guidance_scale))
+        g = self._graphs.get(key)
+        if g is None:
+            dit = self.estimator
+            P, T, _ = x.shape
+            dev = x.device
+            dit.ensure_plan(2 * P, T, dev)
+            for t in ts:
+                dit.step_embedding(t, dev)
+            x_in, inc_in, mu_in = torch.empty_like(x), torch.empty_like(inc), torch.empty_like(mu)
+            x_in.copy_(x); inc_in.copy_(inc); mu_in.copy_(mu)
+            est = lambda inp, t: dit(inp, t, use_graph=False)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                                 # warm-up outside capture: one-time kernel attributes, scratch, allocator pools
+                self._euler_steps(x_in.clone(), x_in.clone(), inc_in, n, ts[:2], mu_in, guidance_scale, est)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self._pool):
+                y = self._euler_steps(x_in.clone(), x_in.clone(), inc_in, n, ts, mu_in, guidance_scale, lambda inp, t: dit(inp, t))
+            if self._pool is None:
+                self._pool = graph.pool()                                 # one memory pool for every recorded shape
+            while len(self._graphs) >= 6:                                 # a handful of shapes per deployment (P x {first, later} windows)
+                self._graphs.pop(next(iter(self._graphs)))
+            g = self._graphs[key] = (graph, x_in, inc_in, mu_in, y)
+        graph, x_in, inc_in, mu_in, y = g
+        x_in.copy_(x); inc_in.copy_(inc); mu_in.copy_(mu)
+        graph.replay()
+        return y.clone()
 
 
 class AudioThinking(nn.Module):

@@ -312,7 +312,7 @@ class ScalarModel(nn.Module):
         finally:
             _ConvOp.default_fast = False
         self._dec_tc = bool(fast_decode) and self._decoder_tc_ok()
-        self._graphs = {}
+        self._graphs, self._graph_pool = {}, None
         self._ready = True
         return self
 
@@ -320,8 +320,11 @@ class ScalarModel(nn.Module):
         """Every decoder conv behind the first one can run on split planes (channel counts in whole groups of 32, PReLU-only
         epilogues); the last conv writes the fp32 waveform."""
         convs = []
-        for layer in list(self.decoder)[1:]:
+        n_dec = len(list(self.decoder))
+        for i, layer in enumerate(list(self.decoder)[1:], start=1):
             if isinstance(layer, nn.Conv1d):
+                if i < n_dec - 1:                       # a plain conv in the middle of the stack: it runs on planes too, same requirements
+                    convs.append(self._dec_ops[i])
                 continue
             if isinstance(layer, ResDecoderBlock):
                 convs.append(layer.up_conv._op)
@@ -361,8 +364,8 @@ class ScalarModel(nn.Module):
     @torch.inference_mode()
     def decode(self, x, use_graph=None):
         """latent -> wav; the latent is snapped to the 1/9 grid first (:403-407).
-        use_graph (default: on for the split-plane path): the ~44 launches of a decode are captured once per input shape into a
-        HIP graph and replayed — stage 2 decodes window after window of one shape (reason_tokenizer.py:277-290), and issued one by
+        use_graph (default: on for the split-plane path): the ~44 launches of a decode are captured once per (input shape, device)
+        into a HIP graph — an LRU of 8 shapes on one shared memory pool — and replayed — stage 2 decodes window after window of one shape (reason_tokenizer.py:277-290), and issued one by
         one from Python the chain is ~0.7 ms of host time against ~1.1 ms of kernels: the next kernel speed-up would have been
         host-bound."""
         if not self._ready:
@@ -372,11 +375,11 @@ class ScalarModel(nn.Module):
             use_graph = self._dec_tc and os.environ.get("UA2_CODEC_NO_GRAPH") is None
         if not use_graph or torch.cuda.is_current_stream_capturing():
             return self._decode_impl(x)
-        key = tuple(x.shape)
-        g = self._graphs.get(key)
+        key = (tuple(x.shape), x.device.index)
+        g = self._graphs.pop(key, None)                               # re-inserted below: the dict's order is the LRU order
         if g is None:
-            if len(self._graphs) >= 8:                                # bounded: a caller with ever-changing shapes replays nothing
-                return self._decode_impl(x)
+            while len(self._graphs) >= 8:                             # least recently used shape goes; all graphs share one memory pool
+                self._graphs.pop(next(iter(self._graphs)))
             x_in = torch.empty_like(x)
             x_in.copy_(x)
             side = torch.cuda.Stream(device=x.device)
@@ -385,9 +388,12 @@ class ScalarModel(nn.Module):
                 self._decode_impl(x_in)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, pool=self._graph_pool):
                 y = self._decode_impl(x_in)
-            g = self._graphs[key] = (graph, x_in, y)
+            if self._graph_pool is None:
+                self._graph_pool = graph.pool()
+            g = (graph, x_in, y)
+        self._graphs[key] = g
         graph, x_in, y = g
         x_in.copy_(x)
         graph.replay()

@@ -45,21 +45,27 @@ class ProjectLayer(nn.Module):
         self._lin = PackedLinear(self.ffn_2.weight, self.ffn_2.bias, dtype)
 
     def run(self, x, B, T):
-        """x [B*T, Cin] fp32 rows -> [B*T, Cout].  The k-tap conv is k accumulated GEMMs over row-shifted views of a
-        zero-padded copy (tap j reads frames t + j - k//2)."""
+        """x [B*T, Cin] fp32 rows -> [B*T, Cout].  The k-tap conv is k accumulated GEMMs over row-shifted views of a zero-padded
+        copy (tap j reads frames t + j - k//2).  All B sequences go through ONE launch per tap: the padded copies lie back to back
+        as [B * (T + 2 pad), Cin] rows, tap j multiplies rows j .. j + B (T + 2 pad) - 2 pad of it, and the 2 pad rows per sequence
+        whose window straddles two sequences are computed and dropped (a row's value never depends on its neighbours in a
+        GEMM)."""
         k, Cin = self.kernel_size, x.shape[1]
         pad = k // 2
-        xp = torch.zeros(B, T + 2 * pad, Cin, dtype=torch.float32, device=x.device)
+        Tp = T + 2 * pad
+        xp = torch.zeros(B, Tp, Cin, dtype=torch.float32, device=x.device)
         xp[:, pad:pad + T] = x.view(B, T, Cin)
-        y = torch.empty(B * T, self._taps[0].N, dtype=torch.float32, device=x.device)
-        for b in range(B):
-            yb = y[b * T:(b + 1) * T]
-            for j, tap in enumerate(self._taps):
-                src = xp[b, j:j + T]
-                if j == 0:
-                    tap(src, y=yb, M=T)
-                else:
-                    tap(src, epilogue=EPI_RESIDUAL, resid=yb, y=yb, M=T)
+        xf = xp.view(B * Tp, Cin)
+        Mv = B * Tp - 2 * pad                                          # rows whose k-frame window lies inside the buffer
+        yf = torch.empty(B * Tp, self._taps[0].N, dtype=torch.float32, device=x.device)
+        yv = yf[:Mv]
+        for j, tap in enumerate(self._taps):
+            src = xf[j:j + Mv]
+            if j == 0:
+                tap(src, y=yv, M=Mv)
+            else:
+                tap(src, epilogue=EPI_RESIDUAL, resid=yv, y=yv, M=Mv)
+        y = yf.view(B, Tp, -1)[:, :T].reshape(B * T, -1)               # row (b, t) of the flat result = output frame t of sequence b
         return self._lin(y)
 
 
@@ -234,7 +240,7 @@ class Transformer1DModel(nn.Module):
         pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
         self._pe = pe.to(dev).contiguous()
         self._table = self.scale_shift_table.detach().float().contiguous().view(-1)
-        self._dtype, self._ready, self._kv, self._graphs = dtype, True, None, {}
+        self._dtype, self._ready, self._kv, self._graphs, self._emb_cache = dtype, True, None, {}, {}
         return self
 
     def _forward_impl(self, hidden_states, emb):
@@ -254,6 +260,23 @@ class Transformer1DModel(nn.Module):
         hm = ops.ew_fma(hn, b=ops.ew_fma(scale, beta=1.0), c=shift)           # * (1 + scale) + shift  :381
         return self.proj_out.run(hm, B, T).view(B, T, self.out_channels)
 
+    def step_embedding(self, timestep, dev):
+        """sinusoid(t) on the device, cached per t (the Euler schedule revisits the same few times window after window)."""
+        key = float(timestep)
+        e = self._emb_cache.get(key)
+        if e is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("Transformer1DModel: time embedding of t=%r requested for the first time inside a graph capture "
+                                   "(warm the step up outside the capture first)" % key)
+            e = self._emb_cache[key] = self.adaln_single.sinusoid(key).to(dev)
+        return e
+
+    def ensure_plan(self, B, T, dev):
+        """K/V pools and row tables for B sequences of T frames (allocations and one host sync: outside any capture)."""
+        if self._kv is None or self._kv.B != B or self._kv.T != T:
+            self._kv = DenseKV(B, T, self.heads, self.head_dim, self._dtype, dev)
+            self._graphs = {}
+
     @torch.inference_mode()
     def forward(self, hidden_states, timestep: float, use_graph: bool = True):
         """hidden_states (B, T, in_channels) fp32, one timestep for the whole batch -> (B, T, out_channels) fp32
@@ -264,9 +287,15 @@ class Transformer1DModel(nn.Module):
             self.prepare()
         B, T, Cin = hidden_states.shape
         dev = hidden_states.device
-        if self._kv is None or self._kv.B != B or self._kv.T != T:
-            self._kv = DenseKV(B, T, self.heads, self.head_dim, self._dtype, dev)
-            self._graphs = {}
+        if torch.cuda.is_current_stream_capturing():
+            if self._kv is None or self._kv.B != B or self._kv.T != T:
+                raise RuntimeError("Transformer1DModel: no K/V plan for this shape inside a graph capture (run the step once outside it)")
+        else:
+            self.ensure_plan(B, T, dev)
+        if torch.cuda.is_current_stream_capturing():
+            # inside somebody else's capture (BASECFM.solve_euler records a whole window): the launches of this step become nodes
+            # of THAT graph; the step's time embedding must already be on the device (no host copy may be recorded)
+            return self._forward_impl(hidden_states, self.step_embedding(timestep, dev))
         emb = self.adaln_single.sinusoid(float(timestep))
         if not use_graph:
             return self._forward_impl(hidden_states, emb.to(dev))

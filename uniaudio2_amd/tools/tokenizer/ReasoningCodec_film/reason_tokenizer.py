@@ -317,6 +317,52 @@ class ReasoningTokenizer:
         segments = [self.SQCodec.decode(lat.transpose(1, 2).contiguous()).squeeze(0) for lat in latents]      # (1, N) per :295
         return crossfade_concat(segments, plan["wav_window"], plan["wav_ovlp"], plan["target_len"])
 
+    @torch.no_grad()
+    def detokenize_no_reason_batch(self, rec_codecs, steps=50, guidance_scale=1.5, max_batch=8, duration=20):
+        """list of rec_codec (8, T_u) -> list of waves (1, N_u) float32 on the CPU: `detokenize_no_reason` for several utterances
+        with window k of up to `max_batch` of them going through ONE flow-matching solve (2 x P x 500 rows per DiT step instead of
+        1000: the regime the many-row GEMM is built for) and ONE SQ-Codec decode.  Windows of one utterance stay sequential — window
+        k + 1 takes the last 32 latent frames of window k as in-context frames (reason_tokenizer.py:277-283) — so the batch is over
+        utterances ("shard by utterance, not by window").
+        Randomness: every `torch.randn` of the one-by-one path (:235 / :282 on the CPU generator, AudioDiffusion1D.py:655 on the
+        device generator) is drawn HERE, utterance by utterance and window by window — the order a loop over
+        `detokenize_no_reason` consumes the two generators in — and handed to the windows, so a seeded batch run produces the
+        utterances' one-by-one noise.  With the row-invariant GEMM contract (Transformer1DModel.sum_order = 0, no K slabs) the
+        waves are then bit-identical to the one-by-one ones (tests/test_gpu_codec_model.py); with the default order-free DiT they
+        agree to the DiT's own bf16 noise."""
+        if self.latent_fn is not None or self.model is None or not hasattr(self.model, "cfm_wrapper"):
+            return [self.detokenize_no_reason(c, steps=steps, guidance_scale=guidance_scale) for c in rec_codecs]
+        dev = self.device
+        plans = [window_plan(c.shape[-1], duration, self.rec_frame_rate, self.sample_rate, self.sq_codec_hz) for c in rec_codecs]
+        tiled = [tile_codes(c.unsqueeze(0).to(dev), p["tiled_len"]) for c, p in zip(rec_codecs, plans)]
+        L, ov, Cl = plans[0]["latent_length"], plans[0]["ovlp_frames"], self.model.sq_codec_latent
+        nwin = [len(p["starts"]) for p in plans]
+        cpu_noise, dev_noise = [], []
+        for p, w in zip(plans, nwin):                                 # the one-by-one consumption order of both generators
+            cpu_noise.append([torch.randn(1, L if i == 0 else L - ov, Cl) for i in range(w)])
+            dev_noise.append([self.model.prepare_latents(1, L, torch.float32, dev) for _ in range(w)])
+        latents = [[] for _ in rec_codecs]
+        segments = [[] for _ in rec_codecs]
+        for i in range(max(nwin)):
+            active = [u for u, w in enumerate(nwin) if w > i]
+            for g0 in range(0, len(active), max(1, max_batch)):
+                grp = active[g0:g0 + max(1, max_batch)]
+                s0 = plans[grp[0]]["starts"][i]                        # i * hop: the same for every utterance
+                window = torch.cat([tiled[u][:, :, s0:s0 + plans[u]["min_codes"]] for u in grp], 0)
+                noise = torch.cat([dev_noise[u][i] for u in grp], 0)
+                if i == 0:
+                    true, n_inc = torch.cat([cpu_noise[u][0] for u in grp], 0).to(dev), 0
+                else:
+                    true = torch.cat([torch.cat([latents[u][-1][:, -ov:, :], cpu_noise[u][i].to(dev)], 1) for u in grp], 0)
+                    n_inc = ov
+                lat = self.model.inference_codes([window], None, true, L, n_inc, additional_feats=[], guidance_scale=1.5, num_steps=steps,
+                                                 scenario="other_seg", noise=noise).float()
+                wav = self.SQCodec.decode(lat.transpose(1, 2).contiguous())          # (P, 1, N)
+                for k, u in enumerate(grp):
+                    latents[u].append(lat[k:k + 1])
+                    segments[u].append(wav[k])
+        return [crossfade_concat(seg, p["wav_window"], p["wav_ovlp"], p["target_len"]) for seg, p in zip(segments, plans)]
+
     def detokenize_no_reason(self, rec_codec, return_reasoning_text=False, min_duration=30, steps=50, guidance_scale=1.5,
                              disable_progress=False):
         """rec_codec (8, T) -> wave (1, N) float32 on the CPU (:399-404)."""
