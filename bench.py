@@ -310,7 +310,7 @@ def stage2_leg(dev, steps=10):
     sq = ScalarModel(**SCALAR_CFG).to(dev).prepare()
     tok = ReasoningTokenizer(sq_codec=sq, model=model, device=dev)
     codes = torch.randint(0, 8192, (8, 250))
-    tok.detokenize_no_reason(codes, steps=2)                       # warm: packs, graph capture
+    tok.detokenize_no_reason(codes, steps=steps)                   # warm: packs, the recorded solve of this (shape, schedule), the decode graph
     # best of 3: the leg issues ~3000 graph nodes / small launches per window from the host, and on a GPU box whose host cores are
     # shared (cgroup quota) one pass in a few runs 25x slower (1815 ms against 70.5: round-4 evidence run) — a host artefact, not
     # a property of the kernels; every pass is reported

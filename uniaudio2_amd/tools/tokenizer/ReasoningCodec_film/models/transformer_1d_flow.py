@@ -240,7 +240,7 @@ class Transformer1DModel(nn.Module):
         pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
         self._pe = pe.to(dev).contiguous()
         self._table = self.scale_shift_table.detach().float().contiguous().view(-1)
-        self._dtype, self._ready, self._kv, self._graphs, self._emb_cache = dtype, True, None, {}, {}
+        self._dtype, self._ready, self._kv, self._kvs, self._graphs, self._emb_cache = dtype, True, None, {}, {}, {}
         return self
 
     def _forward_impl(self, hidden_states, emb):
@@ -272,10 +272,14 @@ class Transformer1DModel(nn.Module):
         return e
 
     def ensure_plan(self, B, T, dev):
-        """K/V pools and row tables for B sequences of T frames (allocations and one host sync: outside any capture)."""
-        if self._kv is None or self._kv.B != B or self._kv.T != T:
-            self._kv = DenseKV(B, T, self.heads, self.head_dim, self._dtype, dev)
-            self._graphs = {}
+        """K/V pools and row tables for B sequences of T frames (allocations and one host sync: outside any capture).  One plan per
+        (B, T), kept for the model's lifetime: recorded graphs — this module's per-step ones and the whole-solve ones of
+        BASECFM.solve_euler — hold raw pointers into the plan they were captured with (a handful of shapes per deployment:
+        2 x codec_batch sequences of 500 frames)."""
+        kv = self._kvs.get((B, T))
+        if kv is None:
+            kv = self._kvs[(B, T)] = DenseKV(B, T, self.heads, self.head_dim, self._dtype, dev)
+        self._kv = kv
 
     @torch.inference_mode()
     def forward(self, hidden_states, timestep: float, use_graph: bool = True):
@@ -288,8 +292,9 @@ class Transformer1DModel(nn.Module):
         B, T, Cin = hidden_states.shape
         dev = hidden_states.device
         if torch.cuda.is_current_stream_capturing():
-            if self._kv is None or self._kv.B != B or self._kv.T != T:
+            if (B, T) not in self._kvs:
                 raise RuntimeError("Transformer1DModel: no K/V plan for this shape inside a graph capture (run the step once outside it)")
+            self._kv = self._kvs[(B, T)]
         else:
             self.ensure_plan(B, T, dev)
         if torch.cuda.is_current_stream_capturing():
