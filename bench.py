@@ -69,14 +69,14 @@ def make_prompt(device, seed):
     return t.to(device), m.to(device)
 
 
-def utterance(model, tokens, mask, frames=FRAMES):
+def utterance(model, tokens, mask, frames=FRAMES, skip_text_head=False):
     """prefill + `frames` frames, all on device; returns the (frames, 1, 9) id log (device)."""
     L = tokens.size(1)
     model.reset_caches()
     pos = torch.arange(L, device=tokens.device).unsqueeze(0)
     model.forward_prefix(tokens[:, :-1], tokens_mask=mask, input_pos=pos[:, :-1])
     model.begin_decode(tokens[:, -1:], mask[:, -1:], torch.tensor([L - 1], device=tokens.device))
-    return model.generate_frames(frames, 1, 0, reason_eos=-1, reason_card=REASON_CARD, max_pos=L + frames)
+    return model.generate_frames(frames, 1, 0, reason_eos=-1, reason_card=REASON_CARD, max_pos=L + frames, skip_text_head=skip_text_head)
 
 
 def roofline_leg(model):
@@ -216,7 +216,12 @@ def codec_leg(dev, cpu=False):
            "scalar_decode_frac_hbm": round(work["bytes"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "rvq_encode_us_125x6x8192x32": round(rvq_us, 1), "config": "placeholder init_channel=32, hop 960"}
     if cpu:
-        res["cpu_baseline"] = codec_cpu_baseline(sq, lat, x, emb, dec_ms, rvq_us)
+        res["cpu_baseline"] = codec_cpu_baseline(sq, lat, x, emb, dec_ms, rvq_us, gpu_wav=wav)
+        # the north_star's waveform bar (<= 1e-4 RMS against the reference codec on the same input), measured here on the very
+        # window the leg times: GPU split-plane decode against the CPU oracle's fp32 decode of the same latent
+        for k in ("scalar_decode_rms_vs_cpu_oracle", "scalar_decode_ref_rms", "scalar_decode_rel_rms_vs_cpu_oracle"):
+            if k in res["cpu_baseline"]:
+                res[k] = res["cpu_baseline"].pop(k)
     return res
 
 
@@ -250,7 +255,7 @@ def host_cpu_budget():
     return info
 
 
-def codec_cpu_baseline(sq, lat, x, emb, gpu_dec_ms, gpu_rvq_us):
+def codec_cpu_baseline(sq, lat, x, emb, gpu_dec_ms, gpu_rvq_us, gpu_wav=None):
     """the codec half of the metric on the host beside the GPU numbers — `ScalarModel.decode` of the same
     (1, 136, 500) latent through the CPU oracle (oracle/codec_oracle.py, plain PyTorch fp32 convolutions: the reference's own
     arithmetic) and the RVQ search of the same 125 x 6 x 8192 x 32 problem through the C oracle (one thread, the scalar port)."""
@@ -271,6 +276,13 @@ def codec_cpu_baseline(sq, lat, x, emb, gpu_dec_ms, gpu_rvq_us):
             dec_s = time.perf_counter() - t0
         out.update({"scalar_decode_s_per_20s_window": round(dec_s, 3), "scalar_decode_rtf": round(dec_s / (w.shape[-1] / 24000.0), 5),
                     "gpu_speedup_scalar_decode": round(dec_s * 1e3 / gpu_dec_ms, 1)})
+        if gpu_wav is not None:
+            g_, r_ = gpu_wav.detach().cpu().double().reshape(-1), w.double().reshape(-1)
+            n_ = min(g_.numel(), r_.numel())
+            rms = float((g_[:n_] - r_[:n_]).pow(2).mean().sqrt())
+            ref = float(r_[:n_].pow(2).mean().sqrt())
+            out.update({"scalar_decode_rms_vs_cpu_oracle": float(f"{rms:.3e}"), "scalar_decode_ref_rms": float(f"{ref:.3e}"),
+                        "scalar_decode_rel_rms_vs_cpu_oracle": float(f"{rms / max(ref, 1e-30):.3e}")})
     except Exception as e:  # noqa: BLE001 — an information leg must not take the bench line down
         out["scalar_decode_error"] = repr(e)[:200]
     finally:
@@ -802,6 +814,29 @@ def main():
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(100))
     p50, p99 = per[49], per[98]
 
+    # the same utterance with the text head skipped on the audio-feedback frames (UA2_FRAME_SKIP_TEXT_HEAD: identical audio ids,
+    # tests/test_gpu_lm.py) — what the product's generators run; `value` above keeps the reference's work (lm_head every frame)
+    skip = {}
+    try:
+        def utt_skip(frames=FRAMES):
+            return utterance(model, tokens, mask, frames=frames, skip_text_head=True)
+        ref_log = utterance(model, tokens, mask)
+        got = utt_skip()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref_log[:, :, 1:], got[:, :, 1:]))
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            utt_skip()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        utt_skip(2)
+        e0.record()
+        model.generate_frames(64, 1, 0, reason_eos=-1, reason_card=REASON_CARD, skip_text_head=True)
+        e1.record(); torch.cuda.synchronize()
+        skip = {"value_skip_text_head": round(8 * FRAMES * a.steps / dts, 1), "decode_ms_per_frame_skip_text_head": round(e0.elapsed_time(e1) / 64, 3),
+                "skip_text_head_audio_ids_identical": same}
+    except Exception as e:  # noqa: BLE001 — information
+        skip = {"value_skip_text_head": repr(e)[:200]}
     audio_tokens = 8 * FRAMES * a.steps * world
     res = {"metric": "audio tokens/sec (TTS greedy)", "value": round(audio_tokens / dt, 1), "unit": "audio tokens/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -811,7 +846,9 @@ def main():
                                   "audio-token rate (multi_task_inference.py:486-525), stage 2 (codes -> waveform, :527-548) = "
                                   "top-level `codec_rtf`, `stage_all_ms_per_utterance` = both; "
                                   "Llama-3.2-3B backbone + 3L/2L experts + 4L local decoder x8, V_a=12296, random init",
-                      "parallelism": f"dp{world} (one utterance per GPU, RCCL all-gather of token tensors)"},
+                      "parallelism": (f"dp{world} (one utterance per GPU, RCCL all-gather of token tensors inside the timed region)" if use_dist else
+                                      "dp1, no collective (a single rank outside torchrun; `torchrun --nproc-per-node=1 bench.py --gpus 1` runs the RCCL path)")},
+           **skip,
            "decode_ms_per_frame": round(ms_frame, 3), "decode_frames_per_s": round(1e3 / ms_frame, 1),
            "decode_ms_per_frame_p50": round(p50, 3), "decode_ms_per_frame_p99": round(p99, 3)}
     solo = rank == 0 and world == 1

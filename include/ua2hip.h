@@ -543,7 +543,12 @@ int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream);
  * row_pos += 1, applies the reason_eos -> forbid_prefix switch (tts_task.py:263-266). */
 int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card, void* stream);
 /* trunk + heads + feedback (mode < 0: no feedback), captured once into a hipGraph and replayed
- * (use_graph != 0). */
+ * (use_graph != 0).
+ * mode | UA2_FRAME_SKIP_TEXT_HEAD (audio-feedback modes 0 and 2 only): the frame skips lm_head and the text sample — in those
+ * loops the text id is fed back under a zero mask and collected into a list the generators never read
+ * (evaluation/tts_task.py:259,274-277; model_new.py:617 computes it every frame), so the audio ids are bit-identical with and
+ * without it; the frame log's text column holds -1 for such frames and the next frame's (masked) text token is 0. */
+#define UA2_FRAME_SKIP_TEXT_HEAD 16
 int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
                      int32_t use_graph, void* stream);
 /* Expose intermediate buffers for tests: name in {"h_final","text_logits","audio_logits"}. */

@@ -106,7 +106,7 @@ class _ScriptedModel:
 
     def set_sampling(self, topk, temperature, seed=None): self.sampling = (topk, temperature)
 
-    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False):
         self.calls.append((n, batch, mode))
         out = self.log[self.cursor:self.cursor + n]
         self.cursor += n
@@ -192,6 +192,99 @@ def test_speech_s2s_condition_sequence_and_loop():
     assert all(c[1] == 1 and c[2] == 0 for c in gen._model.calls) and gen.is_cfg
 
 
+def _text_log(ids):
+    """A scripted frame log whose text column spells `ids` then EOS (128001), audio columns zero (the on-device text loop)."""
+    log = torch.zeros(len(ids) + 1 + 16, 1, 9, dtype=torch.int32)
+    log[:len(ids), 0, 0] = torch.tensor(ids, dtype=torch.int32)
+    log[len(ids):, 0, 0] = 128001
+    return log
+
+
+def _restated_asr_prompt(prompt, reason, sem):
+    """prepare_lyric_asr_task / prepare_audio_caption_task restated (lyric_asr_task.py:175-200, audio_music_caption_task.py:175-200:
+    identical bodies): task prompt rows (text column, mask on it) | reason bos, frames, eos | semantic bos, frames, eos, all
+    shifted by the reason cardinality (audio columns, mask on them)."""
+    P, w = prompt.shape[0], 9
+    text = torch.zeros(P, w, dtype=torch.int64); text[:, -1] = prompt
+    tmask = torch.zeros(P, w); tmask[:, -1] = 1
+    r = torch.cat([torch.full((1, 8), TA.reason_bos), reason, torch.full((1, 8), TA.reason_eos)])
+    sm = torch.cat([torch.full((1, 8), TA.semantic_bos), sem, torch.full((1, 8), TA.semantic_eos)]) + TA.audio_reason_card
+    a = torch.cat([r, sm]).long()
+    audio = torch.zeros(a.shape[0], w, dtype=torch.int64); audio[:, :8] = a
+    amask = torch.zeros(a.shape[0], w); amask[:, :8] = 1
+    return torch.cat([text, audio]), torch.cat([tmask, amask])
+
+
+@pytest.mark.parametrize("module,prep,gen_name", [("lyric_asr_task", "prepare_lyric_asr_task", "generate_lyric_asr"),
+                                                  ("audio_music_caption_task", "prepare_audio_caption_task", "generate_audio_caption"),
+                                                  ("asr_task", "prepare_asr_task", "generate_asr")])
+def test_asr_shaped_delegates_prompt_layout_and_loop(module, prep, gen_name):
+    """The reference's lyric_asr_task / audio_music_caption_task Generators under their own names (the boundary: a direct
+    importer of the reference's modules finds the same module, class and method names): prompt layout against the restated
+    reference, text loop against a scripted model, generate_asr kept on all of them (the CLI calls it for lyric_recognition)."""
+    import importlib
+    Generator = importlib.import_module(f"uniaudio2_amd.evaluation.{module}").Generator
+    ids = [11, 12, 13, 14, 15]
+    gen = Generator(_ScriptedModel(_text_log(ids)), TA, text_tokenizer_path="ids")
+    prompt = torch.tensor([128000, 5, 6, 128001])
+    reason, sem = torch.arange(3 * 8).view(3, 8), 100 + torch.arange(4 * 8).view(4, 8)
+    data, mask = getattr(gen, prep)(prompt, reason, sem)
+    want_d, want_m = _restated_asr_prompt(prompt, reason, sem)
+    assert torch.equal(data.long(), want_d) and torch.equal(mask.float(), want_m)
+    out = getattr(gen, gen_name)(prompt, module, reason_token=reason, semantic_token=sem, topk=1)
+    assert out == gen._text_tokenizer.decode(torch.tensor(ids))
+    assert all(c[1] == 1 and c[2] == 1 for c in gen._model.calls)          # one sequence, text-feedback mode
+    assert hasattr(gen, "generate_asr")
+
+
+def test_audio_understanding_and_speech_s2t_delegates():
+    """audio_understanding.py:233-339 / speech_s2t.py:274-381: the condition sequence (question text with its special tokens, then
+    the clip's reason / semantic codes) and generate_answer; speech_s2t takes the codes in either orientation, returns
+    (text, 1) and refuses prompts of >= 1500 frames with (-1, -1) as the reference does."""
+    from uniaudio2_amd.evaluation import audio_understanding, speech_s2t
+    ids = [21, 22, 23]
+    reason, sem = torch.arange(8 * 3).view(8, 3), torch.arange(8 * 5).view(8, 5)
+    prompt = torch.tensor([128000, 7, 128001])
+    au = audio_understanding.Generator(_ScriptedModel(_text_log(ids)), TA, text_tokenizer_path="ids")
+    q = torch.tensor([128000, 31, 32, 128001])
+    d = {"text_seq_question": q, "reason_seq": reason, "semantic_seq": sem}
+    data, mask = au.get_condition_seq(d, list(d), ["text", "audio", "audio"], prompt)
+    nq = au.add_special_token("text_seq_question", q).shape[0]
+    assert data.shape == (3 + nq + 5 + 7, 9)
+    off = 3 + nq
+    assert data[off, :8].eq(TA.reason_bos).all() and torch.equal(data[off + 1:off + 4, :8], reason.t())
+    assert torch.equal(data[off + 6:off + 11, :8], sem.t() + TA.audio_reason_card)
+    assert mask[:off, -1].eq(1).all() and mask[off:, :8].eq(1).all()
+    assert au.generate_answer(prompt, "audio_understanding", d=d, keys=list(d), types=["text", "audio", "audio"], topk=1) == \
+        au._text_tokenizer.decode(torch.tensor(ids))
+    st = speech_s2t.Generator(_ScriptedModel(_text_log(ids)), TA, text_tokenizer_path="ids")
+    d8 = {"reason_seq": reason, "semantic_seq": sem}
+    dT = {"reason_seq": reason.t().contiguous(), "semantic_seq": sem.t().contiguous()}          # (T, 8), as the reference's CLI passes them
+    a, am = st.get_condition_seq(d8, list(d8), ["audio", "audio"], prompt)
+    b, bm = st.get_condition_seq(dT, list(dT), ["audio", "audio"], prompt)
+    assert torch.equal(a, b) and torch.equal(am, bm) and a.shape == (3 + 5 + 7, 9)
+    res = st.generate_answer(prompt, "speech_s2t", d=dT, keys=list(dT), types=["audio", "audio"], topk=5)
+    assert res == (st._text_tokenizer.decode(torch.tensor(ids)), 1)
+    long_d = {"reason_seq": torch.zeros(8, 700, dtype=torch.long), "semantic_seq": torch.zeros(8, 800, dtype=torch.long)}
+    assert st.generate_answer(prompt, "speech_s2t", d=long_d, keys=list(long_d), types=["audio", "audio"]) == (-1, -1)
+
+
+def test_speech_edit_delegate_and_cli_routing():
+    """speech_edit_ss.py:229-343 is speech_s2s's generator under another module name; the CLI routes every task to the module the
+    reference routes it to (multi_task_inference.py:187-255)."""
+    from uniaudio2_amd.evaluation import speech_edit_ss, speech_s2s
+    from uniaudio2_amd.multi_task_inference import _get_generator_class
+    assert issubclass(speech_edit_ss.Generator, speech_s2s.Generator) and hasattr(speech_edit_ss.Generator, "generate_audio")
+    want = {"asr": "asr_task", "yue_asr": "asr_task", "lyric_recognition": "lyric_asr_task", "audio_caption": "audio_music_caption_task",
+            "music_caption": "audio_music_caption_task", "audio_understanding": "audio_understanding", "speech_s2t": "speech_s2t",
+            "tts": "tts_task", "yue_tts": "tts_task", "tta": "audiogen_task", "ttm": "musicgen_task", "lts": "songen_task",
+            "instruct_tts": "insturct_tts_task", "speech_s2s": "speech_s2s"}
+    for task, mod in want.items():
+        assert _get_generator_class(task).__module__ == f"uniaudio2_amd.evaluation.{mod}", task
+    with pytest.raises(ValueError):
+        _get_generator_class("nope")
+
+
 def test_ragged_schedule_runs_every_sequence_exactly_its_frames():
     """Continuous-batching plan of Model_stage3.generate_ragged."""
     from uniaudio2_amd.llm_models.model_new import ragged_schedule
@@ -235,7 +328,7 @@ class _ScriptedBatchModel:
     def set_sampling(self, topk, temperature, seed=None):
         self.sampling = (topk, temperature)
 
-    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False):
         assert batch == len(self.rows) and mode == 0
         self.calls.append((n, batch))
         out = torch.zeros(n, batch, 9, dtype=torch.int32)
@@ -297,7 +390,7 @@ class _ScriptedPairModel(_ScriptedBatchModel):
         self.rows = list(range(len(prompts)))                   # row -> original row; utterance = row // 2
         self.cursor = {b: 0 for b in range(len(prompts) // 2)}
 
-    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None):
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False):
         assert batch == len(self.rows) and mode == 2 and batch % 2 == 0
         assert all(self.rows[r] + 1 == self.rows[r + 1] and self.rows[r] % 2 == 0 for r in range(0, batch, 2)), "pairs stay adjacent"
         self.calls.append((n, batch))

@@ -154,6 +154,41 @@ def test_on_device_loop_equals_per_frame_api(golden, sd, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_skipping_the_text_head_leaves_the_audio_ids_unchanged(golden, sd, dtype):
+    """UA2_FRAME_SKIP_TEXT_HEAD: in the audio-feedback loops the text id a frame samples is fed back
+    under a zero mask and never read (evaluation/tts_task.py:259,274-277), so frames that skip lm_head + its sample produce the
+    same (reason, semantic) ids bit for bit — greedy, top-k sampling (the samplers' streams are keyed per head) and the guided
+    pair; the log's text column says -1.  The fp32 ids of the greedy run are the reference's own (golden)."""
+    d, _ = golden
+
+    def run(case, B, mode, skip, topk=1, cfg=1.0, frames=12):
+        tokens, mask = _case(d, case)
+        m = build_product_model(sd, dtype, batch=B)
+        dev = "cuda"
+        tokens, mask = tokens[:B].to(dev), mask[:B].to(dev)
+        L = tokens.shape[1]
+        m.reset_caches()
+        pos = torch.arange(0, L, device=dev).unsqueeze(0).repeat(B, 1)
+        m.forward_prefix(tokens[:, :-1], labels=tokens[:, 1:, :-1], tokens_mask=mask, loss_mask=mask, input_pos=pos[:, :-1])
+        m.set_cfg(cfg)
+        m.set_sampling(topk, 0.9, seed=77)
+        m.begin_decode(tokens[:, -1:], mask[:, -1:], torch.tensor([L - 1], device=dev))
+        return m.generate_frames(frames, B, mode, reason_eos=-1, reason_card=40, skip_text_head=skip).cpu().clone()
+
+    for case, B, mode, topk, cfg in (("tts2", 2, 0, 1, 1.0), ("tts2", 2, 0, 5, 1.0), ("cfg2", 2, 2, 1, 1.5), ("cfg2", 2, 2, 4, 1.5)):
+        full, skip = run(case, B, mode, False, topk, cfg), run(case, B, mode, True, topk, cfg)
+        assert torch.equal(full[:, :, 1:], skip[:, :, 1:]), (case, mode, topk)
+        assert int((skip[:, :, 0] != -1).sum()) == 0 and int((full[:, :, 0] < 0).sum()) == 0
+    if dtype == torch.float32:                                     # and those are the reference's ids
+        got = run("tts2", 2, 0, True)
+        ref = torch.from_numpy(d["tts2_samples"])
+        n = int((d["tts2_forbid"] == 0).sum())                     # the golden raises forbid_prefix by hand from there on
+        assert n >= 4 and torch.equal(got[:n, :, 1:].long(), ref[:n, :, 1:].long())
+    with pytest.raises(ValueError):
+        run("tts2", 2, 1, True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batch_rows_equal_single_runs_ragged(golden, sd, dtype):
     """Ragged batching the reference never had: rows with different prompt lengths
     in one batch reproduce their own B=1 runs bit for bit (ids and logits)."""

@@ -191,14 +191,15 @@ __global__ void bump_kernel(int32_t* c) { c[0] += 1; }
 __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int reason_card, int log_frames,
                                 int max_rows, int32_t* __restrict__ tokens, uint8_t* __restrict__ mask,
                                 int32_t* __restrict__ row_pos, int32_t* __restrict__ forbid,
-                                const int32_t* __restrict__ out, int32_t* __restrict__ log, int32_t* counters) {
+                                const int32_t* __restrict__ out, int32_t* __restrict__ log, int32_t* counters, int no_text) {
   const int frame = counters[0];
   const int w = ncb + 1;
   const bool audio_fb = (mode == 0 || mode == 2);
   for (int m = threadIdx.x; m < R; m += blockDim.x) {
     const int32_t* own = out + (size_t)m * w;
     if (frame < log_frames)
-      for (int j = 0; j < w; ++j) log[((size_t)frame * max_rows + m) * w + j] = (audio_fb || j == 0) ? own[j] : 0;   // text loop: no audio ids exist
+      for (int j = 0; j < w; ++j)   // text loop: no audio ids exist; UA2_FRAME_SKIP_TEXT_HEAD: no text id exists (logged as -1)
+        log[((size_t)frame * max_rows + m) * w + j] = (j == 0 && no_text) ? -1 : ((audio_fb || j == 0) ? own[j] : 0);
     // mode 2 (classifier-free-guidance pairs, tts_task.py:256-258,278-280): every row continues from the sample of
     // its pair's conditional row (rows 2p, 2p + 1; the reference has the one pair)
     const int32_t* o = (mode == 2) ? out + (size_t)(m & ~1) * w : own;
@@ -208,7 +209,7 @@ __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int re
       tokens[(size_t)m * w + i] = audio_fb ? o[1 + i] : 0;
       mask[(size_t)m * w + i] = audio_fb ? 1 : 0;
     }
-    tokens[(size_t)m * w + ncb] = o[0];
+    tokens[(size_t)m * w + ncb] = no_text ? 0 : o[0];           // fed back under a zero mask in the audio loop: any valid id
     mask[(size_t)m * w + ncb] = audio_fb ? 0 : 1;
     row_pos[m] += 1;
     if (audio_fb && all_reason_eos) forbid[m] = reason_card;  // tts_task.py:263-266
@@ -345,7 +346,12 @@ extern "C" int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream) {
 // text_only: the text head and its sample only.  The on-device text loop (feedback mode 1, asr_task.py:668-682) feeds
 // back zeros for the audio streams, so what the depth decoder would sample is never read: skipping its 8 passes leaves
 // the text ids unchanged ("waste removal with identical outputs") and removes ~45 % of the frame.
-static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
+// skip_text: the depth decoder only.  In the audio-feedback loops (feedback modes 0 and 2 of the TTS / TTA / TTM / LTS / S2S
+// generators) the sampled text id is fed back under a ZERO mask (evaluation/tts_task.py:274-277: text_mask = False) and appended
+// to a list nobody reads (:259), so the frame's audio ids do not depend on it: skipping lm_head + its arg-max (788 MB of weights
+// at 3072 x 128256 bf16 = 117 us of the 3.1 ms B = 1 frame, 220 us at 64 rows) leaves (reason, semantic) bit-identical
+// (model_new.py:617 computes it every frame).  generate_frame's (B, 9) API never sets it.
+static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bool skip_text = false) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_batch, "ua2_stage3_heads: R=%d out of range", R);
   hipStream_t s = (hipStream_t)stream;
   const ua2_stage3_desc& d = h->d;
@@ -369,14 +375,18 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
     UA2_HIP(hipEventRecord(h->ev_fork, s));
     UA2_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
   }
-  if (int rc = ua2_linear_launch(a, side)) return rc;
+  UA2_CHECK(!(skip_text && text_only), "ua2_stage3_heads: nothing left to compute");
+  if (!skip_text)
+    if (int rc = ua2_linear_launch(a, side)) return rc;
   // model_new.py:618-622: with guidance the sampler sees l[1] + (l[0] - l[1]) * cfg_scale and both rows take its sample
   const bool cfg = h->cfg_scale > 1.f && R > 1;
   UA2_CHECK(!cfg || R % 2 == 0, "ua2_stage3_heads: classifier-free guidance needs (conditional, unconditional) row pairs, R=%d", R);
   const int key_shift = cfg ? 1 : 0;                       // the two rows of a pair hold the same guided logits and draw the same numbers
-  if (cfg)
+  if (cfg && !skip_text)
     if (int rc = ua2_cfg_mix(h->text_logits, d.vt, d.vt, h->cfg_scale, nullptr, h->pmax_t, h->pidx_t, R / 2, side)) return rc;
-  if (h->topk == 1) {
+  if (skip_text) {
+    // nothing: the sampler streams are keyed by (seed, draw index, row, stream id), so the audio streams' draws do not move
+  } else if (h->topk == 1) {
     if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
                                   side)) return rc;
   } else {   // model_new.py:623 sample_topk(text_logits, topk, temperature)
@@ -424,32 +434,39 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream) {
 
 extern "C" int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream) { return heads_impl(h, R, false, stream); }
 
-extern "C" int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
-                                   void* stream) {
+static int feedback_impl(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card, void* stream, int no_text) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_rows && mode >= 0 && mode <= 2, "ua2_stage3_feedback: bad arguments");
   const ua2_stage3_desc& d = h->d;
   hipLaunchKernelGGL(feedback_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, R, d.n_cb, mode, reason_eos,
                      reason_card, d.log_frames, d.max_rows, d.tokens, d.mask, d.row_pos, d.forbid, d.out_tokens,
-                     d.frame_log, d.counters);
+                     d.frame_log, d.counters, no_text);
   UA2_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
+                                   void* stream) {
+  return feedback_impl(h, R, mode, reason_eos, reason_card, stream, 0);
 }
 
 extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
                                 int32_t use_graph, void* stream) {
   UA2_CHECK(h != nullptr, "ua2_stage3_frame: NULL handle");
   hipStream_t s = (hipStream_t)stream;
+  const bool skip_text = mode >= 0 && (mode & UA2_FRAME_SKIP_TEXT_HEAD) != 0;
+  if (mode >= 0) mode &= ~UA2_FRAME_SKIP_TEXT_HEAD;
+  UA2_CHECK(!skip_text || mode == 0 || mode == 2, "ua2_stage3_frame: UA2_FRAME_SKIP_TEXT_HEAD goes with the audio-feedback modes (0, 2)");
   auto body = [&](hipStream_t st) -> int {
     if (int rc = trunk_impl(h, R, true, st)) return rc;
-    if (int rc = heads_impl(h, R, mode == 1, st)) return rc;
+    if (int rc = heads_impl(h, R, mode == 1, st, skip_text)) return rc;
     if (mode < 0) return 0;
-    return ua2_stage3_feedback(h, R, mode, reason_eos, reason_card, st);
+    return feedback_impl(h, R, mode, reason_eos, reason_card, st, skip_text ? 1 : 0);
   };
   if (!use_graph) return body(s);
   int tbits, cbits;
   memcpy(&tbits, &h->temperature, sizeof(int));
   memcpy(&cbits, &h->cfg_scale, sizeof(int));
-  const auto key = std::make_tuple((int)R, (int)mode, (int)reason_eos, (int)reason_card, (int)h->topk, tbits, cbits);
+  const auto key = std::make_tuple((int)R, (int)mode | (skip_text ? UA2_FRAME_SKIP_TEXT_HEAD : 0), (int)reason_eos, (int)reason_card, (int)h->topk, tbits, cbits);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;

@@ -15,6 +15,8 @@ the EOS frame are discarded, so the returned ids are those of the reference's lo
 """
 from typing import Tuple
 
+import os
+
 import torch
 
 SPECIAL_TOKENS = {'<think>': 128002, '</think>': 128003, '</answer>': 128005,
@@ -65,6 +67,10 @@ class PhaseSplitter:
 
 class GeneratorBase:
     chunk_frames = 16        # frames per device-side chunk between host EOS checks
+    # The audio-feedback loops never read the text id a frame samples (tts_task.py:259 appends it to a list nobody uses, :274-277
+    # feed it back under text_mask = False): the on-device loop skips lm_head + its sample there (ua2hip.h
+    # UA2_FRAME_SKIP_TEXT_HEAD; identical (reason, semantic)).  UA2_KEEP_TEXT_HEAD=1 computes it as the reference does.
+    skip_text_head = os.environ.get("UA2_KEEP_TEXT_HEAD") is None
 
     def __init__(self, model, train_args, audio_tokenizer_config=None, audio_model_path=None,
                  text_tokenizer_path=None, is_cfg=False):
@@ -206,8 +212,8 @@ class GeneratorBase:
         while not ph.done and frame < max_audio_frames:
             n = min(self.chunk_frames, max_audio_frames - frame)
             log = self._model.generate_frames(n, B, 2 if self.is_cfg else 0, reason_eos=self.reason_eos,
-                                              reason_card=self.audio_reason_card,
-                                              max_pos=L + max_audio_frames).cpu()       # (n, B, 9)
+                                              reason_card=self.audio_reason_card, max_pos=L + max_audio_frames,
+                                              skip_text_head=self.skip_text_head).cpu()       # (n, B, 9)
             for f in range(n):
                 if not ph.push(log[f, 0:1, 1:]):                      # conditional row only (tts_task.py:256-258)
                     break
@@ -248,7 +254,8 @@ class GeneratorBase:
         while active and frame < max_audio_frames:
             n = min(self.chunk_frames, max_audio_frames - frame)
             log = self._model.generate_frames(n, per * len(active), 2 if self.is_cfg else 0, reason_eos=self.reason_eos,
-                                              reason_card=self.audio_reason_card, max_pos=longest + max_audio_frames).cpu()       # (n, rows, 9)
+                                              reason_card=self.audio_reason_card, max_pos=longest + max_audio_frames,
+                                              skip_text_head=self.skip_text_head).cpu()       # (n, rows, 9)
             keep = []
             for r, b in enumerate(active):
                 row = per * r                                        # the utterance's (conditional) row

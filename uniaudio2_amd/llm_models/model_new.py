@@ -275,12 +275,20 @@ class Model_stage3(nn.Module):
     # ---- MI355X-native fast path ---------------------------------------------------------------
     @torch.inference_mode()
     def generate_frames(self, n_frames: int, batch: int, mode: int, reason_eos: int = -1, reason_card: int = 0,
-                        max_pos: Optional[int] = None, use_graph: bool = True, frame_events=None) -> torch.Tensor:
+                        max_pos: Optional[int] = None, use_graph: bool = True, frame_events=None,
+                        skip_text_head: bool = False) -> torch.Tensor:
         """Runs `n_frames` frames back to back from the state left by the previous frame (first
         call: after `begin_decode`).  mode 0 = audio feedback (evaluation/tts_task.py:259-280),
         1 = text feedback (evaluation/asr_task.py:668-682; the depth decoder is skipped there — its samples are
         never fed back — so the audio columns of the log are zeros), 2 = guided pair.  Returns the log slice
-        (n_frames, batch, 9) int32 (device)."""
+        (n_frames, batch, 9) int32 (device).
+        skip_text_head (modes 0 and 2): lm_head and the text sample are skipped — the audio loops feed the text id back under
+        a zero mask and never read it (tts_task.py:259,274-277), so the audio columns are bit-identical with and without it;
+        the text column of the log then holds -1.  The reference-shaped generate_frame always computes it."""
+        if skip_text_head:
+            if mode not in (0, 2):
+                raise ValueError("skip_text_head applies to the audio-feedback modes (0, 2)")
+            mode = mode | 16                                  # UA2_FRAME_SKIP_TEXT_HEAD
         self._need()
         st = self._st
         start = int(st["counters"][0].item())

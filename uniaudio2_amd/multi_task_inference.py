@@ -113,9 +113,11 @@ def _load_config_and_llm(args):
 
 def _get_generator_class(task):
     task = task.strip().lower()
-    from .evaluation import asr_task, audiogen_task, insturct_tts_task, musicgen_task, songen_task, speech_s2s, tts_task
-    table = {"asr": asr_task, "yue_asr": asr_task, "lyric_recognition": asr_task, "audio_caption": asr_task,
-             "music_caption": asr_task, "audio_understanding": asr_task, "speech_s2t": asr_task,
+    from .evaluation import (asr_task, audio_music_caption_task, audio_understanding, audiogen_task, insturct_tts_task, lyric_asr_task,
+                             musicgen_task, songen_task, speech_s2s, speech_s2t, tts_task)
+    # the reference's routing, module for module (multi_task_inference.py:187-255)
+    table = {"asr": asr_task, "yue_asr": asr_task, "lyric_recognition": lyric_asr_task, "audio_caption": audio_music_caption_task,
+             "music_caption": audio_music_caption_task, "audio_understanding": audio_understanding, "speech_s2t": speech_s2t,
              "tts": tts_task, "yue_tts": tts_task, "tta": audiogen_task, "ttm": musicgen_task, "lts": songen_task,
              "instruct_tts": insturct_tts_task, "instructtts": insturct_tts_task, "speech_s2s": speech_s2s}
     if task not in table:
@@ -196,10 +198,18 @@ def run_understanding(args):
                                                      temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
             elif task == "speech_s2t":                                                             # :363-379: samples with --topk
                 d = {"reason_seq": reason.transpose(0, 1), "semantic_seq": semantic.transpose(0, 1)}
-                text_out = generator.generate_answer(task_prompt, task_name="speech_s2t", d=d, keys=["reason_seq", "semantic_seq"],
-                                                     types=["audio", "audio"], temperature=args.temperature, topk=args.topk,
-                                                     cfg_scale=args.cfg_scale)
-            else:
+                result = generator.generate_answer(task_prompt, task_name="speech_s2t", d=d, keys=["reason_seq", "semantic_seq"],
+                                                   types=["audio", "audio"], temperature=args.temperature, topk=args.topk,
+                                                   cfg_scale=args.cfg_scale)
+                if result == (-1, -1):                                                             # :379-381
+                    print(f"[Skip] {name}: sequence too long for speech_s2t")
+                    continue
+                text_out = result[0] if isinstance(result, tuple) else result
+            elif task in ("audio_caption", "music_caption"):                                       # :329-342
+                text_out = generator.generate_audio_caption(task_prompt, task_name=task, reason_token=reason, semantic_token=semantic,
+                                                            temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
+            else:   # asr, yue_asr, lyric_recognition (:310-327: the reference calls generate_asr on all three; its lyric module only
+                    # defines generate_lyric_asr, so the call fails there — here the lyric Generator has both names)
                 text_out = generator.generate_asr(task_prompt, task_name=task, reason_token=reason, semantic_token=semantic,
                                                   temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
             f_out.write(f"{name}\t{text_out}\n")
