@@ -421,11 +421,12 @@ def stage2_leg(dev, steps=10):
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
 
 
-def batched_leg(model, dev, B=64, frames=24, max_seq=2048):
+def batched_leg(model, dev, B=64, frames=24, max_seq=2048, order_free_rows=0):
     """Information beside the B = 1 headline: one GPU decoding B = 64 sequences together
     (32..33-token prompts, greedy, same kernels; rows bit-identical to their B = 1 runs, tests/test_gpu_configs.py).
     Re-plans the caches for 64 sequences, so it runs last."""
     model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=max_seq, max_rows=B * PROMPT_LEN, log_frames=frames + 8)
+    model.set_order_free_rows(order_free_rows)
     g = torch.Generator().manual_seed(99)
     t = torch.zeros(B, PROMPT_LEN, 9, dtype=torch.long)
     t[:, :, -1] = torch.randint(0, 128000, (B, PROMPT_LEN), generator=g)
@@ -510,7 +511,8 @@ def config4_leg(model, dev, world, rank, per_rank=64, seed=0):
     return {"prompts_total": n_total, "prompts_per_gpu": per_rank, "n_gpus": world, "frames_total": frames, "gathered_ok": ok,
             "seconds": round(dt, 4), "audio_tokens_per_s": round(8 * frames / dt, 1),
             "audio_tokens_per_s_per_gpu": round(8 * frames / dt / world, 1), "max_frames_of_a_sequence": int(nfr.max()),
-            "scaling": "weak", "exchange": "one fixed-shape int32 all-gather of the token tensors per shard, inside the timed region"}
+            "scaling": "weak", "exchange": ("one fixed-shape int32 all-gather of the token tensors per shard, inside the timed region" if world > 1 else
+                                            "none at world = 1 (parallel.gather_results returns before any collective; under --gpus N one int32 all-gather per shard)")}
 
 
 def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
@@ -647,7 +649,7 @@ def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
                                 "round 3's Tall == T1); prefill uses torch's intra-op threads"}, ids[:, 0], bf16_ids
 
 
-def config3_leg(model, dev, B=32, n_text=15, n_reason=53, n_sem=128, frames=32):
+def config3_leg(model, dev, B=32, n_text=15, n_reason=53, n_sem=128, frames=32, order_free_rows=0):
     """SURVEY.md §8d config 3 (ASR batch of 32 x 10-s clips), LLM half: per clip a prompt of 15 text frames + 53 reason
     frames + 128 semantic frames (L = 196; audio ids uniform in the valid card), one ragged prefill of 32 x 195 rows,
     then 32 greedy TEXT frames for all 32 sequences together (on-device text loop, depth decoder skipped —
@@ -666,6 +668,7 @@ def config3_leg(model, dev, B=32, n_text=15, n_reason=53, n_sem=128, frames=32):
         prompts.append((t.to(dev), m.to(dev)))
     rows = B * (L - 1)
     model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=2048, max_rows=rows, log_frames=frames + 8)
+    model.set_order_free_rows(order_free_rows)             # 0 = the default plan: every row keeps the bits of its single-sequence run
     res = {}
     for rep in range(2):                                   # first pass warms / captures
         torch.cuda.synchronize()
@@ -688,7 +691,8 @@ def config3_leg(model, dev, B=32, n_text=15, n_reason=53, n_sem=128, frames=32):
             "text_frames": frames, "decode_ms_per_frame": round(dec_ms / frames, 3),
             "text_tokens_per_s": round(B * frames / (dec_ms * 1e-3), 1),
             "clips_per_s_llm_half": round(B / ((pre_ms + dec_ms) * 1e-3), 2),
-            "roofline": {"kernel": "trunk prefill: prep + 128x128 tiled MFMA GEMM (ua2_gemm.hip) x 5 Linear x 33 layers, attention included in the time",
+            "roofline": {"kernel": ("trunk prefill: prep + order-free 256-row-tile MFMA GEMM (ua2_gemm2.hip; opt-in set_order_free_rows(%d)) x 5 Linear x 33 layers, attention included in the time" % order_free_rows)
+                                   if order_free_rows else "trunk prefill: prep + row-invariant 128x128 tiled MFMA GEMM (ua2_gemm.hip) x 5 Linear x 33 layers, attention included in the time",
                          "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(tf / 2500.0, 4), "traffic": None, "gemm_tflop": round(flop / 1e12, 2)}}
 
@@ -903,7 +907,15 @@ def main():
             res["batched_decode_1024"] = batched_leg(model, dev, B=1024, frames=6, max_seq=64)
         except Exception as e:  # noqa: BLE001 — information leg
             res["batched_decode_1024"] = {"error": repr(e)[:200]}
+        try:   # the same frame with the trunk's launches opted into the order-free GEMM (set_order_free_rows: rows >= 1024)
+            res["batched_decode_1024_order_free"] = batched_leg(model, dev, B=1024, frames=6, max_seq=64, order_free_rows=1024)
+        except Exception as e:  # noqa: BLE001
+            res["batched_decode_1024_order_free"] = {"error": repr(e)[:200]}
         res["config3_asr_batch32"] = config3_leg(model, dev)
+        try:   # ... and config 3's prefill (6240 rows) with it: what the opt-in buys, beside the default plan's line above
+            res["config3_asr_batch32_order_free"] = config3_leg(model, dev, order_free_rows=2048)
+        except Exception as e:  # noqa: BLE001
+            res["config3_asr_batch32_order_free"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if use_dist:

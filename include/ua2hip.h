@@ -527,6 +527,13 @@ int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint
  * pages on the MFMA flash kernel.  ua2_stage3_frame (decode) never uses groups. */
 int ua2_stage3_set_prefill_groups(ua2_stage3* h, const int32_t* group_rows, const int32_t* group_seq, const int32_t* group_nkeys,
                                   int32_t n_groups, int32_t group_q_tiles);
+/* rows > 0 (UA2_BF16 plans; default 0 = off): launches of the three trunk GPTs with at least `rows` rows — prefill chunks of
+ * batches (BASELINE config 3: 32 x 195 rows), decode frames of >= `rows` sequences — set ua2_linear_args.sum_order =
+ * UA2_SUM_ORDER_FREE: the 256-row-tile GEMM with one chain over K (csrc/ua2_gemm2.hip), 10-25 % faster per launch at >= 2048
+ * rows.  The price is the row-invariance contract ACROSS that threshold: a sequence prefilled alone (few rows) and inside a big
+ * batch (>= rows) then differs by fp32 summation noise in its K/V cache, i.e. by bf16-level noise in later logits — the same
+ * class of difference the MFMA prefill attention already has against decode rows.  Below the threshold nothing changes. */
+int ua2_stage3_set_order_free_rows(ua2_stage3* h, int32_t rows);
 /* cfg_scale > 1: frames of (conditional, unconditional) row pairs — rows 2p, 2p + 1; an even row count — sample from the guided
  * logits (ua2_cfg_mix); feedback mode 2 continues every row from its pair's conditional row. */
 int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale);

@@ -21,14 +21,15 @@ model = bench.build_model(dev)
 if os.environ.get("UA2_FORCE_LINEAR_MODE"):      # A/B: 4 = weights-stationary forms wherever they exist, 5 = the tiled GEMM everywhere (same bits)
     from uniaudio2_amd._lib import lib
     lib.ua2_debug_force_general_linear(int(os.environ["UA2_FORCE_LINEAR_MODE"]))
+ofr = int(os.environ.get("UA2_ORDER_FREE_ROWS", "0"))
 if leg == "config3":
-    print(bench.config3_leg(model, dev))
+    print(bench.config3_leg(model, dev, order_free_rows=ofr))
 elif leg == "batched":
     print(bench.batched_leg(model, dev))
 elif leg == "batched256":
     print(bench.batched_leg(model, dev, B=256, frames=12, max_seq=128))
 elif leg == "batched1024":
-    print(bench.batched_leg(model, dev, B=1024, frames=6, max_seq=64))
+    print(bench.batched_leg(model, dev, B=1024, frames=6, max_seq=64, order_free_rows=ofr))
 elif leg == "batched_both":
     print(bench.batched_leg(model, dev))
     print(bench.batched_leg(model, dev, B=256, frames=12, max_seq=128))

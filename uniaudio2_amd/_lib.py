@@ -100,6 +100,7 @@ _EXPORTS = {
     "ua2_dwconv1d": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ua2_cfg_mix": (C.c_int, [vp, i32, i32, C.c_float, vp, vp, vp, i32, vp]),
     "ua2_stage3_set_cfg": (C.c_int, [vp, C.c_float]),
+    "ua2_stage3_set_order_free_rows": (C.c_int, [vp, i32]),
     "ua2_linear_workspace_bytes": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_linear_chain_timed": (C.c_int, [C.POINTER(LinearArgs), i32, i32, vp, C.POINTER(C.c_float)]),
     "ua2_attn": (C.c_int, [C.POINTER(AttnArgs), vp]),

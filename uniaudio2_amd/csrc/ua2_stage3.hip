@@ -44,6 +44,7 @@ struct ua2_stage3 {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
   float cfg_scale = 1.f;       // > 1: classifier-free guidance over a (conditional, unconditional) row pair
+  int32_t order_free_rows = 0; // > 0 (bf16 plans): trunk launches of at least this many rows take UA2_SUM_ORDER_FREE (ua2_stage3_set_order_free_rows)
   // row groups of the next ua2_stage3_trunk call (prefill): the trunk's attention then runs the MFMA flash kernel
   const int32_t *group_rows = nullptr, *group_seq = nullptr, *group_nkeys = nullptr;
   int32_t n_groups = 0, group_q_tiles = 0;
@@ -125,6 +126,9 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   const Handover ho(h, R, C);
+  // ua2_stage3_set_order_free_rows: many-row launches of the trunk on the 256-row-tile kernel (one chain over K); the launcher falls
+  // back to the invariant kernels for anything outside that kernel's forms (scaled hand-over, small grids)
+  const int order = (dt == UA2_BF16 && !local && h->order_free_rows > 0 && R >= h->order_free_rows) ? UA2_SUM_ORDER_FREE : UA2_SUM_ORDER_INVARIANT;
   for (int l = 0; l < g.n_layer; ++l) {
     ua2_kv_geom kv{};                      // ring_pages = 0: the LM's caches are linear
     kv.k_pool = h->pools[gi][0][l]; kv.v_pool = h->pools[gi][1][l]; kv.page_table = g.page_table;
@@ -137,6 +141,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.w0 = h->ptrs[gi][0][l]; a.row_pos = row_pos; a.row_seq = row_seq; a.rope_cos = g.rope_cos;
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
     if (scaled) ho.consume(a);
+    a.sum_order = order;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     static const bool no_fuse = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
@@ -165,6 +170,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     if (fuse_attn) { a.row_pos = row_pos; a.row_seq = row_seq; a.kv = kv; }
     if (pack_o && !fuse_attn) a.x_packed = h->gemm_ws;
     if (scaled) ho.produce(a, h->norms[gi][1][l]);              // x after attention -> norm_2 + fc_1 / fc_2
+    a.sum_order = order;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -173,6 +179,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.w0 = h->ptrs[gi][2][l]; a.w1 = h->ptrs[gi][3][l]; a.ldy = g.inter;
     if (pack_act) a.y_packed = h->act_ws; else a.y = h->act;
     if (scaled) ho.consume(a);
+    a.sum_order = order;
     if (int rc = ua2_linear_launch(a, s)) return rc;
 
     fresh_args(h, a);
@@ -181,6 +188,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (pack_act) a.x_packed = h->act_ws;
     if (scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
+    a.sum_order = order;
     if (int rc = ua2_linear_launch(a, s)) return rc;
   }
   return 0;
@@ -327,6 +335,16 @@ extern "C" int ua2_stage3_set_prefill_groups(ua2_stage3* h, const int32_t* group
   UA2_CHECK(n_groups == 0 || (group_rows && group_seq && group_nkeys && group_q_tiles > 0), "ua2_stage3_set_prefill_groups: missing tables");
   h->group_rows = group_rows; h->group_seq = group_seq; h->group_nkeys = group_nkeys;
   h->n_groups = n_groups; h->group_q_tiles = group_q_tiles;
+  return 0;
+}
+
+extern "C" int ua2_stage3_set_order_free_rows(ua2_stage3* h, int32_t rows) {
+  UA2_CHECK(h != nullptr && rows >= 0, "ua2_stage3_set_order_free_rows: NULL handle or rows < 0");
+  if (h->order_free_rows != rows) {                  // recorded frames bake the kernel choice: drop them
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+  }
+  h->order_free_rows = rows;
   return 0;
 }
 

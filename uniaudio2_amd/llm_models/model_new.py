@@ -272,6 +272,13 @@ class Model_stage3(nn.Module):
             check(lib.ua2_stage3_set_cfg(self._h, cfg_scale), "ua2_stage3_set_cfg")
             self._cfg = cfg_scale
 
+    def set_order_free_rows(self, rows: int = 0):
+        """bf16 plans: trunk launches of >= `rows` rows (batched prefill, decode frames of that many sequences) run on the
+        order-free 256-row-tile GEMM (include/ua2hip.h ua2_stage3_set_order_free_rows; 0 = off, the default: every row keeps
+        the bits of its single-sequence run)."""
+        self._need()
+        check(lib.ua2_stage3_set_order_free_rows(self._h, int(rows)), "ua2_stage3_set_order_free_rows")
+
     # ---- MI355X-native fast path ---------------------------------------------------------------
     @torch.inference_mode()
     def generate_frames(self, n_frames: int, batch: int, mode: int, reason_eos: int = -1, reason_card: int = 0,
