@@ -425,7 +425,7 @@ def batched_leg(model, dev, B=64, frames=24, max_seq=2048, order_free_rows=0):
     """Information beside the B = 1 headline: one GPU decoding B = 64 sequences together
     (32..33-token prompts, greedy, same kernels; rows bit-identical to their B = 1 runs, tests/test_gpu_configs.py).
     Re-plans the caches for 64 sequences, so it runs last."""
-    model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=max_seq, max_rows=B * PROMPT_LEN, log_frames=frames + 8)
+    model.setup_caches(B, dtype=torch.bfloat16, max_seq_length=max_seq, max_rows=B * PROMPT_LEN, log_frames=2 * frames + 8)
     model.set_order_free_rows(order_free_rows)
     g = torch.Generator().manual_seed(99)
     t = torch.zeros(B, PROMPT_LEN, 9, dtype=torch.long)
@@ -452,10 +452,18 @@ def batched_leg(model, dev, B=64, frames=24, max_seq=2048, order_free_rows=0):
                # 11.8 GFLOP per sequence and frame against the dense bf16 MFMA peak
                "decode_gemm_frac_bf16_mfma_peak": round(11.8e9 * B / (ms * 1e-3) / 2.5e15, 4),
                "decode_frac_hbm_streamed_weights": round(11.8e9 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    try:   # the same frames with the text head skipped (what the batch generator runs; identical audio ids)
+        model.generate_frames(2, B, 0, reason_eos=-1, reason_card=REASON_CARD, skip_text_head=True)
+        e1.record()
+        model.generate_frames(frames - 4, B, 0, reason_eos=-1, reason_card=REASON_CARD, skip_text_head=True)
+        e2.record(); torch.cuda.synchronize()
+        res["decode_ms_per_frame_skip_text_head"] = round(e1.elapsed_time(e2) / (frames - 4), 3)
+    except Exception as e:  # noqa: BLE001
+        res["decode_ms_per_frame_skip_text_head"] = repr(e)[:120]
     return res
 
 
-def config4_leg(model, dev, world, rank, per_rank=64, seed=0):
+def config4_leg(model, dev, world, rank, per_rank=64, seed=0, skip_text_head=True):
     """BASELINE.json config 4 / SURVEY.md §8d: batched TTS, 64 ragged prompts PER GPU (512 over 8 GPUs), prompt lengths
     uniform[24, 48], frames to generate uniform[60, 300] (deterministic stop), sharded longest-first round-robin over the ranks
     (uniaudio2_amd/parallel.py), each rank decoding its shard as ONE continuous batch (sequences retire the frame they finish)
@@ -480,7 +488,8 @@ def config4_leg(model, dev, world, rank, per_rank=64, seed=0):
     model.setup_caches(per_rank, dtype=torch.bfloat16, max_seq_length=512, max_rows=4096, log_frames=320)
 
     def generate_batch(chunk):
-        ids = model.generate_ragged([(t, m) for t, m, _ in chunk], [n for _, _, n in chunk], mode=0, reason_eos=-1, reason_card=REASON_CARD)
+        ids = model.generate_ragged([(t, m) for t, m, _ in chunk], [n for _, _, n in chunk], mode=0, reason_eos=-1, reason_card=REASON_CARD,
+                                    skip_text_head=skip_text_head)   # as the product's batch generator runs it (identical audio ids)
         out = []
         for o in ids:                                        # (T, 9) int32 -> the (reason (8, T_r), semantic (8, T_s)) contract
             a = o[:, 1:].t().contiguous()
@@ -511,6 +520,7 @@ def config4_leg(model, dev, world, rank, per_rank=64, seed=0):
     return {"prompts_total": n_total, "prompts_per_gpu": per_rank, "n_gpus": world, "frames_total": frames, "gathered_ok": ok,
             "seconds": round(dt, 4), "audio_tokens_per_s": round(8 * frames / dt, 1),
             "audio_tokens_per_s_per_gpu": round(8 * frames / dt / world, 1), "max_frames_of_a_sequence": int(nfr.max()),
+            "text_head": "skipped on the audio-feedback frames (UA2_FRAME_SKIP_TEXT_HEAD, what evaluation/_generator.py runs: identical audio ids)" if skip_text_head else "computed every frame (the reference's work)",
             "scaling": "weak", "exchange": ("one fixed-shape int32 all-gather of the token tensors per shard, inside the timed region" if world > 1 else
                                             "none at world = 1 (parallel.gather_results returns before any collective; under --gpus N one int32 all-gather per shard)")}
 

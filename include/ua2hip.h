@@ -183,7 +183,9 @@ typedef struct ua2_linear_args {
   const float* x_ssq;
   /* [v7] Optional scratch for a K split of UA2_EPI_RESIDUAL launches that take the tiled many-row kernel with a long K and a
      grid too small for the device (the codec DiT's FF2: 1000 x 1536, K = 6144 on 192 workgroups).  When given (and N % 64 == 0,
-     no hand-over outputs, K >= 4096), the launcher may cut K into S <= 4 slabs — S a function of (M, N, K) only — whose
+     no hand-over outputs, K >= 4096), the launcher may cut K into S <= 4 slabs — S a function of (M, N, K) AND of how many slabs
+     split_ws_bytes holds: S = min(4, ceil(768 / workgroups(M, N)), split_ws_bytes / (M N 4)); a shorter last window of the DiT or a
+     smaller scratch therefore means another S, i.e. another (equally valid) summation order — whose
      workgroups run side by side and write fp32 partial sums [S][M][N] here; a second launch forms
      y = resid + out_scale (.) ((((s0 + s1) + s2) + s3) + bias) in that fixed order.  Deterministic, but the last bits differ
      from the unsplit launch (one chain per slab instead of the decode kernel's ranges): callers that rely on the row-count
@@ -319,7 +321,9 @@ int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32
  * other with BOUNDED spins; if one expires (a peer held back by another stream / process) the launch raises a device
  * flag and a second, self-contained launch behind it on the same stream — a no-op when the flag is clean — recomputes
  * every vector: rc 0 always means oracle-exact codes.  ua2_rvq_fallbacks counts how often that happened (health counter;
- * synchronous copy from the device).  Env UA2_RVQ_SPIN_LIMIT overrides the spin bound (tests force the path with 0). */
+ * synchronous copy from the device).  The second launch is enqueued on EVERY split encode (its workgroups read the flag and
+ * return when it is clean: ~2 us of launch + boundary per encode against the 51 us search — measured, profiles/r3_rvq.txt — the
+ * price of never needing a host round trip to learn whether the spin expired).  Env UA2_RVQ_SPIN_LIMIT overrides the spin bound (tests force the path with 0). */
 int ua2_rvq_encode(const float* x, const float* emb, const float* embT, int64_t N, int32_t L, int32_t C, int32_t D,
                    int32_t* codes, float* quantized, void* workspace, size_t workspace_bytes, void* stream);
 size_t ua2_rvq_workspace_bytes(int64_t N, int32_t L);
@@ -382,8 +386,9 @@ int ua2_conv1d(const ua2_conv1d_args* a, void* stream);
  * every layer emits the next layer's operand.  C must be a multiple of 32 (channel groups of the MFMA K dimension).
  * Arithmetic per output: the ua2_conv1d precision-1 sum (chunks = (channel group, tap) ascending; per chunk Wl*Xh, Wh*Xl,
  * Wh*Xh), bias added once, PReLU with single roundings, residual x = hi + lo (exact in fp32) added last, then the hi / lo
- * split.  Two kernels with identical bits (`variant`): 1 = plain (any K <= 32, reference of the bit-identity test),
- * 2 = software-pipelined LDS-DMA form (K in {1, 2, 7}), 0 = automatic. */
+ * split.  Three kernels with identical bits (`variant`): 1 = plain (any K <= 32, reference of the bit-identity test),
+ * 2 = software-pipelined LDS-DMA form (K in {1, 2, 7}), 3 = big-tile form (fused residual units of 32 / 64 channels: one 512- / 1024-step
+ * tile per 8-wave workgroup), 0 = automatic (big-tile for those units, pipelined otherwise, plain as the fallback). */
 typedef struct ua2_convtc_args {
   int32_t B, Cin, Cout, Tin, Tout;
   int32_t K, dilation, pad_left;   /* stride is 1 on the decode side */
@@ -391,7 +396,9 @@ typedef struct ua2_convtc_args {
   int32_t out_phases, out_trim_left; /* transposed conv as out_phases phase filters: packed row n = phase * Cout + co lands at
                                       y[t * out_phases + phase - out_trim_left][co] (see ua2_conv1d) */
   int32_t post_act;                /* UA2_ACT_NONE or UA2_ACT_PRELU */
-  int32_t variant;                 /* 0 auto, 1 plain, 2 pipelined (error if the shape is outside its instantiations) */
+  int32_t variant;                 /* 0 auto (fused 32- / 64-channel residual units: the big-tile kernel; everything else the pipelined one,
+                                      the plain one for shapes outside both), 1 plain, 2 pipelined, 3 big-tile (error if the shape is outside
+                                      the requested kernel's instantiations).  All three give identical bits. */
   const uint16_t* x_hi;            /* [B, Tin, Cin] bf16 */
   const uint16_t* x_lo;
   const void* w;                   /* ops.pack_conv_weight_x3 of the [rows, Cin, K] filter: hi ... */

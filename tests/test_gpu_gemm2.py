@@ -172,12 +172,18 @@ def test_k_slabs_on_small_grids(g2env):
         return y
 
     base = run(0, 0)
-    one = run(SUM_ORDER_FREE, 0)
+    # the tile-choice rule: 48 tiles of 128 x 256 are too few for the order-free kernel — without scratch for slabs the launch goes
+    # back to the invariant kernels (same bits as the default contract); with four slabs (192 workgroups) it takes it
+    assert torch.equal(run(SUM_ORDER_FREE, 0), base)
     four, again = run(SUM_ORDER_FREE, 4 * M * N), run(SUM_ORDER_FREE, 4 * M * N)
     assert torch.equal(four, again) and not torch.isnan(four).any()
-    for y in (one, four, run(SUM_ORDER_FREE, 2 * M * N + 3), run(SUM_ORDER_FREE, 4 * M * N, UA2_GEMM_NO_KSPLIT=1)):
+    assert 0 < (four - base).abs().max().item() < 2e-5 * K ** 0.5
+    # the kernel itself on this shape, tile forced: one chain, two slabs, four slabs, slabs switched off
+    one = run(SUM_ORDER_FREE, 0, UA2_GEMM2_BMT=8)
+    for y in (one, run(SUM_ORDER_FREE, 4 * M * N, UA2_GEMM2_BMT=8), run(SUM_ORDER_FREE, 2 * M * N + 3, UA2_GEMM2_BMT=8)):
         assert 0 < (y - base).abs().max().item() < 2e-5 * K ** 0.5
-    assert not torch.equal(one, four)
+    assert torch.equal(run(SUM_ORDER_FREE, 4 * M * N, UA2_GEMM2_BMT=8, UA2_GEMM_NO_KSPLIT=1), one)
+    assert torch.equal(run(SUM_ORDER_FREE, 4 * M * N, UA2_GEMM2_BMT=8), four) and not torch.equal(one, four)
 
 
 @pytest.mark.parametrize("M,N,K,bmt", [(6272, 1024, 3072, 16), (8000, 1536, 1536, 16), (1000, 1536, 6144, 8), (333, 512, 1056, 8), (2048, 3072, 8192, 16)])

@@ -1065,15 +1065,20 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
     const int mblocks = ua2_ceil_div(mtiles, B);
     size_t smem = (size_t)(G ? ring_slots(B) : 2 * kKS) * TILES * 1024;
     smem = std::max(smem, (size_t)4 * (B / 2) * 16 * 64 * sizeof(float));   // the staged epilogues park a 64-column patch per wave in the ring
-    const char* ks_env = getenv("UA2_GEMM_KSPLIT_HACK");   // timing experiment: every slab runs the full epilogue on its partial sums (wrong results)
-    int ks = ks_env ? std::max(1, atoi(ks_env)) : 1;
+    int ks = 1;
+#ifdef UA2_GEMM_EXPERIMENTS   // timing-only hooks with WRONG results (every slab runs the full epilogue on its partial sums): experiment builds only
+    if (const char* ks_env = getenv("UA2_GEMM_KSPLIT_HACK")) ks = std::max(1, atoi(ks_env));
+#endif
     int split_flags = 0;
     if constexpr (EPI == UA2_EPI_RESIDUAL && !H) {
       // K split proper (ua2hip.h split_ws): long K, a grid that leaves the device short of work, scratch for the slabs.  S depends on
-      // the shape only.  Measured inside the DiT step (FF2, 1000 x 1536, K = 6144, 192 workgroups): 6.06 -> 5.49 ms per step
+      // (M, N, K) through the grid AND on how many slabs the caller's scratch holds (`fit`): a launch's bits are a function of
+      // (M, N, K, split_ws_bytes) — another window length or a smaller scratch is another summation order (documented in ua2hip.h).  Measured inside the DiT step (FF2, 1000 x 1536, K = 6144, 192 workgroups): 6.06 -> 5.49 ms per step
       // with 4 slabs before the combine launch, 5.74 with 2 (timing-only hook UA2_GEMM_KSPLIT_LONGK, profiles/r4_notes.md §12).
       const int64_t grid1 = (int64_t)mblocks * nblocks;
       if (a.split_ws && a.prologue != UA2_PRO_SCALED && !a.part_max && a.N % 64 == 0 && a.ldr % 4 == 0 && a.ldy % 4 == 0 &&
+          ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.resid) | reinterpret_cast<uintptr_t>(a.bias) |
+            reinterpret_cast<uintptr_t>(a.out_scale) | reinterpret_cast<uintptr_t>(a.split_ws)) & 15) == 0 &&
           ua2_ceil_div(a.K, Elem<DT>::KC) >= (getenv("UA2_GEMM_KSPLIT_MIN_CHUNKS") ? atoi(getenv("UA2_GEMM_KSPLIT_MIN_CHUNKS")) : 128) &&
           grid1 < 512 && !getenv("UA2_GEMM_NO_KSPLIT")) {
         const int want = (int)std::min<int64_t>(4, (768 + grid1 - 1) / grid1);
@@ -1081,9 +1086,16 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
         if (std::min(want, fit) > 1) { ks = std::min(want, fit); split_flags = 2; }
       }
     }
+#ifdef UA2_GEMM_EXPERIMENTS
     if (const char* e2 = getenv("UA2_GEMM_KSPLIT_LONGK"))   // the same, only for RESIDUAL launches with K >= 4096 (the DiT's FF2 inside the step)
-      if (EPI == UA2_EPI_RESIDUAL && ua2_ceil_div(a.K, Elem<DT>::KC) >= 128) ks = std::max(1, atoi(e2));
-    const int flags = (getenv("UA2_GEMM_OLD_EPI") && !split_flags ? 0 : 1) | split_flags;   // test hook: the per-element epilogue everywhere (same bits)
+      if (EPI == UA2_EPI_RESIDUAL && ua2_ceil_div(a.K, Elem<DT>::KC) >= 128 && !split_flags) ks = std::max(1, atoi(e2));
+#endif
+    // the staged epilogue moves y / resid / bias / out_scale / y_norm_w as 16-byte pieces: row strides in whole float4s, 16-byte bases
+    // (everything torch hands over is; a caller's odd view takes the per-element form: same bits)
+    auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+    const bool vec_ok = a.ldy % 4 == 0 && al16(a.y) && (EPI != UA2_EPI_RESIDUAL || (a.ldr % 4 == 0 && al16(a.resid) && al16(a.out_scale))) &&
+                        al16(a.bias) && al16(a.bias1) && al16(a.y_norm_w) && (!a.y_h || a.ldh % 4 == 0) && al16(a.y_h);
+    const int flags = (((getenv("UA2_GEMM_OLD_EPI") && !split_flags) || (!vec_ok && !split_flags)) ? 0 : 1) | split_flags;   // UA2_GEMM_OLD_EPI: test hook, the per-element epilogue everywhere (same bits)
     hipLaunchKernelGGL(kern, dim3(mblocks * nblocks, ks), dim3(256), smem, s, a, ap, ks > 1 ? 1 : nw, mblocks, nblocks, group_m, flags);
     if (split_flags) {
       const size_t total4 = (size_t)a.M * (a.N / 4);

@@ -384,7 +384,7 @@ class Model_stage3(nn.Module):
         return pos
 
     @torch.inference_mode()
-    def generate_ragged(self, prompts, n_frames, mode: int = 0, reason_eos: int = -1, reason_card: int = 0):
+    def generate_ragged(self, prompts, n_frames, mode: int = 0, reason_eos: int = -1, reason_card: int = 0, skip_text_head: bool = False):
         """Batched fixed-length generation with continuous batching: prompts[b] = (tokens (L_b, 9), mask (L_b, 9)),
         n_frames[b] frames for sequence b (deterministic stop).  All sequences decode
         together; a sequence leaves the batch the frame it finishes.  Returns a list of (n_frames[b], 9) int32
@@ -399,7 +399,7 @@ class Model_stage3(nn.Module):
         for step, active, keep in ragged_schedule(n_frames):
             n_act = len(active)
             if step > 0:
-                log = self.generate_frames(step, n_act, mode, reason_eos, reason_card, max_pos=max_pos).clone()
+                log = self.generate_frames(step, n_act, mode, reason_eos, reason_card, max_pos=max_pos, skip_text_head=skip_text_head).clone()
                 for r, b in enumerate(active):
                     out[b].append(log[:, r])
             self.retire_rows(keep, n_act)
