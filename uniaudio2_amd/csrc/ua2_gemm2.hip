@@ -527,7 +527,12 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
   else if (nb6) pick_var(integral_constant<int, 8>{}, integral_constant<int, 6>{});
   else pick_var(integral_constant<int, 8>{}, integral_constant<int, 3>{});
 #else
+  // 128-row tiles: three slots and two workgroups per CU when the grid has more workgroups than CUs; six slots (five chunks in flight)
+  // when every workgroup has a CU to itself anyway — the small launches of the DiT's single window start on weights that are in no
+  // cache, and with two chunks in flight a workgroup advances one chunk per HBM round trip (measured in situ: profiles/r5_notes.md §3)
+  const bool deep = grid1 * ks <= env_int("UA2_GEMM2_DEEP_MAX_GRID", 256) && !env_int("UA2_GEMM2_NO_DEEP", 0);
   if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 2>{});
+  else if (deep) go(integral_constant<int, 8>{}, integral_constant<int, 6>{}, integral_constant<int, 2>{});
   else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 2>{});
 #endif
   if (flags & 2) {
