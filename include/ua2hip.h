@@ -245,7 +245,11 @@ typedef struct ua2_attn_args {
   const int32_t* group_nkeys;  /* [n_groups] 1 + the largest row_pos in the group (keys visited: 0 .. nkeys-1) */
   int32_t n_groups;
   int32_t group_q_tiles;       /* 16-row tiles per group: 2 with grouped-query heads (n_head > n_kv), 4 with n_head == n_kv */
+  int32_t flags;               /* [v8] UA2_ATTN_BF16_QP: the grouped form may round q and the softmax weights to bf16 once (no hi / lo
+                                  split) — what torch SDPA under bf16 autocast computes (the codec's DiT, reason_tokenizer.py:265); half the
+                                  matrix work.  Served at head size 64, 8 query tiles; ignored (the fp32-grade form runs) elsewhere. */
 } ua2_attn_args;
+#define UA2_ATTN_BF16_QP 1
 
 int ua2_attn(const ua2_attn_args* a, void* stream);
 /* Short-context form for the local (depth) decoder (model_new.py:629-641): every row attends to positions

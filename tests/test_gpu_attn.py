@@ -76,6 +76,32 @@ def test_flash_attention_eight_query_tiles_equal_four():
     assert float((outs[1].cpu() - s["ref"]).abs().max()) < 2e-4
 
 
+def test_flash_attention_bf16_q_and_weights_form():
+    """UA2_ATTN_BF16_QP (the DiT's order-free plan): q and the softmax weights rounded to bf16 once, as torch SDPA under bf16
+    autocast does — half the matrix work.  Against the fp32-grade form and the torch fp32 softmax: bf16-level agreement
+    (2^-8 relative on the weights: the bar is 1e-2 on unit-scale outputs), deterministic, padding rows untouched; and the
+    unmasked fast path of fully visible key blocks leaves the fp32-grade form's bits where they were (causal and dense)."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import ATTN_BF16_QP
+    s = _setup(24, 24, 64, [150, 150, 77], causal=False, seed=5)
+    R = s["q"].shape[0]
+    groups = ops.attn_groups(s["pos_h"].numpy(), s["seq_h"].numpy(), 24, 24, "cuda", q_tiles=8)
+    outs = []
+    for flags in (0, ATTN_BF16_QP, ATTN_BF16_QP):
+        y = torch.zeros_like(s["q"])
+        ops.attn(dtype=torch.bfloat16, R=R, q=s["q"], row_pos=s["pos"], row_seq=s["seq"], kv=s["geom"], y=y, groups=groups, flags=flags)
+        outs.append(y)
+    assert torch.equal(outs[1], outs[2]) and not torch.equal(outs[0], outs[1])
+    err = float((outs[1].cpu() - s["ref"]).abs().max())
+    print(f"flash, bf16 q / weights vs torch fp32: {err:.2e} (fp32-grade form: {float((outs[0].cpu() - s['ref']).abs().max()):.2e})")
+    assert err < 1e-2
+    # the flag is ignored where the form is not built (4 query tiles): the fp32-grade bits
+    g4 = ops.attn_groups(s["pos_h"].numpy(), s["seq_h"].numpy(), 24, 24, "cuda", q_tiles=4)
+    y4 = torch.zeros_like(s["q"])
+    ops.attn(dtype=torch.bfloat16, R=R, q=s["q"], row_pos=s["pos"], row_seq=s["seq"], kv=s["geom"], y=y4, groups=g4, flags=ATTN_BF16_QP)
+    assert torch.equal(y4, outs[0])
+
+
 def test_flash_attention_rows_do_not_depend_on_the_grouping():
     """Re-grouping the query rows (other tile compositions, padded groups, one row per group) leaves every row's bits
     unchanged: chunked prefill == one-pass prefill, a prompt alone == the same prompt inside a ragged batch."""

@@ -186,53 +186,81 @@ def gemm2_asm(tmp_path_factory):
     return out.read_text()
 
 
+def _kernels_whole(asm_text):
+    """as _kernels, but to the end of the function (a kernel with early exits has several s_endpgm)"""
+    out = {}
+    for m in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm_text, re.S | re.M):
+        ins, inasm = [], False
+        for line in m.group(2).splitlines():
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                inasm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                inasm = False
+                continue
+            t = t.split(";")[0].strip()
+            if t and not t.startswith(".") and not t.endswith(":"):
+                ins.append((t, inasm))
+        out[m.group(1)] = ins
+    return out
+
+
 def test_gemm2_phase_loop_requests_and_waits(gemm2_asm):
-    ks = {k: v for k, v in _kernels(gemm2_asm).items() if "gemm2_kernel" in k}
-    assert len(ks) >= 10, sorted(_kernels(gemm2_asm))
+    ks = {k: v for k, v in _kernels_whole(gemm2_asm).items() if "gemm2_kernel" in k}
+    assert len(ks) >= 15, sorted(_kernels(gemm2_asm))
     vmem = re.compile(r"(global|buffer|flat|scratch)_(load|store|atomic)")
     m0 = re.compile(r"\bm0\b")
     for name, ins in ks.items():
-        bmt, nb, var = (int(x) for x in re.search(r"gemm2_kernelILi\d+ELi(\d+)ELi(\d+)ELi(\d+)E", name).groups())
-        late = bool(var & 1)                                           # requests issued inside the C phase
+        bmt, nb = (int(x) for x in re.search(r"gemm2_kernelILi\d+ELi(\d+)ELi(\d+)ELi\d+E", name).groups())
         loads = (bmt + 16) // 8
+        steps = nb + (nb - 1)                                            # a whole turn of the ring (the loop body) + the partial last turn
         first_mfma = next(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
         last_mfma = max(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
         # prologue: NB - 1 chunks requested, then the wait that leaves NB - 2 in flight
-        hand_pre = [int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1)) for t, inasm in ins[:first_mfma] if inasm and t.startswith("s_waitcnt vmcnt")]
-        assert hand_pre and hand_pre[0] == (nb - 2) * loads, (name, hand_pre)
         n_pre_dma = 0
         for t, _ in ins[:first_mfma]:
             if t.startswith("s_waitcnt vmcnt"):
                 break
             n_pre_dma += t.startswith("global_load_lds")
         assert n_pre_dma == (nb - 1) * loads, (name, n_pre_dma)
-        # the loop: split at the hand-written barriers
-        seg_dma, seg_mfma, seg = [], [], [0, 0]
-        for t, inasm in ins[:last_mfma + 60]:
-            if t.startswith("global_load_lds"):
-                assert inasm, f"{name}: compiler-emitted LDS-DMA"
-                seg[0] += 1
-            elif t.startswith("v_mfma"):
-                seg[1] += 1
-            elif t.startswith("s_barrier"):
-                assert inasm, f"{name}: compiler-emitted s_barrier inside the phase loop"
-                seg_dma.append(seg[0]); seg_mfma.append(seg[1]); seg = [0, 0]
-            elif not inasm:
-                assert not (t.startswith("s_waitcnt") and "vmcnt" in t), f"{name}: compiler vmcnt wait in the phase loop: {t}"
-                assert not (vmem.match(t) and not t.startswith("scratch")), f"{name}: other vector-memory traffic in the phase loop: {t}"
-                assert not m0.search(t), f"{name}: compiler-emitted use of m0: {t}"
-        phases = [(d, m) for d, m in zip(seg_dma, seg_mfma)][1:]          # [0] = the prologue's requests
-        c_phases = [p for p in phases if p[1]]
-        l_phases = [p for p in phases if not p[1]][:nb + 1]
-        assert len(c_phases) == nb, (name, phases)                       # the loop is unrolled over the ring
-        assert all(m == 4 * bmt // 2 and d == (loads if late else 0) for d, m in c_phases), (name, phases)
-        assert sum(1 for d, _ in l_phases if d == (0 if late else loads)) >= nb, (name, phases)
-        # hand waits inside the loop leave NB - 2 chunks in flight (NB - 3 behind an L phase of the late-request form); the one in
-        # front of the epilogue drains
-        hand = [int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1)) for t, inasm in ins if inasm and t.startswith("s_waitcnt vmcnt")]
-        want = {(nb - 2) * loads} | ({(nb - 3) * loads} if late else set())
-        assert hand[-1] == 0 and set(hand[1:-1]) == want, (name, hand)
-        assert len(hand) == 1 + 2 * nb + 1, (name, hand)                 # prologue + (group 1 in L, group 0 in C) per unrolled step + drain
+        # the steps, located by their merged wait (block layout may put the epilogue's entry between the last turn's steps): the L
+        # phase = back to the previous hand-written barrier, the C phase = between the two barriers that follow
+        def clean(seg, what):
+            for t, inasm in seg:
+                if inasm:
+                    continue
+                assert not (t.startswith("s_waitcnt") and "vmcnt" in t), f"{name}: compiler vmcnt wait in {what}: {t}"
+                assert not vmem.match(t), f"{name}: other vector-memory traffic in {what}: {t}"
+                assert not m0.search(t), f"{name}: compiler-emitted use of m0 in {what}: {t}"
+                assert not t.startswith("s_barrier"), f"{name}: compiler-emitted s_barrier in {what}"
+        waits = [i for i, (t, inasm) in enumerate(ins) if inasm and re.match(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)", t)]
+        assert nb <= len(waits) <= steps, (name, len(waits))               # the compiler may share a step of the last turn with the loop body's
+        steps = len(waits)
+        for i in waits:
+            j = i - 1
+            while not ins[j][0].startswith(("s_barrier", "s_cbranch", "s_branch", "s_endpgm", "s_setpc")):   # the straight-line block of the step's L phase
+                j -= 1
+            lseg = ins[j + 1:i]
+            clean(lseg, "an L phase")
+            assert sum(1 for t, a in lseg if t.startswith("global_load_lds")) == loads and all(a for t, a in lseg if t.startswith("global_load_lds")), name
+            assert not any(t.startswith("v_mfma") for t, _ in lseg), name
+            assert ins[i + 1][1] and ins[i + 1][0].startswith("s_barrier"), (name, ins[i + 1])
+            k = i + 2
+            while not (ins[k][1] and ins[k][0].startswith("s_barrier")):
+                k += 1
+            cseg = ins[i + 2:k]
+            clean(cseg, "a C phase")
+            assert sum(1 for t, _ in cseg if t.startswith("v_mfma")) == 4 * bmt // 2, (name, len(cseg))
+            assert not any(t.startswith("global_load_lds") or t.startswith("s_cbranch") for t, _ in cseg), name
+            # both groups run one stream: no branch once a step has begun (loop / tail-guard branches sit in front of its fragment reads:
+            # the segment was cut behind the last of them)
+            assert sum(1 for t, _ in lseg if t.startswith("ds_read")) == bmt // 2 + 4, (name, "fragment reads of a step")
+        # every in-loop wait is the merged `vmcnt((NB - 2) LOADS) lgkmcnt(0)` behind the step's requests; the last one drains
+        hand = [re.match(r"s_waitcnt vmcnt\((\d+)\)( lgkmcnt\(0\))?", t) for t, inasm in ins if inasm and t.startswith("s_waitcnt vmcnt")]
+        counts = [int(h.group(1)) for h in hand]
+        assert sorted(counts) == [0] + [(nb - 2) * loads] * (1 + steps), (name, counts)       # prologue + one per step + the drain (text order varies)
+        assert sum(1 for h in hand if h.group(2)) == steps, name
         # M0 saved before and restored after every request batch
         text = [t for t, inasm in ins if inasm]
         assert sum(1 for t in text if re.match(r"s_mov_b32 s\d+, m0", t)) == sum(1 for t in text if re.match(r"s_mov_b32 m0, s\d+", t)) - sum(
@@ -246,9 +274,8 @@ def test_gemm2_no_scratch_in_the_phase_loop(gemm2_asm):
     assert len(names) >= 10
     for name, scratch in names:
         assert int(vg[name]) <= 256, name
-        if not re.search(r"gemm2_kernelILi\d+ELi8ELi3E", name):           # the two-workgroups-per-CU experiment form may spill in its epilogue
-            assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
-    for name, ins in _kernels(gemm2_asm).items():
+        assert int(scratch) == 0, f"{name} spills {scratch} B of scratch per lane"
+    for name, ins in _kernels_whole(gemm2_asm).items():
         if "gemm2_kernel" not in name:
             continue
         first = next(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))

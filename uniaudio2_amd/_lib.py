@@ -23,6 +23,7 @@ NORM_RMS_LIT, NORM_RMS_MOSHI, NORM_LAYERNORM = 0, 1, 2
 ROPE_HALF_SPLIT, ROPE_INTERLEAVED, ROPE_NONE = 0, 1, 2
 ACT_KIND_DEFAULT, GELU_TANH, GATE_SIGMOID_SECOND = 0, 1, 2
 SUM_ORDER_INVARIANT, SUM_ORDER_FREE = 0, 1
+ATTN_BF16_QP = 1
 UA2_PAGE = 64
 
 vp, i32, f32, i64 = C.c_void_p, C.c_int32, C.c_float, C.c_int64
@@ -49,7 +50,7 @@ class LinearArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("dtype", i32), ("R", i32), ("q", vp), ("row_pos", vp), ("row_seq", vp), ("kv", KvGeom), ("y", vp),
                 ("window", i32), ("y_packed", vp), ("group_rows", vp), ("group_seq", vp), ("group_nkeys", vp), ("n_groups", i32),
-                ("group_q_tiles", i32)]
+                ("group_q_tiles", i32), ("flags", i32)]
 
 
 class Conv1dArgs(C.Structure):

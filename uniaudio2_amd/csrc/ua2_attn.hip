@@ -286,7 +286,10 @@ int launch_fused(const ua2_attn_args& a, hipStream_t s) {
 // A row's result is a function of its own q, its position and the cache: key blocks are visited in order 0, 1, ...,
 // masked keys contribute exact zeros, MFMA output rows do not see each other — the composition of tiles and groups never
 // changes a row's bits (tests/test_gpu_invariance.py).
-template <int HS, int G, int QT>
+// SPLIT = false (ua2_attn_args.flags & UA2_ATTN_BF16_QP: callers outside the fp32-grade-softmax contract, i.e. the codec's DiT,
+// whose reference runs torch SDPA under bf16 autocast — q, k, v AND the softmax weights in bf16, reason_tokenizer.py:265): q and p are
+// rounded to bf16 once (no lo halves): half the MFMAs of both products and none of the lo-half conversions.
+template <int HS, int G, int QT, bool SPLIT = true>
 __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_args a) {
   constexpr int NW = G * QT;
   constexpr int DC = HS / 32;                 // 32-dim chunks of the QK product
@@ -377,20 +380,30 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
 #pragma unroll
       for (int dc = 0; dc < DC; ++dc) {
         const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(k_lds + (kt * 16 + ql) * KROW + dc * 64 + g * 16));
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qlo[dc]), st[kt], 0, 0, 0);
+        if constexpr (SPLIT) st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qlo[dc]), st[kt], 0, 0, 0);
         st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, __builtin_bit_cast(bf16x8, qh[dc]), st[kt], 0, 0, 0);
       }
     }
     // online softmax of this lane's query over the block's 64 keys: 16 local values, then the 4 lane groups
     float mx = -INFINITY;
+    // a block every query of the wave sees in full needs no mask (wave-uniform test; masking visible keys is the identity, so the
+    // bits do not depend on which path a block takes)
+    const bool all_visible = __all(row < 0 || qpos >= kb * UA2_PAGE + UA2_PAGE - 1);
+    if (all_visible) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kpos = kb * UA2_PAGE + kt * 16 + 4 * g + r;
-        if (kpos > qpos) st[kt][r] = -INFINITY;               // causal / padding mask by select: stale cache slots never leak
-        mx = fmaxf(mx, st[kt][r]);
-      }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kpos = kb * UA2_PAGE + kt * 16 + 4 * g + r;
+          if (kpos > qpos) st[kt][r] = -INFINITY;             // causal / padding mask by select: stale cache slots never leak
+          mx = fmaxf(mx, st[kt][r]);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
@@ -411,10 +424,14 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
       // (cycle stamps, profiles/r3_notes.md §8)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        unsigned hi, lo;
-        split_pair(pv[2 * e], pv[2 * e + 1], hi, lo);
-        ph[kc][e] = hi;
-        pl[kc][e] = lo;
+        if constexpr (SPLIT) {
+          unsigned hi, lo;
+          split_pair(pv[2 * e], pv[2 * e + 1], hi, lo);
+          ph[kc][e] = hi;
+          pl[kc][e] = lo;
+        } else {
+          ph[kc][e] = pack_bf16x2(pv[2 * e], pv[2 * e + 1]);
+        }
       }
     }
     ps += __shfl_xor(ps, 16);
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
         const char* vr = v_lds + (size_t)(dt * 16 + ql) * VROW + (kc * 32 + 4 * g) * 2;
         const uint2 v0 = *reinterpret_cast<const uint2*>(vr), v1 = *reinterpret_cast<const uint2*>(vr + 32);   // keys 4g..4g+3 | 16+4g..
         const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4{v0.x, v0.y, v1.x, v1.y});
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pl[kc]), o[dt], 0, 0, 0);
+        if constexpr (SPLIT) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pl[kc]), o[dt], 0, 0, 0);
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, ph[kc]), o[dt], 0, 0, 0);
       }
     }
@@ -456,9 +473,9 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   }
 }
 
-template <int HS, int G, int QT>
+template <int HS, int G, int QT, bool SPLIT = true>
 void launch_flash_one(const ua2_attn_args& a, hipStream_t s) {
-  constexpr auto kern = attn_flash_kernel<HS, G, QT>;
+  constexpr auto kern = attn_flash_kernel<HS, G, QT, SPLIT>;
   ua2_allow_big_lds<kern>();
   const size_t smem = (size_t)UA2_PAGE * (HS * 2 + 16) + (size_t)HS * (UA2_PAGE * 2 + 16);
   hipLaunchKernelGGL(kern, dim3(a.n_groups, a.kv.n_kv), dim3(64 * G * QT), smem, s, a);
@@ -470,6 +487,7 @@ int launch_flash(const ua2_attn_args& a, hipStream_t s) {
   if (hs == 128 && G == 3 && qt == 2) launch_flash_one<128, 3, 2>(a, s);
   else if (hs == 128 && G == 1 && qt == 4) launch_flash_one<128, 1, 4>(a, s);
   else if (hs == 64 && G == 1 && qt == 4) launch_flash_one<64, 1, 4>(a, s);
+  else if (hs == 64 && G == 1 && qt == 8 && (a.flags & UA2_ATTN_BF16_QP)) launch_flash_one<64, 1, 8, false>(a, s);
   else if (hs == 64 && G == 1 && qt == 8) launch_flash_one<64, 1, 8>(a, s);
   else if (hs == 64 && G == 2 && qt == 2) launch_flash_one<64, 2, 2>(a, s);
   else if (hs == 64 && G == 4 && qt == 2) launch_flash_one<64, 4, 2>(a, s);

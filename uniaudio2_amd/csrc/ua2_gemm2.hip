@@ -31,8 +31,8 @@
 //         lgkmcnt(0) in front of the barrier (the slot's next writer is a DMA two phases on).
 //   C(c): 8 WM MFMAs.
 //   landing: chunk c + 1 must be in LDS when phase 2c + 2 starts; every wave waits for ITS pieces of it — hand-counted
-//         `s_waitcnt vmcnt((NB - 2) LOADS)`: the NB - 2 younger chunks stay in flight, vmcnt retires in order — at the end of phase
-//         2c + 1 (group 0: behind C(c); group 1: behind L(c)), in front of the barrier every reader passes.
+//         `s_waitcnt vmcnt((NB - 2) LOADS)`: the NB - 2 younger chunks stay in flight, vmcnt retires in order — behind the requests
+//         of its L(c) (phase 2c for group 0, 2c + 1 for group 1), in front of a barrier every reader passes before phase 2c + 2.
 // The DMA is issued through inline asm (the builtin makes hipcc drain vmcnt / lgkmcnt at every later dependency:
 // profiles/r4_notes.md §2) and the waits are hand-counted; tests/test_isa_waits.py checks the compiled code for exactly that.
 //
@@ -87,24 +87,29 @@ __device__ __forceinline__ void g2_dma(const char* s0, const char* s1, const cha
       : "memory");
 }
 
-__device__ __forceinline__ void g2_dma1(const char* s0, unsigned voff, unsigned d0) {
-  unsigned keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(s0), "v"(voff), "s"(d0)
-               : "memory");
-}
-
 // Timing-only knock-outs (tools/ubench/build_alt.sh ... -DUA2_G2_DBG=<bits>; wrong results): 1 no ring refills after the prologue,
 // 2 no MFMAs, 4 no fragment reads.
 #ifndef UA2_G2_DBG
 #define UA2_G2_DBG 0
 #endif
+// bit 8: cycle stamps of waves 0 (group 0) and 4 (group 1) of workgroup 0 over chunks 8 .. 11 of its loop, read back through
+// ua2_g2_stamps (tools/ubench/g2_stamps.py); s_memtime costs ~11 % of a wave's cycles: a build for looking, not for timing
+#if UA2_G2_DBG & 8
+__device__ unsigned long long g_g2_stamp[2][4][8];
+extern "C" int ua2_g2_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g2_stamp), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#define G2_STAMP(slot)                                                                                              \
+  do {                                                                                                              \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wn == 0 && c >= 8 && c < 12)                            \
+      g_g2_stamp[grp][c - 8][(slot)] = __builtin_readcyclecounter();                                              \
+  } while (0)
+#else
+#define G2_STAMP(slot) do { } while (0)
+#endif
 
-// VAR (same bits, a cost choice): bit 0 = the requests of chunk c + NB - 1 are issued inside C(c), spread among its MFMAs, instead
-// of in L(c) (a request costs a wave ~60 issue cycles among bare MFMAs and 100-185 beside its fragment reads:
-// MI355X_MICROARCH.md "LDS-DMA piece issue cost"); group 1 then waits `vmcnt((NB - 3) LOADS)` behind L(c) — it has not yet
-// requested chunk c + NB - 1 there.  bit 1 = no s_setprio around the MFMAs.
+// VAR (same bits, a cost choice): 0 = plain, 1 = s_setprio 1 around the MFMAs (measured 1-3 % behind).  A third form — the requests
+// of chunk c + NB - 1 issued inside C(c), spread among its MFMAs — was measured 10 % behind and removed (profiles/r5_notes.md §1).
 template <int EPI, int BMT, int NB, int VAR>
 __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kernel(const ua2_linear_args a, const char* __restrict__ apack, const int mblocks,
                                                        const int nblocks, const int group_m, const int flags) {
@@ -116,8 +121,7 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
   constexpr int TILES = BMT + 16;        // fragment blocks per chunk
   constexpr int LOADS = TILES / 8;       // LDS-DMA requests per wave and chunk
   constexpr int NF = WM + 4;             // fragments a wave reads per chunk
-  constexpr bool DMA_C = (VAR & 1) != 0, PRIO = (VAR & 2) == 0;
-  static_assert(!DMA_C || NB >= 3, "the late-request form needs three slots");
+  constexpr bool PRIO = VAR == 1;
   static_assert(TILES % 8 == 0 && (LOADS == 3 || LOADS == 4), "request lists below");
   static_assert((NB - 1) * LOADS <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char g2_smem[];
@@ -162,10 +166,6 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
     if constexpr (LOADS == 4) g2_dma(tb[0] + co, tb[1] + co, tb[2] + co, tb[3] + co, voff, d, d + 8192u, d + 16384u, d + 24576u);
     else g2_dma(tb[0] + co, tb[1] + co, tb[2] + co, voff, d, d + 8192u, d + 16384u);
   };
-  auto dma_piece = [&](int c_req, int slot, int j) {
-    const size_t co = (size_t)min(c_req, nchunks - 1) * 1024;
-    g2_dma1(tb[j] + co, voff, lds0 + (unsigned)(slot * TILES + j * 8) * 1024u);
-  };
 
   const u32x4* lfa = reinterpret_cast<const u32x4*>(g2_smem) + (size_t)(grp * WM) * 64 + lane;          // this wave's A blocks of slot 0
   const u32x4* lfb = reinterpret_cast<const u32x4*>(g2_smem) + (size_t)(BMT + wn * WNT) * 64 + lane;    // ... and B blocks (matrix 0)
@@ -187,53 +187,65 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  for (int c0 = 0; c0 < nchunks; c0 += NB) {
+  // One chunk step of a wave = L(c) then C(c), slot index U = c % NB a compile-time constant (fragment addresses are immediates).
+  // Both groups run the SAME instruction stream — the wait for chunk c + 1 sits behind the requests of L(c) in both (group 0 could
+  // wait a phase later; a group-dependent wait costs two branches and their VALU -> SALU round trips per chunk: ~200 of the
+  // ~1550 cycles a chunk took, cycle stamps in profiles/r5_notes.md §2) — and nothing but the two barriers separates the phases.
+  auto step = [&](auto u_c, const int c) {
+    constexpr int u = decltype(u_c)::value;
+    // ---- L(c) ----
+    G2_STAMP(0);
+    if constexpr (!(UA2_G2_DBG & 4)) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int c = c0 + u;
-      if (c >= nchunks) break;
-      // ---- L(c) ----
-      if constexpr (!(UA2_G2_DBG & 4)) {
+      for (int mi = 0; mi < WM; ++mi) fr[mi] = lfa[(size_t)(u * TILES + mi) * 64];
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi) fr[mi] = lfa[(size_t)(u * TILES + mi) * 64];
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int ni = 0; ni < WNT; ++ni) fr[WM + t * WNT + ni] = lfb[(size_t)(u * TILES + t * BNM + ni) * 64];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(UA2_G2_DBG & 1) && !DMA_C) dma(c + NB - 1, (u + NB - 1) % NB);
-      if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (DMA_C ? NB - 3 : NB - 2) * LOADS) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- C(c) ----
-      if constexpr (!(UA2_G2_DBG & 2)) {
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-          for (int ci = 0; ci < 4; ++ci)
-            acc[mi][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[mi]), __builtin_bit_cast(bf16x8, fr[WM + ci]),
-                                                                  acc[mi][ci], 0, 0, 0);
-          if constexpr (DMA_C && !(UA2_G2_DBG & 1)) {
-#pragma unroll
-            for (int j = 0; j < LOADS; ++j)
-              if (mi == (j + 1) * WM / (LOADS + 1) - 1) {            // request j behind row tile mi: spread over the first 3/4 of the phase
-                __builtin_amdgcn_sched_barrier(0);
-                dma_piece(c + NB - 1, (u + NB - 1) % NB, j);
-                __builtin_amdgcn_sched_barrier(0);
-              }
-          }
-        }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-      } else if constexpr (DMA_C && !(UA2_G2_DBG & 1)) {
-        dma(c + NB - 1, (u + NB - 1) % NB);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (NB - 2) * LOADS) : "memory");
-      asm volatile("s_barrier" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+        for (int ni = 0; ni < WNT; ++ni) fr[WM + t * WNT + ni] = lfb[(size_t)(u * TILES + t * BNM + ni) * 64];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    G2_STAMP(1);
+    if constexpr (!(UA2_G2_DBG & 1)) dma(c + NB - 1, (u + NB - 1) % NB);
+    G2_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((UA2_G2_DBG & 1) ? 0 : (NB - 2) * LOADS) : "memory");
+    G2_STAMP(3);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    G2_STAMP(4);
+    // ---- C(c) ----
+    if constexpr (!(UA2_G2_DBG & 2)) {
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+          acc[mi][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[mi]), __builtin_bit_cast(bf16x8, fr[WM + ci]),
+                                                                acc[mi][ci], 0, 0, 0);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    G2_STAMP(5);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    G2_STAMP(7);
+  };
+  using std::integral_constant;
+  int c0 = 0;
+  for (; c0 + NB <= nchunks; c0 += NB) {             // whole turns of the ring: no per-step bound checks
+    step(integral_constant<int, 0>{}, c0);
+    step(integral_constant<int, 1>{}, c0 + 1);
+    if constexpr (NB > 2) step(integral_constant<int, 2>{}, c0 + 2);
+    if constexpr (NB > 3) step(integral_constant<int, 3>{}, c0 + 3);
+    if constexpr (NB > 4) step(integral_constant<int, 4>{}, c0 + 4);
+    if constexpr (NB > 5) step(integral_constant<int, 5>{}, c0 + 5);
+  }
+  {                                                  // the last, partial turn
+    const int r = nchunks - c0;
+    if (r > 0) step(integral_constant<int, 0>{}, c0);
+    if (r > 1) step(integral_constant<int, 1>{}, c0 + 1);
+    if constexpr (NB > 3) { if (r > 2) step(integral_constant<int, 2>{}, c0 + 2); }
+    if constexpr (NB > 4) { if (r > 3) step(integral_constant<int, 3>{}, c0 + 3); }
+    if constexpr (NB > 5) { if (r > 4) step(integral_constant<int, 4>{}, c0 + 4); }
   }
   if (grp == 0) {                                    // group 1's last C phase
     asm volatile("s_barrier" ::: "memory");
@@ -469,10 +481,9 @@ int env_int(const char* name, int dflt) {
   return e && *e ? atoi(e) : dflt;
 }
 
-// Instantiations: the production forms are BMT = 16 / four slots (one workgroup per CU) and BMT = 8 / three slots (two per CU, 128
-// registers), both without s_setprio (VAR = 2: measured 1-3 % ahead of VAR = 0, the late-request form VAR = 1 10 % behind —
-// profiles/r5_notes.md §1).  -DUA2_G2_EXPERIMENTS adds the other variants and the six-slot 128-row form behind the UA2_GEMM2_VAR /
-// UA2_GEMM2_NB hooks (tools/ubench/gemm2_variants.py).
+// Instantiations: BMT = 16 / four slots (one workgroup per CU), BMT = 8 / three slots (two per CU, 128 registers) and BMT = 8 / six
+// slots (small grids), all without s_setprio.  -DUA2_G2_EXPERIMENTS adds the s_setprio variant and free choice of the ring behind
+// the UA2_GEMM2_VAR / UA2_GEMM2_NB hooks (tools/ubench/gemm2_variants.py).
 template <int EPI>
 int launch2(const ua2_linear_args& a, hipStream_t s) {
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
@@ -514,26 +525,21 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
   };
   using std::integral_constant;
 #ifdef UA2_G2_EXPERIMENTS
-  const int var = env_int("UA2_GEMM2_VAR", 2), nb6 = env_int("UA2_GEMM2_NB", 0) == 6;
+  const int var = env_int("UA2_GEMM2_VAR", 0) == 1, nbx = env_int("UA2_GEMM2_NB", 0);
   auto pick_var = [&](auto bmt_c, auto nb_c) {
-    switch (var) {
-      case 0: go(bmt_c, nb_c, integral_constant<int, 0>{}); break;
-      case 1: go(bmt_c, nb_c, integral_constant<int, 1>{}); break;
-      case 3: go(bmt_c, nb_c, integral_constant<int, 3>{}); break;
-      default: go(bmt_c, nb_c, integral_constant<int, 2>{}); break;
-    }
+    if (var) go(bmt_c, nb_c, integral_constant<int, 1>{}); else go(bmt_c, nb_c, integral_constant<int, 0>{});
   };
   if (bmt == 16) pick_var(integral_constant<int, 16>{}, integral_constant<int, 4>{});
-  else if (nb6) pick_var(integral_constant<int, 8>{}, integral_constant<int, 6>{});
+  else if (nbx == 6) pick_var(integral_constant<int, 8>{}, integral_constant<int, 6>{});
   else pick_var(integral_constant<int, 8>{}, integral_constant<int, 3>{});
 #else
   // 128-row tiles: three slots and two workgroups per CU when the grid has more workgroups than CUs; six slots (five chunks in flight)
   // when every workgroup has a CU to itself anyway — the small launches of the DiT's single window start on weights that are in no
   // cache, and with two chunks in flight a workgroup advances one chunk per HBM round trip (measured in situ: profiles/r5_notes.md §3)
   const bool deep = grid1 * ks <= env_int("UA2_GEMM2_DEEP_MAX_GRID", 256) && !env_int("UA2_GEMM2_NO_DEEP", 0);
-  if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 2>{});
-  else if (deep) go(integral_constant<int, 8>{}, integral_constant<int, 6>{}, integral_constant<int, 2>{});
-  else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+  if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{});
+  else if (deep) go(integral_constant<int, 8>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{});
+  else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 0>{});
 #endif
   if (flags & 2) {
     const size_t total4 = (size_t)a.M * (a.N / 4);

@@ -135,10 +135,11 @@ def attn_groups(pos, seq, n_head, n_kv, device, q_tiles=None):
     return to(np.stack(rows)).contiguous(), to(gseq), to(nkeys), qt
 
 
-def attn(*, dtype, R, q, row_pos, row_seq, kv, y=None, window=0, groups=None, y_packed=None):
+def attn(*, dtype, R, q, row_pos, row_seq, kv, y=None, window=0, groups=None, y_packed=None, flags=0):
     """y [R, n_head*hs] fp32 and / or y_packed: the same rows already in ua2_linear's operand order (its consumer then takes
     them as x_packed and needs no prep launch)."""
     a = AttnArgs()
+    a.flags = flags
     a.y_packed = ptr(y_packed)
     if groups is not None:
         a.group_rows, a.group_seq, a.group_nkeys = ptr(groups[0]), ptr(groups[1]), ptr(groups[2])

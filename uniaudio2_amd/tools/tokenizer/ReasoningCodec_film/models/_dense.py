@@ -67,6 +67,7 @@ class DenseKV:
         self.row_seq = torch.arange(B, **i32).repeat_interleave(T)            # ... of sequence b
         self.all_pos = torch.full((B * T,), T - 1, **i32)                     # non-causal: every row sees positions 0..T-1
         self.dtype, self.B, self.T = dtype, B, T
+        self.attn_flags = 0            # ua2hip.h UA2_ATTN_BF16_QP: set by callers whose reference runs SDPA under bf16 autocast (the DiT)
         # bf16: the MFMA flash form of ua2_attn (K/V pages staged once per 64 query rows instead of once per row)
         # (128 query rows per workgroup at head size 64: the DiT step 6.76 -> 6.61 ms against 64)
         self.groups = ops.attn_groups(self.all_pos.cpu().numpy(), self.row_seq.cpu().numpy(), n_head, n_head, device,
@@ -77,7 +78,7 @@ class DenseKV:
         y_packed (a ua2_linear workspace) the rows are written in the consumer's operand order instead and nothing is returned."""
         y = torch.empty_like(q) if y_packed is None else None
         ops.attn(dtype=self.dtype, R=q.shape[0], q=q, row_pos=self.all_pos, row_seq=self.row_seq, kv=self.geom, y=y, groups=self.groups,
-                 y_packed=y_packed)
+                 y_packed=y_packed, flags=self.attn_flags)
         return y
 
 

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
-from ....._lib import EPI_GELU, EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EW_SILU, GELU_TANH, ROPE_NONE
+from ....._lib import ATTN_BF16_QP, EPI_GELU, EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EW_SILU, GELU_TANH, ROPE_NONE
 from ._dense import DenseKV, PackedLinear
 
 
@@ -227,6 +227,7 @@ class Transformer1DModel(nn.Module):
         for b in self.transformer_blocks:
             b.prepare(dtype)
         order = int(os.environ.get("UA2_DIT_SUM_ORDER", self.sum_order)) if dtype == torch.bfloat16 else 0
+        self._order = order
         for b in self.transformer_blocks:
             for k in ("qkv", "out", "ff1", "ff2"):
                 b._p[k].sum_order = order
@@ -279,6 +280,8 @@ class Transformer1DModel(nn.Module):
         kv = self._kvs.get((B, T))
         if kv is None:
             kv = self._kvs[(B, T)] = DenseKV(B, T, self.heads, self.head_dim, self._dtype, dev)
+            # order-free plan: attention as the reference's bf16-autocast SDPA computes it (q and softmax weights in bf16)
+            kv.attn_flags = ATTN_BF16_QP if (self._order and os.environ.get("UA2_DIT_ATTN_SPLIT") is None) else 0
         self._kv = kv
 
     @torch.inference_mode()
