@@ -538,7 +538,7 @@ int ua2_stage3_set_sampling(ua2_stage3* h, int32_t topk, float temperature, uint
  * pages on the MFMA flash kernel.  ua2_stage3_frame (decode) never uses groups. */
 int ua2_stage3_set_prefill_groups(ua2_stage3* h, const int32_t* group_rows, const int32_t* group_seq, const int32_t* group_nkeys,
                                   int32_t n_groups, int32_t group_q_tiles);
-/* rows > 0 (UA2_BF16 plans; default 0 = off): launches of the three trunk GPTs with at least `rows` rows — prefill chunks of
+/* rows > 0 (UA2_BF16 plans; default 0 = off): launches of the four GPTs (trunk and depth decoder) with at least `rows` rows — prefill chunks of
  * batches (BASELINE config 3: 32 x 195 rows), decode frames of >= `rows` sequences — set ua2_linear_args.sum_order =
  * UA2_SUM_ORDER_FREE: the 256-row-tile GEMM with one chain over K (csrc/ua2_gemm2.hip), 10-25 % faster per launch at >= 2048
  * rows.  The price is the row-invariance contract ACROSS that threshold: a sequence prefilled alone (few rows) and inside a big

@@ -87,6 +87,51 @@ def test_detokenize_no_reason_is_the_same_entry_point():
     check_t2a(437, model.calls, wave)
 
 
+class _NoisyStubModel(StubModel):
+    """The stand-in with the real model's second source of randomness: `prepare_latents` (AudioDiffusion1D.py:651-656) draws the
+    start noise on the device's generator inside inference_codes unless the caller hands it in."""
+
+    def prepare_latents(self, batch_size, num_frames, dtype, device):
+        return torch.randn(batch_size, num_frames, self.sq_codec_latent, device=device, dtype=torch.float32)
+
+    def inference_codes(self, codes_input, spk_embeds, true_latents, latent_length, incontext_length, noise=None, **kw):
+        if noise is None:
+            noise = self.prepare_latents(codes_input[-1].shape[0], latent_length, torch.float32, true_latents.device)
+        lat = super().inference_codes(codes_input, spk_embeds, true_latents, latent_length, incontext_length, **kw)
+        lat = lat + 0.01 * noise.to(lat.device)
+        if incontext_length > 0:
+            lat[:, :incontext_length] = true_latents[:, :incontext_length].float()
+        return lat
+
+
+@pytest.mark.parametrize("max_batch", [1, 2, 8])
+def test_batched_detokenize_equals_the_one_by_one_loop_on_the_stand_ins(max_batch):
+    """detokenize_no_reason_batch (window k of several utterances per inference_codes call, one decode per group) against a loop
+    over detokenize_no_reason with the same seed, on the deterministic stand-ins (CPU: both sources of randomness are then ONE
+    generator, so this also pins the interleaving of the draws): equal waves, the same windows / in-context lengths / `true`
+    latents per utterance, groups never larger than max_batch, utterances of 1 to 6 windows."""
+    Ts = (437, 100, 250, 1000, 251)
+    codes = [make_codes(T)[0] for T in Ts]
+    one = _NoisyStubModel()
+    tok1 = ReasoningTokenizer(sq_codec=StubCodec(), model=one, device="cpu")
+    torch.manual_seed(SEED)
+    want = [tok1.detokenize_no_reason(c, False, steps=7) for c in codes]
+    bat = _NoisyStubModel()
+    tokb = ReasoningTokenizer(sq_codec=StubCodec(), model=bat, device="cpu")
+    torch.manual_seed(SEED)
+    got = tokb.detokenize_no_reason_batch(codes, steps=7, max_batch=max_batch)
+    assert len(got) == len(want)
+    for T, a, b in zip(Ts, want, got):
+        assert a.shape == b.shape == (1, int(T / 12.5 * 24000)) and torch.equal(a, b), T
+    assert all(c["codes"].shape[0] <= max_batch for c in bat.calls)
+    # every (utterance, window) of the loop appears exactly once in the batch calls, with the same codes and `true` latents
+    rows = [(c["codes"][b], c["true"][b], c["incontext"]) for c in bat.calls for b in range(c["codes"].shape[0])]
+    assert len(rows) == len(one.calls)
+    for c in one.calls:
+        hit = [r for r in rows if r[2] == c["incontext"] and torch.equal(r[0], c["codes"][0]) and torch.equal(r[1], c["true"][0])]
+        assert len(hit) >= 1
+
+
 def check_a2t(n, reason, rec, fetch_calls=None):
     k = f"a2t_{n}_"
     assert reason.dtype == torch.int64 and rec.dtype == torch.int64

@@ -44,7 +44,7 @@ struct ua2_stage3 {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
   float cfg_scale = 1.f;       // > 1: classifier-free guidance over a (conditional, unconditional) row pair
-  int32_t order_free_rows = 0; // > 0 (bf16 plans): trunk launches of at least this many rows take UA2_SUM_ORDER_FREE (ua2_stage3_set_order_free_rows)
+  int32_t order_free_rows = 0; // > 0 (bf16 plans): GPT launches (trunk and depth decoder) of at least this many rows take UA2_SUM_ORDER_FREE (ua2_stage3_set_order_free_rows)
   // row groups of the next ua2_stage3_trunk call (prefill): the trunk's attention then runs the MFMA flash kernel
   const int32_t *group_rows = nullptr, *group_seq = nullptr, *group_nkeys = nullptr;
   int32_t n_groups = 0, group_q_tiles = 0;
@@ -128,7 +128,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
   const Handover ho(h, R, C);
   // ua2_stage3_set_order_free_rows: many-row launches of the trunk on the 256-row-tile kernel (one chain over K); the launcher falls
   // back to the invariant kernels for anything outside that kernel's forms (scaled hand-over, small grids)
-  const int order = (dt == UA2_BF16 && !local && h->order_free_rows > 0 && R >= h->order_free_rows) ? UA2_SUM_ORDER_FREE : UA2_SUM_ORDER_INVARIANT;
+  const int order = (dt == UA2_BF16 && h->order_free_rows > 0 && R >= h->order_free_rows) ? UA2_SUM_ORDER_FREE : UA2_SUM_ORDER_INVARIANT;
   for (int l = 0; l < g.n_layer; ++l) {
     ua2_kv_geom kv{};                      // ring_pages = 0: the LM's caches are linear
     kv.k_pool = h->pools[gi][0][l]; kv.v_pool = h->pools[gi][1][l]; kv.page_table = g.page_table;

@@ -338,9 +338,12 @@ class ReasoningTokenizer:
         L, ov, Cl = plans[0]["latent_length"], plans[0]["ovlp_frames"], self.model.sq_codec_latent
         nwin = [len(p["starts"]) for p in plans]
         cpu_noise, dev_noise = [], []
-        for p, w in zip(plans, nwin):                                 # the one-by-one consumption order of both generators
-            cpu_noise.append([torch.randn(1, L if i == 0 else L - ov, Cl) for i in range(w)])
-            dev_noise.append([self.model.prepare_latents(1, L, torch.float32, dev) for _ in range(w)])
+        for p, w in zip(plans, nwin):                                 # the one-by-one consumption order of both generators: utterance by
+            cn, dn = [], []                                           # utterance, window by window, :235 / :282 first, then :655
+            for i in range(w):
+                cn.append(torch.randn(1, L if i == 0 else L - ov, Cl))
+                dn.append(self.model.prepare_latents(1, L, torch.float32, dev))
+            cpu_noise.append(cn); dev_noise.append(dn)
         latents = [[] for _ in rec_codecs]
         segments = [[] for _ in rec_codecs]
         for i in range(max(nwin)):
