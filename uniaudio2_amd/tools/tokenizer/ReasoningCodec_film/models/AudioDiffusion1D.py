@@ -129,7 +129,7 @@ class BASECFM(nn.Module):
                 y = self._euler_steps(x_in.clone(), x_in.clone(), inc_in, n, ts, mu_in, guidance_scale, lambda inp, t: dit(inp, t))
             if self._pool is None:
                 self._pool = graph.pool()                                 # one memory pool for every recorded shape
-            while len(self._graphs) >= 6:                                 # a handful of shapes per deployment (P x {first, later} windows)
+            while len(self._graphs) >= 18:                                # P = 1 .. codec_batch utterances x {first, later} windows; one shared pool
                 self._graphs.pop(next(iter(self._graphs)))
             g = self._graphs[key] = (graph, x_in, inc_in, mu_in, y)
         graph, x_in, inc_in, mu_in, y = g

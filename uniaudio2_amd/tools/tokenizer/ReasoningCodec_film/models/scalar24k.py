@@ -365,7 +365,7 @@ class ScalarModel(nn.Module):
     def decode(self, x, use_graph=None):
         """latent -> wav; the latent is snapped to the 1/9 grid first (:403-407).
         use_graph (default: on for the split-plane path): the ~44 launches of a decode are captured once per (input shape, device)
-        into a HIP graph — an LRU of 8 shapes on one shared memory pool — and replayed — stage 2 decodes window after window of one shape (reason_tokenizer.py:277-290), and issued one by
+        into a HIP graph — an LRU of 12 shapes on one shared memory pool — and replayed — stage 2 decodes window after window of one shape (reason_tokenizer.py:277-290), and issued one by
         one from Python the chain is ~0.7 ms of host time against ~1.1 ms of kernels: the next kernel speed-up would have been
         host-bound."""
         if not self._ready:
@@ -378,7 +378,7 @@ class ScalarModel(nn.Module):
         key = (tuple(x.shape), x.device.index)
         g = self._graphs.pop(key, None)                               # re-inserted below: the dict's order is the LRU order
         if g is None:
-            while len(self._graphs) >= 8:                             # least recently used shape goes; all graphs share one memory pool
+            while len(self._graphs) >= 12:                            # least recently used shape goes; all graphs share one memory pool
                 self._graphs.pop(next(iter(self._graphs)))
             x_in = torch.empty_like(x)
             x_in.copy_(x)
