@@ -116,6 +116,42 @@ def test_config3_prefill_on_the_order_free_gemm_stays_inside_the_bf16_bars(full_
     print(f"  ids equal on {B - int(differ.sum())} of {B} sequences")
 
 
+def test_decode_frames_on_the_order_free_gemm_trunk_and_depth_decoder(full_model):
+    """set_order_free_rows(256) with 256 sequences decoding together: every GPT launch of the frame — the 33 trunk layers at
+    256 rows and the depth decoder's 4 layers x 8 codebook steps at 256 rows — takes the one-chain kernel (the heads keep the
+    invariant kernels).  Same prefill (done on the default plan, so both frames start from identical K/V caches), one frame each
+    way: codebook 0's audio logits see only the trunk + one decoder pass and are held to the bf16 bars; later codebooks condition
+    on the ids sampled before them, so they are compared on the sequences whose earlier ids agree."""
+    m, bench = full_model
+    B = 256
+    prompts = []
+    for i in range(B):
+        g = torch.Generator().manual_seed(3000 + i)
+        prompts.append(_text_rows(torch.randint(0, 128000, (8,), generator=g)))
+    got = []
+    for rows in (0, 256):
+        m.setup_caches(B, dtype=torch.bfloat16, max_seq_length=64, max_rows=B * 8, log_frames=8)
+        m.set_order_free_rows(0)
+        m.begin_ragged(prompts)
+        m.set_order_free_rows(rows)
+        log = m.generate_frames(1, B, 0).clone()
+        got.append((m.buffer("audio_logits", B).float().cpu().clone(), log[0].cpu()))
+    m.set_order_free_rows(0)
+    (la, ia), (lb, ib) = got
+    d0 = la[:, 0] - lb[:, 0]
+    err, rms = d0.abs().max().item(), d0.double().pow(2).mean().sqrt().item()
+    scale = la[:, 0].double().pow(2).mean().sqrt().item()
+    print(f"B = 256 decode frame, order-free vs invariant: codebook-0 logits rms {rms:.3e} max {err:.3e} (logit rms {scale:.3f})")
+    assert 0 < err < 0.4 and rms < 8e-2, (err, rms)
+    same = torch.ones(B, dtype=torch.bool)
+    for k in range(8):
+        dk = (la[:, k] - lb[:, k])[same]
+        assert dk.abs().max().item() < 0.4, (k, dk.abs().max().item(), int(same.sum()))
+        same &= ia[:, 1 + k] == ib[:, 1 + k]
+    print(f"  all 8 audio ids equal on {int(same.sum())} of {B} sequences")
+    assert int(same.sum()) >= B // 2
+
+
 def test_config4_ragged_tts_batch_with_retirement(full_model):
     m, bench = full_model
     B = 64
