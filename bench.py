@@ -521,8 +521,15 @@ def config4_leg(model, dev, world, rank, per_rank=64, seed=0, skip_text_head=Tru
             "seconds": round(dt, 4), "audio_tokens_per_s": round(8 * frames / dt, 1),
             "audio_tokens_per_s_per_gpu": round(8 * frames / dt / world, 1), "max_frames_of_a_sequence": int(nfr.max()),
             "text_head": "skipped on the audio-feedback frames (UA2_FRAME_SKIP_TEXT_HEAD, what evaluation/_generator.py runs: identical audio ids)" if skip_text_head else "computed every frame (the reference's work)",
-            "scaling": "weak", "exchange": ("one fixed-shape int32 all-gather of the token tensors per shard, inside the timed region" if world > 1 else
-                                            "none at world = 1 (parallel.gather_results returns before any collective; under --gpus N one int32 all-gather per shard)")}
+            "scaling": "weak", "exchange": ("one fixed-shape int32 all-gather of the token tensors per shard (parallel.gather_results: pack -> device -> "
+                                            f"dist.all_gather on `{_dist_backend()}` -> parse), inside the timed region, world = {world}" if _dist_backend() else
+                                            "none (no process group: a plain `python bench.py` run; under torchrun — any --gpus N, one rank included — "
+                                            "parallel.gather_results runs one int32 all-gather per shard)")}
+
+
+def _dist_backend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else ""
 
 
 def cpu_baseline_leg(model, tokens, mask, frames_all=20, frames_t1=3):
@@ -760,6 +767,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the codec / batched / config-3 / config-5 information legs")
+    ap.add_argument("--config4-leg", action="store_true", help="with --no-legs: still run the config-4 leg (the product's sharded runner + its all-gather)")
     a = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -899,7 +907,7 @@ def main():
         res["parity_notes"] = ("bf16 ids are asserted teacher-forced against the bf16 oracle (tests/test_gpu_fullsize.py); the live "
                                "codec's ResidualVQ is restated from vector_quantize_pytorch==1.27.15's published algorithm and is "
                                "parity-UNPINNED against the package itself (absent here)")
-    if not a.no_legs and (world > 1 or solo):
+    if (not a.no_legs or a.config4_leg) and (world > 1 or solo):
         # the named multi-GPU config (BASELINE.json configs[3]): every rank takes part (collective inside)
         res["config4_batched_tts"] = config4_leg(model, dev, world, rank)
     if solo and not a.no_legs:

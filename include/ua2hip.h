@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 8
+#define UA2_VERSION 9
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -213,6 +213,14 @@ size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K);
  * (4: always its skinny form, 5: always its 128-row tiled form).
  * Modes 0, 2, 3, 4 and 5 produce bit-identical results (tests/test_gpu_invariance.py). */
 int ua2_debug_force_general_linear(int on);
+
+/* Test hooks (ABI v9).  ua2_debug_kernel_launches: how many launches of a kernel family this process has issued so far —
+ * "gemm2" (ua2_gemm2.hip, the order-free many-row GEMM), "gemm" (ua2_gemm.hip's tiled kernel), "skinny2", "gemv"; -1 for an unknown
+ * name.  A test that claims "the order-free kernel ran" reads the counter on both sides of the call instead of trusting the
+ * launcher's rules.  ua2_debug_refresh_env: the launchers read their UA2_* tuning / A-B environment variables ONCE (they used to
+ * call getenv on every launch); a process that changes one of them afterwards (the tests do) calls this to have them read again. */
+int64_t ua2_debug_kernel_launches(const char* family);
+void ua2_debug_refresh_env(void);
 
 /* Measurement helper (bench.py roofline leg): launches args[0..n) back to back `iters` times on
  * `stream`, bracketed by hipEvents recorded on that same stream, waits for the stop event and

@@ -28,3 +28,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fresh_kernel_env(request):
+    """The launchers cache their UA2_* knobs (ua2hip.h ua2_debug_refresh_env).  Tests change the environment through monkeypatch /
+    os.environ; this fixture is set up first and torn down last, so the cache is re-read before a GPU test starts and after every
+    other fixture (monkeypatch included) has restored the environment."""
+    gpu = request.node.get_closest_marker("gpu") is not None
+    if gpu:
+        from uniaudio2_amd._lib import lib
+        lib.ua2_debug_refresh_env()
+    yield
+    if gpu:
+        from uniaudio2_amd._lib import lib
+        lib.ua2_debug_refresh_env()

@@ -53,3 +53,29 @@ def test_token_files_follow_the_reference_contract(tmp_path):
     args.save_safetensors = False
     cli._save_tokens(args, "utt_1", reason, semantic)
     assert not (tmp_path / "utt_1_tokens.safetensors").exists() and (tmp_path / "utt_1_reason.pt").exists()
+
+
+def test_extension_flags_default_to_the_reference_behaviour():
+    """The MI355X-only flags give up nothing unless asked: --codec_batch 1 = the reference's one-by-one stage-2 loop
+    (multi_task_inference.py:540-548: a waveform never depends on its batch-mates), --order_free_rows 0 = every LM row keeps the
+    bits of its single-sequence run, --batch_size 1 = one utterance per GPU at a time."""
+    a = cli.get_parser().parse_args(["--task", "TTS"])
+    assert (a.codec_batch, a.order_free_rows, a.batch_size, a.dtype) == (1, 0, 1, "bf16")
+    b = cli.get_parser().parse_args(["--task", "TTS", "--codec_batch", "8", "--order_free_rows", "256"])
+    assert (b.codec_batch, b.order_free_rows) == (8, 256)
+
+
+def test_stage2_shard_by_length_is_a_balanced_partition():
+    """Stage 2 deals utterances longest first (as stage 1 does): every rank's list is sorted by length, so consecutive --codec_batch
+    groups share a window count, and the ranks' total frames differ by at most one utterance."""
+    names = [f"n{i:02d}" for i in range(23)]
+    frames = [250 * (1 + (7 * i) % 3) + i for i in range(23)]               # 1-, 2- and 3-window utterances, interleaved by name
+    for world in (1, 2, 4, 8):
+        shards = [cli.stage2_shard(names, world, r, lengths=frames) for r in range(world)]
+        assert sorted(sum(shards, [])) == names
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1
+        for sh in shards:
+            ln = [frames[names.index(n)] for n in sh]
+            assert ln == sorted(ln, reverse=True)
+        tot = [sum(frames[names.index(n)] for n in sh) for sh in shards]
+        assert max(tot) - min(tot) <= max(frames)

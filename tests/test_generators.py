@@ -265,6 +265,11 @@ def test_audio_understanding_and_speech_s2t_delegates():
     assert torch.equal(a, b) and torch.equal(am, bm) and a.shape == (3 + 5 + 7, 9)
     res = st.generate_answer(prompt, "speech_s2t", d=dT, keys=list(dT), types=["audio", "audio"], topk=5)
     assert res == (st._text_tokenizer.decode(torch.tensor(ids)), 1)
+    # an 8-frame clip: the CLI hands over (T, 8) = (8, 8); speech_s2t.py:291-293 leaves a square input alone, i.e. takes it as (T, 8)
+    r8 = torch.arange(64).view(8, 8)                                                             # (8 codebooks, T = 8) as stored on disk
+    d88 = {"reason_seq": r8.t().contiguous(), "semantic_seq": sem.t().contiguous()}
+    c, _ = st.get_condition_seq(d88, list(d88), ["audio", "audio"], prompt)
+    assert torch.equal(c[3 + 1:3 + 1 + 8, :8], r8.t())                                           # frame t carries codebooks 0..7 of time t
     long_d = {"reason_seq": torch.zeros(8, 700, dtype=torch.long), "semantic_seq": torch.zeros(8, 800, dtype=torch.long)}
     assert st.generate_answer(prompt, "speech_s2t", d=long_d, keys=list(long_d), types=["audio", "audio"]) == (-1, -1)
 

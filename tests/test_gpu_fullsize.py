@@ -200,3 +200,57 @@ def test_fullsize_fp32_greedy_ids_match_oracle(full_model, oracle_runs):
             assert int(ids[f, c]) == int(want[f, c]), (f, c, ids[f].tolist(), want[f].tolist())
             compared += 1
     assert compared == 9 * FRAMES_F32
+
+
+def test_fullsize_order_free_prefill_of_256_rows_vs_bf16_oracle(full_model):
+    """VERDICT r5 #2b: the OPT-IN order-free plan of the LM (`set_order_free_rows`, CLI --order_free_rows) against the ORACLE, not
+    against another HIP kernel: a 257-token prompt is prefilled as ONE 256-row chunk with every eligible trunk launch on
+    csrc/ua2_gemm2.hip (launch counter), then frame 0's text and first-codebook logits are held to the bf16 oracle with the bars of
+    test_fullsize_bf16_frame0_and_properties (rms below 0.75 x the oracle's own bf16-vs-fp32 distance, absolute caps), and the
+    row-invariant plan on the same prompt gives the A/B."""
+    from oracle.lm_oracle import GPTShape, Stage3Oracle, run_decode_loop
+    from uniaudio2_amd._lib import lib
+    m, bench = full_model
+    dev = torch.device("cuda")
+    L = 257
+    g = torch.Generator().manual_seed(777)
+    tokens = torch.zeros(1, L, 9, dtype=torch.long)
+    tokens[0, :, -1] = torch.randint(0, 128000, (L,), generator=g)
+    mask = torch.zeros(1, L, 9, dtype=torch.bool)
+    mask[0, :, -1] = True
+    sd = {k: v.detach().to("cpu", torch.float32) for k, v in m.state_dict().items()}
+    shapes = dict(backbone=GPTShape(28, 3072, 24, 8, 8192), understanding=GPTShape(3, 3072, 24, 8, 8192),
+                  generation=GPTShape(2, 3072, 24, 8, 8192), decoder=GPTShape(4, 2048, 32, 8, 8192))
+    runs = {}
+    for mode in ("bf16", "fp32"):
+        o = Stage3Oracle(sd, shapes, bench.SEM_CARD, bench.REASON_CARD, 8, mode=mode, max_seq=320)
+        o.setup_caches(1)
+        runs[mode] = run_decode_loop(o, tokens, mask, 1, "audio", collect_logits=True)
+        del o
+    tk, mk = tokens.to(dev), mask.to(dev)
+
+    def frame0(order_free_rows):
+        m.setup_caches(1, dtype=torch.bfloat16, max_seq_length=512, max_rows=256, log_frames=16)
+        m.set_order_free_rows(order_free_rows)
+        n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+        m.reset_caches()
+        m.forward_prefix(tk[:, :-1], tokens_mask=mk, input_pos=torch.arange(L - 1, device=dev).unsqueeze(0))
+        torch.cuda.synchronize()
+        n = lib.ua2_debug_kernel_launches(b"gemm2") - n0
+        m.generate_frame(tk[:, -1:], mk[:, -1:], input_pos=torch.tensor([L - 1], device=dev), input_pos_maxp1=L)
+        return m.buffer("text_logits", 1).cpu().numpy()[0].copy(), m.buffer("audio_logits", 1).cpu().numpy()[0, 0].copy(), n
+
+    try:
+        ft, fa, n_free = frame0(256)
+        it, ia, n_inv = frame0(0)
+    finally:
+        m.setup_caches(2, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=64)
+    assert n_inv == 0 and n_free >= 33 * 2, (n_free, n_inv)     # at least q|k|v and the SwiGLU pair of every trunk layer
+    ob, of = runs["bf16"], runs["fp32"]
+    for name, gf, gi, o, f in (("text", ft, it, ob["text_logits"][0][0].numpy(), of["text_logits"][0][0].numpy()),
+                               ("audio0", fa, ia, ob["audio_logits"][0][0, 0].numpy(), of["audio_logits"][0][0, 0].numpy())):
+        d, di, q = gf - o, gi - o, o - f
+        print("full-size, 256-row prefill, frame-0 %s: order-free vs bf16 oracle rms %.3e max %.3e | invariant plan rms %.3e max %.3e | "
+              "oracle bf16-vs-fp32 rms %.3e max %.3e (%d gemm2 launches)" % (name, _rms(d), np.abs(d).max(), _rms(di), np.abs(di).max(), _rms(q), np.abs(q).max(), n_free))
+        assert _rms(d) < 0.75 * _rms(q), name
+        assert _rms(d) < 4e-2 and np.abs(d).max() < 0.3, name

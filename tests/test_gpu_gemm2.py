@@ -37,12 +37,20 @@ def g2env():
             os.environ.pop(k, None)
         for k, v in kw.items():
             os.environ[k] = str(v)
+        _refresh()
     yield set_
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
+    _refresh()
+
+
+def _refresh():
+    """The launchers read their UA2_* knobs once (ua2hip.h ua2_debug_refresh_env): tell them the environment changed."""
+    from uniaudio2_amd._lib import lib
+    lib.ua2_debug_refresh_env()
 
 
 @pytest.mark.parametrize("bmt", [16, 8])

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 (timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $OUT/pytest_gpu.log
 (timeout 1200 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err)
 # one rank under torchrun: init_process_group("nccl"), all_gather and barrier execute on this box (VERDICT r4 #6a)
-(timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --no-legs --no-cpu-baseline --steps 3 --warmup 1 > $OUT/bench_line_torchrun_1rank.json 2> $OUT/bench_torchrun.err)
+(timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --no-legs --config4-leg --no-cpu-baseline --steps 3 --warmup 1 > $OUT/bench_line_torchrun_1rank.json 2> $OUT/bench_torchrun.err)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof_codec -- python $R/tools/ubench/codec_decode.py > $OUT/codec_decode.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -- python $R/tools/ubench/codec_decode.py > /dev/null 2>&1

@@ -97,6 +97,8 @@ _EXPORTS = {
     "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
     "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
+    "ua2_debug_kernel_launches": (i64, [C.c_char_p]),
+    "ua2_debug_refresh_env": (None, []),
     "ua2_struct_size": (C.c_size_t, [C.c_int]),
     "ua2_dwconv1d": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ua2_cfg_mix": (C.c_int, [vp, i32, i32, C.c_float, vp, vp, vp, i32, vp]),

@@ -33,9 +33,13 @@ def build_lib(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    hdr_t = max(os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "ua2hip.h")])
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
+        # per-object: a source is recompiled when it, or any header, is newer than its object (force = everything)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            continue
         procs.append((src, subprocess.Popen([HIPCC, *FLAGS, "-c", src, "-o", obj],
                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = False

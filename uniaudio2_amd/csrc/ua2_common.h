@@ -4,6 +4,7 @@
 #include <atomic>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/ua2hip.h"
 
@@ -155,6 +156,28 @@ inline void ua2_allow_big_lds() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done.fetch_or(bit, std::memory_order_release);
 }
+
+// ---- test hooks (ua2hip.h ABI v9): launch counters per kernel family, and UA2_* environment variables read once -------------
+enum { UA2_CNT_GEMM2 = 0, UA2_CNT_GEMM = 1, UA2_CNT_SKINNY2 = 2, UA2_CNT_GEMV = 3, UA2_CNT_N = 4 };
+extern std::atomic<int64_t> g_ua2_launches[UA2_CNT_N];
+extern std::atomic<int> g_ua2_env_gen;              // bumped by ua2_debug_refresh_env
+inline void ua2_count_launch(int family) { g_ua2_launches[family].fetch_add(1, std::memory_order_relaxed); }
+// An integer knob read from the environment at first use and again after ua2_debug_refresh_env (launchers used to call getenv
+// several times per launch).  `unset` is returned while the variable is absent or empty.  Benign if two threads race on the first read.
+struct Ua2EnvInt {
+  const char* name; int unset; int gen = -1; int val = 0; bool present = false;
+  constexpr Ua2EnvInt(const char* n, int u) : name(n), unset(u) {}
+  void load() {
+    const int g = g_ua2_env_gen.load(std::memory_order_acquire);
+    if (g == gen) return;
+    const char* e = getenv(name);
+    present = e != nullptr;
+    val = (e && *e) ? atoi(e) : unset;
+    gen = g;
+  }
+  int get() { load(); return val; }
+  bool set() { load(); return present; }
+};
 
 // internal launchers used by both the op-level ABI and the frame executor
 int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);

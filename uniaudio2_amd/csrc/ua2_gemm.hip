@@ -1097,6 +1097,7 @@ void launch_gemm(const ua2_linear_args& a, int nw, hipStream_t s) {
                         al16(a.bias) && al16(a.bias1) && al16(a.y_norm_w) && (!a.y_h || a.ldh % 4 == 0) && al16(a.y_h);
     const int flags = (((getenv("UA2_GEMM_OLD_EPI") && !split_flags) || (!vec_ok && !split_flags)) ? 0 : 1) | split_flags;   // UA2_GEMM_OLD_EPI: test hook, the per-element epilogue everywhere (same bits)
     hipLaunchKernelGGL(kern, dim3(mblocks * nblocks, ks), dim3(256), smem, s, a, ap, ks > 1 ? 1 : nw, mblocks, nblocks, group_m, flags);
+    ua2_count_launch(UA2_CNT_GEMM);
     if (split_flags) {
       const size_t total4 = (size_t)a.M * (a.N / 4);
       hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
@@ -1156,8 +1157,13 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
   }
   UA2_LAUNCH_CHECK();
   // callers outside the row-invariance contract (ua2hip.h sum_order): the 256-row-tile kernel with one chain over K.
-  // UA2_GEMM2_FORCE: experiment hook — every eligible bf16 launch, whatever its contract (in-situ timing of LM prefill / big batches).
-  if (a.sum_order == UA2_SUM_ORDER_FREE || getenv("UA2_GEMM2_FORCE"))
+  bool order_free = a.sum_order == UA2_SUM_ORDER_FREE;
+#ifdef UA2_GEMM_EXPERIMENTS
+  // UA2_GEMM2_FORCE (experiment builds only: it breaks the LM's row-invariance contract): every eligible bf16 launch, whatever its
+  // contract, for in-situ timing of LM prefill / big batches
+  order_free = order_free || getenv("UA2_GEMM2_FORCE") != nullptr;
+#endif
+  if (order_free)
     if (const int rc = ua2_gemm2_try_launch(a, s); rc <= 0) return rc;
   const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
   // The weights-stationary form (ua2_skinny.hip) serves the model's bf16 shapes up to a few hundred rows: measured against

@@ -476,10 +476,10 @@ __global__ __launch_bounds__(256) void gemm2_combine_kernel(const ua2_linear_arg
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e && *e ? atoi(e) : dflt;
-}
+// Tuning / A-B knobs: read once (ua2_common.h Ua2EnvInt; ua2_debug_refresh_env re-reads them — the tests toggle some)
+Ua2EnvInt g_group_m{"UA2_GEMM2_GROUP_M", 8}, g_ks_min_chunks{"UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96}, g_ks_max_grid{"UA2_GEMM2_KSPLIT_MAX_GRID", 128},
+    g_no_ksplit{"UA2_GEMM_NO_KSPLIT", 0}, g_bmt{"UA2_GEMM2_BMT", 0}, g_deep_max_grid{"UA2_GEMM2_DEEP_MAX_GRID", 256}, g_no_deep{"UA2_GEMM2_NO_DEEP", 0},
+    g_off{"UA2_GEMM2_OFF", 0}, g_min_rows{"UA2_GEMM2_MIN_ROWS", 256};
 
 // Instantiations: BMT = 16 / four slots (one workgroup per CU), BMT = 8 / three slots (two per CU, 128 registers) and BMT = 8 / six
 // slots (small grids), all without s_setprio.  -DUA2_G2_EXPERIMENTS adds the s_setprio variant and free choice of the ring behind
@@ -490,7 +490,7 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
   constexpr int BNM = 16 / NT;
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16), nblocks = ua2_ceil_div(ntiles, BNM);
   const int nchunks = ua2_ceil_div(a.K, 32);
-  const int group_m = std::max(1, env_int("UA2_GEMM2_GROUP_M", 8));
+  const int group_m = std::max(1, g_group_m.get());
   // Tile choice (a cost model fitted on tools/ubench/gemm2_variants.py, profiles/r5_gemm2_variants.txt): 256-row tiles when they
   // keep >= 70 % of the CU slots of their last round busy (and fill half the device at all); else 128-row tiles, two workgroups per
   // CU, when there are >= 128 of them (K slabs included); else the launch is too small for either and goes back to ua2_gemm.hip
@@ -498,7 +498,7 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
   const int64_t t16 = (int64_t)ua2_ceil_div(mtiles, 16) * nblocks, t8 = (int64_t)ua2_ceil_div(mtiles, 8) * nblocks;
   auto slabs_for = [&](int64_t grid) {
     if constexpr (EPI == UA2_EPI_RESIDUAL) {
-      if (a.split_ws && nchunks >= env_int("UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96) && grid <= env_int("UA2_GEMM2_KSPLIT_MAX_GRID", 128) && !getenv("UA2_GEMM_NO_KSPLIT")) {
+      if (a.split_ws && nchunks >= g_ks_min_chunks.get() && grid <= g_ks_max_grid.get() && !g_no_ksplit.set()) {
         const int want = (int)std::min<int64_t>(4, (256 + grid - 1) / grid);
         const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
         return std::max(1, std::min(want, fit));
@@ -506,7 +506,7 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
     }
     return 1;
   };
-  int bmt = env_int("UA2_GEMM2_BMT", 0);
+  int bmt = g_bmt.get();
   if (!bmt) {
     const double e16 = (double)t16 / (double)(((t16 + 255) / 256) * 256);
     if (t16 >= 128 && e16 >= 0.70) bmt = 16;
@@ -522,10 +522,12 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
     constexpr auto kern = gemm2_kernel<EPI, B, NBUF, V>;
     ua2_allow_big_lds<kern>();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid1, ks), dim3(512), (size_t)NBUF * (B + 16) * 1024, s, a, ap, mblocks, nblocks, group_m, flags);
+    ua2_count_launch(UA2_CNT_GEMM2);
   };
   using std::integral_constant;
 #ifdef UA2_G2_EXPERIMENTS
-  const int var = env_int("UA2_GEMM2_VAR", 0) == 1, nbx = env_int("UA2_GEMM2_NB", 0);
+  static Ua2EnvInt g_var{"UA2_GEMM2_VAR", 0}, g_nb{"UA2_GEMM2_NB", 0};
+  const int var = g_var.get() == 1, nbx = g_nb.get();
   auto pick_var = [&](auto bmt_c, auto nb_c) {
     if (var) go(bmt_c, nb_c, integral_constant<int, 1>{}); else go(bmt_c, nb_c, integral_constant<int, 0>{});
   };
@@ -536,7 +538,7 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
   // 128-row tiles: three slots and two workgroups per CU when the grid has more workgroups than CUs; six slots (five chunks in flight)
   // when every workgroup has a CU to itself anyway — the small launches of the DiT's single window start on weights that are in no
   // cache, and with two chunks in flight a workgroup advances one chunk per HBM round trip (measured in situ: profiles/r5_notes.md §3)
-  const bool deep = grid1 * ks <= env_int("UA2_GEMM2_DEEP_MAX_GRID", 256) && !env_int("UA2_GEMM2_NO_DEEP", 0);
+  const bool deep = grid1 * ks <= g_deep_max_grid.get() && !g_no_deep.get();
   if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{});
   else if (deep) go(integral_constant<int, 8>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{});
   else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 0>{});
@@ -554,9 +556,9 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
 // 0 = launched, 1 = this launch is outside the kernel's forms (the caller goes on to ua2_gemm.hip's kernels).  The operand is
 // already packed (x_packed, or the prep launch into workspace).
 int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
-  if (a.dtype != UA2_BF16 || getenv("UA2_GEMM2_OFF")) return 1;
+  if (a.dtype != UA2_BF16 || g_off.set()) return 1;
   if (a.prologue == UA2_PRO_SCALED || a.part_max || a.y_norm_w) return 1;
-  if (a.M < env_int("UA2_GEMM2_MIN_ROWS", 256) || a.K % 32 != 0) return 1;
+  if (a.M < g_min_rows.get() || a.K % 32 != 0) return 1;
   const bool glu = a.epilogue == UA2_EPI_SWIGLU;
   if (a.N % (glu ? 32 : 64) != 0) return 1;
   if (a.bias && !aligned16(a.bias)) return 1;

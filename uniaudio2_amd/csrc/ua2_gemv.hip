@@ -359,6 +359,7 @@ void launch_one(const ua2_linear_args& a, dim3 grid, int waves, int a_stride, in
   constexpr auto kern = gemv_kernel<DT, PRO, EPI, CPW, MR>;
   ua2_allow_big_lds<kern>();
   hipLaunchKernelGGL(kern, grid, dim3(waves * 64), smem, s, a, a_stride, red_off, rt);
+  ua2_count_launch(UA2_CNT_GEMV);
 }
 
 template <int DT, int PRO, int EPI>

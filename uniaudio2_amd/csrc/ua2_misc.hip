@@ -2,6 +2,7 @@
 // greedy sampling tail + next-step embedding gather.  All are a few KB of traffic; what matters
 // is that each replaces a chain of 5-10 tiny PyTorch launches in the reference with one.
 #include <stdarg.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -17,6 +18,17 @@ void ua2_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ua2_last_error(void) { return g_err; }
 extern "C" int ua2_version(void) { return UA2_VERSION; }
+
+std::atomic<int64_t> g_ua2_launches[UA2_CNT_N];
+std::atomic<int> g_ua2_env_gen{0};
+extern "C" int64_t ua2_debug_kernel_launches(const char* family) {
+  static const char* const names[UA2_CNT_N] = {"gemm2", "gemm", "skinny2", "gemv"};
+  if (!family) return -1;
+  for (int i = 0; i < UA2_CNT_N; ++i)
+    if (!strcmp(family, names[i])) return g_ua2_launches[i].load(std::memory_order_relaxed);
+  return -1;
+}
+extern "C" void ua2_debug_refresh_env(void) { g_ua2_env_gen.fetch_add(1, std::memory_order_acq_rel); }
 
 extern "C" size_t ua2_struct_size(int which) {
   switch (which) {

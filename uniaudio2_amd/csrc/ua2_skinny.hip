@@ -230,6 +230,7 @@ int launch_one(const ua2_linear_args& a, int passes, hipStream_t s) {
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
   const dim3 grid(ua2_ceil_div(ntiles, CT), ua2_ceil_div(mtiles, MT * passes));
   hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), passes);
+  ua2_count_launch(UA2_CNT_SKINNY2);
   return 0;
 }
 

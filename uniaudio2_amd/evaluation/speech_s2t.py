@@ -16,9 +16,9 @@ class Generator(GeneratorBase):
         for key, tp in zip(keys, types):
             if tp != "text":
                 x = d[key].long()
-                if x.dim() == 2 and not (x.shape[0] == 8 and x.shape[1] != 8):
-                    x = x.transpose(0, 1)             # (T, 8) -> the (8, T) the shared builder transposes back (:291-293)
-                fixed[key] = x
+                if x.dim() == 2 and x.shape[0] == 8 and x.shape[1] != 8:
+                    x = x.transpose(0, 1)             # :291-293, verbatim: an (8, T != 8) input becomes (T, 8); an (8, 8) one is taken as (T, 8)
+                fixed[key] = x.transpose(0, 1)        # the shared builder takes (8, T) and transposes back
         return super().get_condition_seq(fixed, keys, types, task_prompt_data)
 
     @torch.inference_mode()

@@ -72,6 +72,7 @@ class Model_stage3(nn.Module):
         self._h = None
         self._st = None
         self.sampling_seed = None      # set by callers that key the sampler themselves (CLI: per-utterance keys)
+        self.order_free_rows = 0       # > 0: every plan setup_caches builds opts its many-row launches into the order-free GEMM (CLI --order_free_rows)
 
     # ---- caches / device plan ----------------------------------------------------------------
     def setup_caches(self, max_batch_size: int, dtype: Optional[torch.dtype] = None, max_seq_length: int = 2048,
@@ -134,6 +135,8 @@ class Model_stage3(nn.Module):
         self._sampling = None
         self._cfg = 1.0
         self._pos_hi = 0
+        if getattr(self, "order_free_rows", 0) > 0 and dtype == torch.bfloat16:
+            self.set_order_free_rows(self.order_free_rows)
 
     def _destroy(self):
         if self._h is not None:

@@ -108,6 +108,7 @@ def _load_config_and_llm(args):
     model = Model_stage3(config)
     resume_for_inference(args.resume, args.exp_dir, model, device)
     model.to(device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.order_free_rows = max(0, int(getattr(args, "order_free_rows", 0) or 0))     # applied by setup_caches (bf16 plans)
     return train_args, model, device
 
 
@@ -197,7 +198,7 @@ def run_understanding(args):
                 text_out = generator.generate_answer(task_prompt, task_name=task, d=d, keys=list(d), types=["text", "audio", "audio"],
                                                      temperature=args.temperature, topk=1, cfg_scale=args.cfg_scale)
             elif task == "speech_s2t":                                                             # :363-379: samples with --topk
-                d = {"reason_seq": reason.transpose(0, 1), "semantic_seq": semantic.transpose(0, 1)}
+                d = {"reason_seq": reason, "semantic_seq": semantic}                                # (T, 8) as the reference passes them (:368)
                 result = generator.generate_answer(task_prompt, task_name="speech_s2t", d=d, keys=["reason_seq", "semantic_seq"],
                                                    types=["audio", "audio"], temperature=args.temperature, topk=args.topk,
                                                    cfg_scale=args.cfg_scale)
@@ -337,11 +338,24 @@ def save_wav(path, wave, sample_rate):
     wavfile.write(path, int(sample_rate), np.round(x.T * 32767.0).astype(np.int16))
 
 
-def stage2_shard(names, world, rank):
-    """Utterances of stage 2 this rank decodes: names[rank::world] of the sorted list (SURVEY.md §8e: "codec stage 2 shards the
-    same way ... by utterance"; the reference loops over all of them on one GPU, multi_task_inference.py:540-548).  The outputs
-    are files, so the stage needs no collective: the union over ranks is every name, the shards are disjoint."""
-    return list(names[rank::max(1, world)])
+def stage2_shard(names, world, rank, lengths=None):
+    """Utterances of stage 2 this rank decodes ("codec stage 2 shards the same way ... by utterance"; the reference
+    loops over all of them on one GPU, multi_task_inference.py:540-548).  With `lengths` (semantic frames per utterance) the split is
+    stage 1's — longest first, dealt round-robin (parallel.shard_indices) — so every rank gets the same mix of 1-, 2- and 3-window
+    utterances and a rank's list comes back longest first: consecutive --codec_batch groups then hold utterances with the same
+    window count and do not shrink window by window.  Without lengths: names[rank::world] of the sorted list.  The outputs are
+    files, so the stage needs no collective: the union over ranks is every name, the shards are disjoint."""
+    if lengths is None:
+        return list(names[rank::max(1, world)])
+    from . import parallel
+    return [names[i] for i in parallel.shard_indices(list(lengths), max(1, world), rank)]
+
+
+def _semantic_frames(path):
+    """T of a `{name}_semantic.pt` (8, T) file; 0 when it is missing (the utterance is then skipped with a message)."""
+    if not os.path.isfile(path):
+        return 0
+    return int(torch.load(path, map_location="cpu").shape[-1])
 
 
 def run_generation_stage2(args):
@@ -365,8 +379,9 @@ def decode_token_dir(codec, args, device):
     wav_dir = args.wav_dir or os.path.join(token_dir, "wavs")
     os.makedirs(wav_dir, exist_ok=True)
     world, grank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    frames = [_semantic_frames(os.path.join(token_dir, f"{n}_semantic.pt")) for n in names]       # every rank reads the same few bytes
     mine = []
-    for name in stage2_shard(names, world, grank):
+    for name in stage2_shard(names, world, grank, lengths=frames):
         sp = os.path.join(token_dir, f"{name}_semantic.pt")
         if not os.path.isfile(sp):
             print(f"[Skip] {name}: missing {sp}")
@@ -409,8 +424,15 @@ def get_parser():
     p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="kernel precision (extension; the reference runs fp32)")
     p.add_argument("--save_safetensors", action="store_true",
                    help="also write {name}_tokens.safetensors next to the reference's two .pt files (extension)")
-    p.add_argument("--codec_batch", type=int, default=8,
-                   help="utterances whose k-th windows share one DiT solve / SQ-Codec decode in stage 2 (extension; 1 = one by one as the reference)")
+    p.add_argument("--codec_batch", type=int, default=1,
+                   help="utterances whose k-th windows share one DiT solve / SQ-Codec decode in stage 2 (extension; default 1 = one by one as "
+                        "the reference: a waveform then never depends on which other files are in the directory, on WORLD_SIZE or on this "
+                        "flag.  8 halves the time per window; under the DiT's default order-free GEMM plan a waveform then differs from its "
+                        "one-by-one value by bf16 rounding noise (~3e-3 relative rms); UA2_DIT_SUM_ORDER=0 keeps the bits at any batch)")
+    p.add_argument("--order_free_rows", type=int, default=0,
+                   help="stage 1, bf16 (extension): LM launches of at least this many rows (batched prefill, decode frames of that many "
+                        "sequences) take the order-free 256-row-tile GEMM — faster, but a sequence's ids may then depend on what shares "
+                        "its batch.  Default 0 = off: every row keeps the bits of its single-sequence run")
     p.add_argument("--batch_size", type=int, default=1,
                    help="utterances decoded together per GPU (extension; TTS / Yue_TTS with --text_file; 1 = one by one as the reference)")
     return p

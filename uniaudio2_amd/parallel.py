@@ -102,7 +102,10 @@ def gather_results(results: Dict[int, Tuple[torch.Tensor, torch.Tensor]], n_tota
     """All ranks end up with every utterance's (reason, semantic) tensors, keyed by global index.  `fatal`: this rank hit a
     non-utterance error (device fault, ua2_* status, a bug) while working on its shard — it still enters the collective (the
     peers would otherwise wait in it until the backend's time-out) and EVERY rank raises after it."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # No process group (a plain `python` run): nothing to exchange.  WITH a process group the collective runs at every world size,
+    # one rank included — `torchrun --nproc-per-node 1` then takes exactly the pack -> device -> all-gather -> parse path of an
+    # 8-rank job (a few tens of microseconds), so the one-GPU box exercises the product's RCCL exchange, not a short-cut around it.
+    if not (dist.is_available() and dist.is_initialized()):
         if fatal:
             raise RuntimeError(fatal)
         return dict(results)

@@ -60,7 +60,7 @@ class BASECFM(nn.Module):
         super().__init__()
         self.sigma_min = 1e-4
         self.estimator = estimator
-        self._graphs, self._pool = {}, None
+        self._graphs, self._pool, self._graphs_gen = {}, None, None
 
     def _euler_steps(self, x, noise, inc, n, ts, mu, guidance_scale, est):
         """The guided Euler loop proper (:99-127) for P utterances at once: rows [0, P) of the estimator batch are the
@@ -108,9 +108,15 @@ class BASECFM(nn.Module):
             est = estimator or (lambda inp, t: self.estimator(inp, t))
             return self._euler_steps(x, x.clone(), inc, n, ts, mu, guidance_scale, est)
         key = (tuple(x.shape), tuple(mu.shape), n, tuple(ts), float(guidance_scale))
-        g = self._graphs.get(key)
+        dit = self.estimator
+        if not getattr(dit, "_ready", True):
+            dit.prepare()
+        gen = getattr(dit, "_plan_gen", 0)
+        if gen != self._graphs_gen:                                       # the DiT was re-prepared (dtype, UA2_DIT_SUM_ORDER): every recording
+            self._graphs.clear()                                          # points at weights / K-V plans / embeddings that no longer exist
+            self._graphs_gen = gen
+        g = self._graphs.pop(key, None)                                   # re-inserted below: the dict's order is the LRU order
         if g is None:
-            dit = self.estimator
             P, T, _ = x.shape
             dev = x.device
             dit.ensure_plan(2 * P, T, dev)
@@ -130,8 +136,9 @@ class BASECFM(nn.Module):
             if self._pool is None:
                 self._pool = graph.pool()                                 # one memory pool for every recorded shape
             while len(self._graphs) >= 18:                                # P = 1 .. codec_batch utterances x {first, later} windows; one shared pool
-                self._graphs.pop(next(iter(self._graphs)))
-            g = self._graphs[key] = (graph, x_in, inc_in, mu_in, y)
+                self._graphs.pop(next(iter(self._graphs)))                # least recently used first
+            g = (graph, x_in, inc_in, mu_in, y)
+        self._graphs[key] = g
         graph, x_in, inc_in, mu_in, y = g
         x_in.copy_(x); inc_in.copy_(inc); mu_in.copy_(mu)
         graph.replay()

@@ -242,6 +242,9 @@ class Transformer1DModel(nn.Module):
         self._pe = pe.to(dev).contiguous()
         self._table = self.scale_shift_table.detach().float().contiguous().view(-1)
         self._dtype, self._ready, self._kv, self._kvs, self._graphs, self._emb_cache = dtype, True, None, {}, {}, {}
+        # recordings made elsewhere over this plan (BASECFM.solve_euler's whole-solve graphs) hold raw pointers to the packed weights,
+        # K/V plans and step embeddings replaced above: they compare this counter and drop themselves
+        self._plan_gen = getattr(self, "_plan_gen", 0) + 1
         return self
 
     def _forward_impl(self, hidden_states, emb):
