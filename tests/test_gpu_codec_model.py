@@ -177,8 +177,9 @@ def test_dit_order_free_plan_vs_oracle_at_640_rows(bmt, monkeypatch):
     finally:
         monkeypatch.delenv("UA2_GEMM2_BMT")
         lib.ua2_debug_refresh_env()
-    # every GEMM of the two blocks (q|k|v, to_out, ff.net.0, ff.net.2) and the Linear of both ProjectLayers reaches the kernel
-    assert n_free >= 4 * c["layers"] + 2, n_free
+    # every GEMM of the two blocks (q|k|v, to_out, ff.net.0, ff.net.2) and proj_in's Linear reach the kernel (the conv taps have
+    # K = 304, not a multiple of 32, and proj_out has 24 columns: those stay on ua2_gemm.hip)
+    assert n_free >= 4 * c["layers"] + 1, n_free
     assert n_inv == 0, n_inv
     e_free, e_inv = rel(free), rel(inv)
     print(f"DiT bf16 at 2 x {T} rows, {16 * bmt}-row tiles: order-free plan vs fp32 oracle {e_free:.3e} ({n_free} gemm2 launches), "

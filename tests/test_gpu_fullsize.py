@@ -205,7 +205,9 @@ def test_fullsize_fp32_greedy_ids_match_oracle(full_model, oracle_runs):
 def test_fullsize_order_free_prefill_of_256_rows_vs_bf16_oracle(full_model):
     """VERDICT r5 #2b: the OPT-IN order-free plan of the LM (`set_order_free_rows`, CLI --order_free_rows) against the ORACLE, not
     against another HIP kernel: a 257-token prompt is prefilled as ONE 256-row chunk with every eligible trunk launch on
-    csrc/ua2_gemm2.hip (launch counter), then frame 0's text and first-codebook logits are held to the bf16 oracle with the bars of
+    csrc/ua2_gemm2.hip (launch counter; UA2_GEMM2_BMT=8 pins the 128-row tile so that q|k|v with the half-split RoPE and the cache
+    write, the o-projection, the SwiGLU pair and the down-projection ALL take it — the launcher's own cost rule would send the
+    narrower ones back to ua2_gemm.hip at 256 rows), then frame 0's text and first-codebook logits are held to the bf16 oracle with the bars of
     test_fullsize_bf16_frame0_and_properties (rms below 0.75 x the oracle's own bf16-vs-fp32 distance, absolute caps), and the
     row-invariant plan on the same prompt gives the A/B."""
     from oracle.lm_oracle import GPTShape, Stage3Oracle, run_decode_loop
@@ -229,7 +231,14 @@ def test_fullsize_order_free_prefill_of_256_rows_vs_bf16_oracle(full_model):
         del o
     tk, mk = tokens.to(dev), mask.to(dev)
 
+    import os
+
     def frame0(order_free_rows):
+        if order_free_rows:
+            os.environ["UA2_GEMM2_BMT"] = "8"
+        else:
+            os.environ.pop("UA2_GEMM2_BMT", None)
+        lib.ua2_debug_refresh_env()
         m.setup_caches(1, dtype=torch.bfloat16, max_seq_length=512, max_rows=256, log_frames=16)
         m.set_order_free_rows(order_free_rows)
         n0 = lib.ua2_debug_kernel_launches(b"gemm2")
@@ -244,8 +253,10 @@ def test_fullsize_order_free_prefill_of_256_rows_vs_bf16_oracle(full_model):
         ft, fa, n_free = frame0(256)
         it, ia, n_inv = frame0(0)
     finally:
+        os.environ.pop("UA2_GEMM2_BMT", None)
+        lib.ua2_debug_refresh_env()
         m.setup_caches(2, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=64)
-    assert n_inv == 0 and n_free >= 33 * 2, (n_free, n_inv)     # at least q|k|v and the SwiGLU pair of every trunk layer
+    assert n_inv == 0 and n_free == 33 * 4, (n_free, n_inv)     # q|k|v, o, SwiGLU pair, down of every trunk layer
     ob, of = runs["bf16"], runs["fp32"]
     for name, gf, gi, o, f in (("text", ft, it, ob["text_logits"][0][0].numpy(), of["text_logits"][0][0].numpy()),
                                ("audio0", fa, ia, ob["audio_logits"][0][0, 0].numpy(), of["audio_logits"][0][0, 0].numpy())):
@@ -254,3 +265,51 @@ def test_fullsize_order_free_prefill_of_256_rows_vs_bf16_oracle(full_model):
               "oracle bf16-vs-fp32 rms %.3e max %.3e (%d gemm2 launches)" % (name, _rms(d), np.abs(d).max(), _rms(di), np.abs(di).max(), _rms(q), np.abs(q).max(), n_free))
         assert _rms(d) < 0.75 * _rms(q), name
         assert _rms(d) < 4e-2 and np.abs(d).max() < 0.3, name
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 7])
+def test_lm_head_riding_on_the_down_projections_gives_identical_bits(full_model, B):
+    """lm_head (model_new.py:617) leaves the frame's critical path without being skipped — its column tiles travel
+    on the idle CUs of the depth decoder's 32 down-projection launches (csrc/ua2_gemv.hip gemv_rider_kernel; up to 6 rows, the
+    down-projection's row tile).  Against the plan with lm_head as its own launch (UA2_NO_RIDER=1): identical text logits (all
+    128 256 of them), identical (text, audio) ids over 4 frames, one GEMV launch less per frame.  B = 7 is past the row tile:
+    both plans are the same there."""
+    import os
+    from uniaudio2_amd._lib import lib
+    m, bench = full_model
+    dev = torch.device("cuda")
+    prompts = [bench.make_prompt(dev, seed=900 + b) for b in range(B)]
+    tokens, mask = torch.cat([t for t, _ in prompts]), torch.cat([k for _, k in prompts])
+    L = tokens.size(1)
+
+    def run(no_rider):
+        if no_rider:
+            os.environ["UA2_NO_RIDER"] = "1"
+        else:
+            os.environ.pop("UA2_NO_RIDER", None)
+        lib.ua2_debug_refresh_env()
+        m.setup_caches(max(B, 2), dtype=torch.bfloat16, max_seq_length=256, max_rows=64, log_frames=16)
+        m.reset_caches()
+        pos = torch.arange(L, device=dev).unsqueeze(0).repeat(B, 1)
+        m.forward_prefix(tokens[:, :-1], tokens_mask=mask, input_pos=pos[:, :-1])
+        m.begin_decode(tokens[:, -1:], mask[:, -1:], torch.tensor([L - 1], device=dev))
+        torch.cuda.synchronize()
+        n0 = lib.ua2_debug_kernel_launches(b"gemv")
+        log = m.generate_frames(1, B, 0, reason_eos=-1, reason_card=bench.REASON_CARD, use_graph=False).clone()
+        torch.cuda.synchronize()
+        n = lib.ua2_debug_kernel_launches(b"gemv") - n0
+        logits = m.buffer("text_logits", B).clone()
+        log = torch.cat([log, m.generate_frames(3, B, 0, reason_eos=-1, reason_card=bench.REASON_CARD).clone()])
+        return log.cpu(), logits.cpu(), n
+
+    try:
+        log_r, logit_r, n_r = run(False)
+        log_n, logit_n, n_n = run(True)
+    finally:
+        os.environ.pop("UA2_NO_RIDER", None)
+        lib.ua2_debug_refresh_env()
+        m.setup_caches(2, dtype=torch.bfloat16, max_seq_length=2048, max_rows=64, log_frames=64)
+    assert torch.equal(logit_r, logit_n), float((logit_r - logit_n).abs().max())
+    assert torch.equal(log_r, log_n)
+    assert (log_r[:, :, 0] >= 0).all()                       # the text ids are real ids (computed, not skipped)
+    assert n_n - n_r == (1 if B <= 6 else 0), (n_r, n_n)       # lm_head's own launch is gone up to the down-projection's row tile

@@ -192,3 +192,6 @@ extern "C" int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, co
                            int32_t* part_idx, int32_t pairs, void* stream);
 // decode-regime specialisation; returns 1 when the problem is outside its regime
 int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s);
+// riders (ua2_gemv.hip gemv_rider_kernel): column tiles [tile0, tile1) of the one-row-tile GEMV `r` on the idle CUs of host launch `a`
+bool ua2_gemv_rider_ok(const ua2_linear_args& a, const ua2_linear_args& r);
+int ua2_gemv_launch_with_rider(const ua2_linear_args& a, const ua2_linear_args& r, int tile0, int tile1, hipStream_t s);

@@ -14,6 +14,8 @@
 //     waves x CPW tiles K exactly for the model's shapes: no tail, no predicated loads.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ua2_common.h"
 #include "ua2_linear_common.h"
 #include "ua2_attn_local.h"
@@ -50,11 +52,10 @@ __device__ __forceinline__ void local_attn_prologue(const ua2_linear_args& a, ch
 // MR = multi-round: <= 8 waves per workgroup, several rounds of CPW chunks per wave, next round's
 // weights prefetched (double buffer); !MR = single burst: up to 16 waves, everything up front.
 template <int DT, int PRO, int EPI, int CPW, bool MR>
-__global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
-                                                              const int red_off, const int rt) {
+__device__ __forceinline__ void gemv_body(const ua2_linear_args& a, char* smem, const int a_stride, const int red_off, const int rt,
+                                          const int bx, const int by) {
   constexpr int KC = Elem<DT>::KC, EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* a_lds = smem;                                        // [rows][a_stride] of T
   float* red = reinterpret_cast<float*>(smem + red_off);     // [nw][NT][256]
   float* ssq = red + kMaxWaves * NT * 256;                   // [nw][16]
@@ -65,18 +66,18 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nw = nthreads >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.y * rt;            // rt rows per workgroup: a function of K and dtype only
+  const int m0 = by * rt;                    // rt rows per workgroup: a function of K and dtype only
   const int rows = min(rt, a.M - m0);
 
   const int nchunks = (a.K + KC - 1) / KC;
   int tile[NT];
   const u32x4* wp[NT];
   if constexpr (EPI == UA2_EPI_SWIGLU) {
-    tile[0] = tile[1] = blockIdx.x;
+    tile[0] = tile[1] = bx;
     wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
     wp[1] = reinterpret_cast<const u32x4*>(a.w1) + (size_t)tile[0] * nchunks * 64 + lane;
   } else {
-    tile[0] = blockIdx.x;
+    tile[0] = bx;
     wp[0] = reinterpret_cast<const u32x4*>(a.w0) + (size_t)tile[0] * nchunks * 64 + lane;
   }
   // chunk range of this wave; rounds of CPW chunks (exactly one round for the model's shapes)
@@ -303,6 +304,96 @@ __global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const u
   linear_epilogue<DT, EPI, NT>(a, v, tile, row, col, pre, m0, rows);
 }
 
+template <int DT, int PRO, int EPI, int CPW, bool MR>
+__global__ __launch_bounds__(MR ? 512 : kMaxWaves * 64) void gemv_kernel(const ua2_linear_args a, const int a_stride,
+                                                              const int red_off, const int rt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemv_body<DT, PRO, EPI, CPW, MR>(a, smem, a_stride, red_off, rt, blockIdx.x, blockIdx.y);
+}
+
+// ---- riders: a second, independent one-row-tile GEMV carried by the idle CUs of a launch that cannot fill the device -----------
+// Why.  A CU takes in at most ~31 GB/s of an HBM stream (~64 KB in flight per CU: profiles/r6_notes.md), so a launch with fewer
+// workgroups than CUs is capped below the HBM rate by the CUs it does not use: the depth decoder's down-projection (K = 8192 ->
+// N = 2048: 128 workgroups of 262 KB) streams 33.5 MB in 10.6 us = 3.2 TB/s with half the device idle, 32 times per frame.
+// lm_head (model_new.py:617: 788 MB, 114 us on its own) depends only on the trunk's output, not on the depth decoder
+// (:629-640), and a forked graph branch replays 0.4 ms per frame SLOWER on ROCm 7.2 (measured in rounds 1 and 6).  So its column
+// tiles ride along: workgroups past the host's grid each take TWO rider tiles (waves 0-7 and 8-15: the rider's eight K ranges
+// each, the operand row staged once), and one slice of lm_head goes with every down-projection launch of the frame.
+// Same bits as the rider's own launch (gemv_kernel<bf16, CAST, STORE, 4, MR>): the bf16 operand row, per range one MFMA chain
+// over its CPWR chunks in order, the eight partial sums added in range order from zero, linear_epilogue.
+template <int CPWR>
+__device__ __forceinline__ void rider_body(const ua2_linear_args& a, char* smem, const int tile0, const int tile1, const int rid) {
+  constexpr int DT = UA2_BF16, KC = 32, NWR = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = wave >> 3, wv = wave & 7;
+  const int i = lane & 15, g = lane >> 4;
+  const int rows = a.M;                                      // one row tile (the launcher checks)
+  constexpr int nchunks = NWR * CPWR;                        // == K / 32 (the launcher checks)
+  constexpr int a_stride = nchunks * KC + 8;
+  char* a_lds = smem;
+  float* red = reinterpret_cast<float*>(smem + (((size_t)rows * a_stride * 2 + 255) & ~(size_t)255));     // [2][NWR][256]
+  const int tile = tile0 + 2 * rid + half;
+  const bool live = tile < tile1;                            // wave-uniform
+  const int tl = min(tile, tile1 - 1);
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.w0) + ((size_t)tl * nchunks + wv * CPWR) * 64 + lane;
+  const int et = tid & 511;                                  // epilogue thread of this half: (row, col) = (et >> 4, et & 15)
+  // small loads first (a wave's loads return in order): the single-row operand piece, the epilogue's row data
+  const bool one = rows == 1 && a.K <= 4 * kMaxWaves * 64;
+  float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (one && tid * 4 < a.K) xv = *reinterpret_cast<const float4*>(a.x + tid * 4);
+  EpiPre pre;
+  if (et < 256) epilogue_prefetch_a<DT, UA2_EPI_STORE>(a, tl, et >> 4, et & 15, pre, 0);
+  u32x4 wf[CPWR];
+#pragma unroll
+  for (int u = 0; u < CPWR; ++u) wf[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+  if (et < 256) epilogue_prefetch_b<DT, UA2_EPI_STORE>(a, tl, et >> 4, et & 15, pre, 0);
+  auto put = [&](int r0, int k, const float4& t) {
+    uint2 p;
+    p.x = (unsigned)f2bf(t.x) | ((unsigned)f2bf(t.y) << 16);
+    p.y = (unsigned)f2bf(t.z) | ((unsigned)f2bf(t.w) << 16);
+    *reinterpret_cast<uint2*>(a_lds + ((size_t)r0 * a_stride + k) * 2) = p;
+  };
+  if (one) {
+    if (tid * 4 < a.K) put(0, tid * 4, xv);
+  } else {
+    for (int r0 = 0; r0 < rows; ++r0)
+      for (int k = tid * 4; k < a.K; k += kMaxWaves * 64 * 4) put(r0, k, *reinterpret_cast<const float4*>(a.x + (size_t)r0 * a.ldx + k));
+  }
+  __syncthreads();
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool arow = i < rows;
+  const char* abase = a_lds + ((size_t)i * a_stride + g * 8) * 2 + (size_t)(wv * CPWR) * KC * 2;
+#pragma unroll
+  for (int u = 0; u < CPWR; ++u) {
+    AFrag<DT> af;
+    u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+    if (arow) raw = *reinterpret_cast<const u32x4*>(abase + (size_t)u * KC * 2);
+    af.v = raw;
+    af.mma(wf[u], acc);
+  }
+  *reinterpret_cast<f32x4*>(&red[((half * NWR + wv) * 256) + lane * 4]) = acc;
+  __syncthreads();
+  if (et >= 256 || !live) return;
+  const int row = et >> 4, col = et & 15;
+  const int src = (((row >> 2) << 4) + col) * 4 + (row & 3);
+  float v[1];
+  {
+    float sacc = 0.f;
+    for (int w = 0; w < NWR; ++w) sacc += red[(half * NWR + w) * 256 + src];
+    v[0] = sacc;
+  }
+  const int tl1[1] = {tile};
+  linear_epilogue<DT, UA2_EPI_STORE, 1>(a, v, tl1, row, col, pre, 0, rows);
+}
+
+// host = a single-burst 16-wave bf16 instantiation of gemv_body (one row tile); workgroups >= host_gx are riders
+template <int PRO, int EPI, int CPW, int CPWR>
+__global__ __launch_bounds__(kMaxWaves * 64) void gemv_rider_kernel(const ua2_linear_args a, const int a_stride, const int red_off, const int rt,
+                                                                    const ua2_linear_args ra, const int tile0, const int tile1, const int host_gx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < host_gx) gemv_body<UA2_BF16, PRO, EPI, CPW, false>(a, smem, a_stride, red_off, rt, blockIdx.x, 0);
+  else rider_body<CPWR>(ra, smem, tile0, tile1, (int)blockIdx.x - host_gx);
+}
+
 constexpr size_t kLdsABudget = 112 * 1024;   // activation tile budget (of 160 KiB; the rest holds the reduction buffers)
 
 }  // namespace
@@ -424,6 +515,61 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---- riders (see gemv_rider_kernel) ------------------------------------------------------------------------------------------
+namespace {
+// host forms with a rider instantiation: (prologue, epilogue, chunks per wave) of a 16-wave single-burst launch.  Only the
+// down-projection (K = 8192, 10.6 us: longer than a rider workgroup's own ~8 us) carries riders: on the 6-us launches (q|k|v and
+// o-projection of the depth decoder: forms measured in round 6, profiles/r6_notes.md) a rider workgroup outlasts its host and the
+// frame got SLOWER (3.18 against 3.11 ms).
+int rider_host_form(const ua2_linear_args& a, const Geometry& geo) {
+  if (geo.waves != 16) return -1;
+  if (a.prologue == UA2_PRO_CAST && a.epilogue == UA2_EPI_RESIDUAL && geo.cpw == 16) return 0;
+  return -1;
+}
+}  // namespace
+
+// Can launches of `a`'s shape (the host) carry column tiles of `r` (the rider)?  A function of the two problems only, so a plan
+// decides once.  Host: a bf16 launch of one row tile in a single-burst 16-wave geometry (rider_host_form) whose grid leaves CUs
+// idle.  Rider: bf16 CAST / STORE (+ arg-max partials), no bias / hand-over, the 8-range x 12-chunk geometry its own launch would
+// take (K = 3072), the same rows.
+bool ua2_gemv_rider_ok(const ua2_linear_args& a, const ua2_linear_args& r) {
+  static Ua2EnvInt off{"UA2_NO_RIDER", 0};
+  if (off.set()) return false;
+  if (a.dtype != UA2_BF16 || a.K % 32 || a.x_packed) return false;
+  const int nch = a.K / 32, gx = ua2_ceil_div(a.N, 16);
+  const Geometry geo = pick_geometry(nch, gx, 1);
+  if (geo.waves * geo.cpw != nch || gx >= 256 || rider_host_form(a, geo) < 0) return false;
+  if (a.M > rows_per_tile(a.dtype, a.K) || r.M != a.M) return false;
+  if (r.dtype != UA2_BF16 || r.prologue != UA2_PRO_CAST || r.epilogue != UA2_EPI_STORE || r.K != 3072 || !r.x || r.ldx % 4) return false;
+  if (r.bias || r.y_norm_w || r.x_packed || r.M > rows_per_tile(r.dtype, r.K)) return false;
+  const Geometry rg = pick_geometry(r.K / 32, ua2_ceil_div(r.N, 16), 1);
+  return rg.waves == 8 && rg.waves * 12 == r.K / 32;       // what the rider's own launch sums like (8 ranges of 12 chunks)
+}
+
+// The host launch with rider tiles [tile0, tile1) of `r` on workgroups past its grid.  0 = launched, 1 = not applicable.
+int ua2_gemv_launch_with_rider(const ua2_linear_args& a, const ua2_linear_args& r, int tile0, int tile1, hipStream_t s) {
+  if (!ua2_gemv_rider_ok(a, r)) return 1;
+  const int nchunks = a.K / 32, gx = ua2_ceil_div(a.N, 16);
+  const int form = rider_host_form(a, pick_geometry(nchunks, gx, 1));
+  const int a_stride = nchunks * 32 + 8;
+  const int red_off = (int)(((size_t)a.M * a_stride * 2 + 255) & ~(size_t)255);
+  const size_t host_smem = (size_t)red_off + (size_t)(kMaxWaves * 256 + 2 * kMaxWaves * 16 + 32) * sizeof(float);
+  const size_t rider_smem = (((size_t)r.M * (r.K + 8) * 2 + 255) & ~(size_t)255) + (size_t)2 * 8 * 256 * sizeof(float);
+  const size_t smem = std::max(host_smem, rider_smem);
+  const int riders = tile1 > tile0 ? ua2_ceil_div(tile1 - tile0, 2) : 0;
+  const int rt = rows_per_tile(a.dtype, a.K);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(gx + riders, 1), dim3(kMaxWaves * 64), smem, s, a, a_stride, red_off, rt, r, tile0, tile1, gx);
+  };
+#define UA2_RIDER(PRO_, EPI_, CPW_) { constexpr auto kern = gemv_rider_kernel<PRO_, EPI_, CPW_, 12>; ua2_allow_big_lds<kern>(); go(kern); }
+  if (form != 0) return 1;
+  UA2_RIDER(UA2_PRO_CAST, UA2_EPI_RESIDUAL, 16)
+#undef UA2_RIDER
+  ua2_count_launch(UA2_CNT_GEMV);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
 
 ua2_gemv_geometry ua2_pick_gemv_geometry(int dtype, int N, int K, int nt) {
   const int kc = dtype == UA2_BF16 ? 32 : 16;

@@ -38,11 +38,7 @@ struct ua2_stage3 {
   int32_t npart_t, npart_a;
   int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
   float temperature = 1.f;
-  hipStream_t cap_stream = nullptr;
-  // optional (UA2_FORK_LM_HEAD=1): lm_head + text arg-max on a side stream, concurrent with the 8-step
-  // local decoder (they only share read-only inputs)
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // capture-only stream (the caller's may be the null stream, which cannot capture)
+  hipStream_t cap_stream = nullptr;                 // capture-only stream (the caller's may be the null stream, which cannot capture)
   float cfg_scale = 1.f;       // > 1: classifier-free guidance over a (conditional, unconditional) row pair
   int32_t order_free_rows = 0; // > 0 (bf16 plans): GPT launches (trunk and depth decoder) of at least this many rows take UA2_SUM_ORDER_FREE (ua2_stage3_set_order_free_rows)
   // row groups of the next ua2_stage3_trunk call (prefill): the trunk's attention then runs the MFMA flash kernel
@@ -117,12 +113,44 @@ struct Handover {
   }
 };
 
+bool no_local_fuse() {
+  static const bool v = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
+  return v;
+}
+
+// A one-row-tile GEMV (lm_head) whose column tiles travel on the idle CUs of a GPT's small launches (ua2_gemv.hip gemv_rider_kernel).
+// Host kinds: 0 = q|k|v, 1 = o-projection, 2 = down-projection.  Tiles are dealt in launch order in proportion to a weight per
+// kind, the last carrying launch takes whatever is left: every tile is computed exactly once per frame whatever the weights.
+struct RiderPlan {
+  ua2_linear_args r;
+  int ntiles = 0, next = 0;
+  double w[3] = {0, 0, 0}, wleft = 0;
+  bool ok[3] = {false, false, false};
+  void take(int kind, int& t0, int& t1) {
+    const int left = ntiles - next;
+    int n = (wleft <= w[kind] * 1.0001) ? left : (int)(left * (w[kind] / wleft) + 0.5);
+    n = std::max(0, std::min(n, left));
+    t0 = next; t1 = next + n; next = t1; wleft -= w[kind];
+  }
+};
+
 // final_norm_w: weight of the RMSNorm + Linear that consumes this GPT's OUTPUT through UA2_PRO_SCALED (the depth decoder's
 // ln_f in front of audio_head), or NULL (the trunk GPTs end in ua2_rmsnorm_blend, which reads the fp32 stream).
 // With h->scaled the caller has already handed over x for layer 0 (embed_frame / rmsnorm_blend / the projection's epilogue).
+// rp: the launches of this GPT that can (RiderPlan::ok) carry their share of the rider's column tiles.
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
             const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false, const float* final_norm_w = nullptr,
-            bool scaled = false) {
+            bool scaled = false, RiderPlan* rp = nullptr) {
+  auto launch = [&](const ua2_linear_args& a, int kind) -> int {
+    if (rp && rp->ok[kind]) {
+      int t0, t1;
+      rp->take(kind, t0, t1);
+      const int rc = ua2_gemv_launch_with_rider(a, rp->r, t0, t1, s);
+      UA2_CHECK(rc <= 0, "ua2_stage3: launch kind %d cannot carry its rider (plan / launch mismatch)", kind);
+      return rc;
+    }
+    return ua2_linear_launch(a, s);
+  };
   const int dt = h->d.dtype;
   const int C = g.n_embd, qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
   const Handover ho(h, R, C);
@@ -142,10 +170,9 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
     if (scaled) ho.consume(a);
     a.sum_order = order;
-    if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (int rc = launch(a, 0)) return rc;
 
-    static const bool no_fuse = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
-    const bool fuse_attn = local && R == 1 && !no_fuse;
+    const bool fuse_attn = local && R == 1 && !no_local_fuse();
     // more than one row tile: the consumer runs a many-row kernel, so its producer writes the packed operand
     // directly and the consumer's prep launch disappears (same bits: the same RNE cast either way)
     static const bool no_handover = getenv("UA2_NO_PACKED_HANDOVER") != nullptr;   // A/B hook
@@ -171,7 +198,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     if (pack_o && !fuse_attn) a.x_packed = h->gemm_ws;
     if (scaled) ho.produce(a, h->norms[gi][1][l]);              // x after attention -> norm_2 + fc_1 / fc_2
     a.sum_order = order;
-    if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (int rc = launch(a, 1)) return rc;
 
     fresh_args(h, a);
     a.dtype = dt; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_SWIGLU;
@@ -189,7 +216,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     if (pack_act) a.x_packed = h->act_ws;
     if (scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
     a.sum_order = order;
-    if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (int rc = launch(a, 2)) return rc;
   }
   return 0;
 }
@@ -278,9 +305,6 @@ extern "C" void ua2_stage3_destroy(ua2_stage3* h) {
   if (!h) return;
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
 }
 
@@ -380,38 +404,54 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
   a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
   a.M = R; a.N = d.vt; a.K = C; a.x = h->hfin; a.ldx = C; a.w0 = d.lm_head; a.y = h->text_logits; a.ldy = d.vt;
   a.part_max = h->pmax_t; a.part_idx = h->pidx_t;
-  if (!h->side_stream) {
-    UA2_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    UA2_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    UA2_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  }
-  // measured (profiles/r1_notes.md): the forked graph replays 0.4 ms/frame SLOWER than the linear
-  // chain on ROCm 7.2 (3.60 vs 3.21 ms), so the fork is opt-in for experiments only
-  static const bool no_fork = getenv("UA2_FORK_LM_HEAD") == nullptr;
-  hipStream_t side = no_fork ? s : h->side_stream;
-  if (!no_fork) {
-    UA2_HIP(hipEventRecord(h->ev_fork, s));
-    UA2_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
-  }
   UA2_CHECK(!(skip_text && text_only), "ua2_stage3_heads: nothing left to compute");
-  if (!skip_text)
-    if (int rc = ua2_linear_launch(a, side)) return rc;
+  // lm_head does not feed the depth decoder (model_new.py:617 vs :629-640).  A forked graph branch for it replays 0.4 ms per frame
+  // SLOWER than the linear chain on ROCm 7.2 (3.49 vs 3.09 ms, re-measured in round 6), so it stays in the chain — but not as a
+  // launch of its own when the depth decoder's down-projections can carry it: each of their n_cb x n_layer launches fills half the
+  // device (128 workgroups: the per-CU ingest cap, ua2_gemv.hip) and takes one slice of lm_head's column tiles on the other half.
+  // Same bits as lm_head's own launch; the text sample moves behind the depth decoder (nothing in between reads it).
+  const ua2_linear_args lm = a;
+  RiderPlan rp;
+  bool ride = false;
+  if (!skip_text && !text_only && d.n_cb > 0 && d.decoder.n_layer > 0) {
+    const ua2_gpt_desc& g = d.decoder;
+    const int qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
+    ua2_linear_args hs[3];
+    for (auto& v : hs) { fresh_args(h, v); v.dtype = d.dtype; v.M = R; v.x = h->act; }
+    hs[0].prologue = h->scaled ? UA2_PRO_SCALED : UA2_PRO_NORM; hs[0].epilogue = UA2_EPI_QKV_ROPE; hs[0].N = nqkv; hs[0].K = Cd;
+    hs[1].prologue = (R == 1 && d.n_cb <= 8 && !no_local_fuse()) ? UA2_PRO_LOCAL_ATTN : UA2_PRO_CAST; hs[1].epilogue = UA2_EPI_RESIDUAL; hs[1].N = Cd; hs[1].K = qn;
+    hs[2].prologue = UA2_PRO_CAST; hs[2].epilogue = UA2_EPI_RESIDUAL; hs[2].N = Cd; hs[2].K = g.inter;
+    const double wk[3] = {0.0, 0.0, 1.0};    // the down-projections only: riders on the 6-us q|k|v / o launches made the frame slower (profiles/r6_notes.md)
+    rp.r = lm; rp.ntiles = (lm.N + 15) / 16;
+#ifdef UA2_RIDER_EXPERIMENTS
+    static Ua2EnvInt frac{"UA2_RIDER_TIMING_PCT", 100};   // timing only (wrong text ids): only this share of lm_head's tiles is computed at all
+    rp.ntiles = (int)((long)rp.ntiles * frac.get() / 100);
+#endif
+    for (int k = 0; k < 3; ++k) {
+      rp.ok[k] = wk[k] > 0 && ua2_gemv_rider_ok(hs[k], lm);
+      rp.w[k] = rp.ok[k] ? wk[k] : 0.0;
+      rp.wleft += rp.w[k] * d.n_cb * g.n_layer;
+      ride = ride || rp.ok[k];
+    }
+  }
+  if (!skip_text && !ride)
+    if (int rc = ua2_linear_launch(lm, s)) return rc;
   // model_new.py:618-622: with guidance the sampler sees l[1] + (l[0] - l[1]) * cfg_scale and both rows take its sample
   const bool cfg = h->cfg_scale > 1.f && R > 1;
   UA2_CHECK(!cfg || R % 2 == 0, "ua2_stage3_heads: classifier-free guidance needs (conditional, unconditional) row pairs, R=%d", R);
   const int key_shift = cfg ? 1 : 0;                       // the two rows of a pair hold the same guided logits and draw the same numbers
-  if (cfg && !skip_text)
-    if (int rc = ua2_cfg_mix(h->text_logits, d.vt, d.vt, h->cfg_scale, nullptr, h->pmax_t, h->pidx_t, R / 2, side)) return rc;
-  if (skip_text) {
-    // nothing: the sampler streams are keyed by (seed, draw index, row, stream id), so the audio streams' draws do not move
-  } else if (h->topk == 1) {
-    if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr,
-                                  side)) return rc;
-  } else {   // model_new.py:623 sample_topk(text_logits, topk, temperature)
-    if (int rc = ua2_sample_topk(d.dtype, R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature, nullptr, 0,
-                                 d.counters + 1, 0, d.out_tokens, w, 0, nullptr, 0, C, nullptr, key_shift, side)) return rc;
-  }
-  if (!no_fork) UA2_HIP(hipEventRecord(h->ev_join, side));
+  auto text_tail = [&]() -> int {
+    if (skip_text) return 0;   // the sampler streams are keyed by (seed, draw index, row, stream id), so the audio streams' draws do not move
+    if (cfg)
+      if (int rc = ua2_cfg_mix(h->text_logits, d.vt, d.vt, h->cfg_scale, nullptr, h->pmax_t, h->pidx_t, R / 2, s)) return rc;
+    if (h->topk == 1)
+      return ua2_argmax_embed(d.dtype, R, h->npart_t, h->pmax_t, h->pidx_t, d.out_tokens, w, 0, nullptr, 0, C, nullptr, s);
+    // model_new.py:623 sample_topk(text_logits, topk, temperature)
+    return ua2_sample_topk(d.dtype, R, h->text_logits, d.vt, d.vt, std::min(h->topk, d.vt), h->temperature, nullptr, 0, d.counters + 1, 0,
+                           d.out_tokens, w, 0, nullptr, 0, C, nullptr, key_shift, s);
+  };
+  if (!ride)
+    if (int rc = text_tail()) return rc;
   const float* curr = h->hfin;
   for (int i = 0; i < (text_only ? 0 : d.n_cb); ++i) {             // model_new.py:630-641
     fresh_args(h, a);
@@ -421,7 +461,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
     if (h->scaled) hod.produce(a, h->norms[3][0][0]);
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8, false,
-                         h->scaled ? d.decoder.ln_f : nullptr, h->scaled)) return rc;
+                         h->scaled ? d.decoder.ln_f : nullptr, h->scaled, ride ? &rp : nullptr)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
@@ -442,11 +482,14 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
     }
     curr = h->curr_h;
   }
+  if (ride) {
+    UA2_CHECK(rp.next == rp.ntiles, "ua2_stage3_heads: %d of %d lm_head tiles rode", rp.next, rp.ntiles);
+    if (int rc = text_tail()) return rc;
+  }
   if (h->topk != 1) {   // one draw index per frame, advanced after every sampler of the frame has read it
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, d.counters + 1);
     UA2_LAUNCH_CHECK();
   }
-  if (!no_fork) UA2_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
   return 0;
 }
 
