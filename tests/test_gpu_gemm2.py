@@ -29,7 +29,7 @@ def _close(a, b, K, what):
 
 @pytest.fixture
 def g2env():
-    keys = ("UA2_GEMM2_BMT", "UA2_GEMM2_OFF", "UA2_GEMM2_MIN_ROWS", "UA2_GEMM2_FORCE", "UA2_GEMM_NO_KSPLIT")
+    keys = ("UA2_GEMM2_BMT", "UA2_GEMM2_OFF", "UA2_GEMM2_MIN_ROWS", "UA2_GEMM2_FORCE", "UA2_GEMM_NO_KSPLIT", "UA2_GEMM2_NO_TAIL", "UA2_GEMM2_R5_FORMS")
     saved = {k: os.environ.get(k) for k in keys}
 
     def set_(**kw):
@@ -226,3 +226,182 @@ def test_phase_structure_is_repeatable(M, N, K, bmt, g2env):
         y = run(SUM_ORDER_FREE)
         torch.cuda.synchronize()
         assert torch.equal(y, first), (i, (y - first).abs().max().item())
+
+
+@pytest.mark.parametrize("bmt", [16, 8])
+def test_scaled_norm_handover_on_both_sides(bmt, g2env):
+    """Round 6: the scaled-norm hand-over (ua2hip.h y_norm_w / UA2_PRO_SCALED; lit_model.py:883-890 folded around :424 / :591) in the
+    order-free kernel.  Producer: a RESIDUAL (and a STORE) launch emits RNE_bf16(y * w_next) in fragment order + per-16-column sums of
+    squares.  Consumer: SWIGLU / STORE / q|k|v-RoPE launches read that operand and scale by rstd[m] (reduced by the small launch in
+    front).  Against the invariant kernels' hand-over: y and the sums of squares to fp32 summation noise, the bf16 operand to a
+    rounding flip, the consumers' outputs to the order-free tolerance — and EXACTLY when the consumer is fed the same hand-over."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_QKV_ROPE, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU, PRO_CAST, SUM_ORDER_FREE, lib
+    PRO_SCALED = 4
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(70 + bmt)
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=g)).to(dev)
+    M, C, Kp, I = 900, 3072, 2048, 4096
+    wp = ops.pack_linear(mk(C, Kp, s=Kp ** -0.5), dt)                       # producer: Kp -> C
+    w0, w1 = ops.pack_linear(mk(I, C, s=C ** -0.5), dt), ops.pack_linear(mk(I, C, s=C ** -0.5), dt)
+    nh, nkv, hs = 8, 4, 128
+    nq = (nh + 2 * nkv) * hs
+    wq = ops.pack_linear(mk(nq, C, s=C ** -0.5), dt, rope_head_size=hs)
+    x, res, nw = mk(M, Kp), mk(M, C, s=2.0), 1.0 + mk(C, s=0.1)
+    pos = torch.arange(M, dtype=torch.int32, device=dev)
+    seq = torch.zeros(M, dtype=torch.int32, device=dev)
+    npg = (M + 63) // 64
+    pt = torch.randperm(npg, generator=g).to(torch.int32).view(1, npg).to(dev)
+    ang = torch.rand(1024, hs // 2, generator=g) * 6.28
+    cos, sin = ang.cos().to(dev), ang.sin().to(dev)
+
+    def produce(order, epi):
+        y = torch.zeros(M, C, device=dev)
+        pk = ops.linear_workspace(dt, M, C, dev).zero_()
+        ssq = torch.zeros(M, C // 16, device=dev)
+        ops.linear(dtype=dt, M=M, N=C, K=Kp, w0=wp, prologue=PRO_CAST, epilogue=epi, x=x, y=y, resid=res if epi == EPI_RESIDUAL else None,
+                   y_norm_w=nw, y_packed=pk, y_ssq=ssq, workspace=ops.linear_workspace(dt, M, Kp, dev), sum_order=order)
+        torch.cuda.synchronize()
+        return y, pk, ssq
+
+    def consume(order, pk, ssq):
+        outs = {}
+        ws = ops.linear_workspace(dt, M, C, dev)
+        outs["glu"] = torch.zeros(M, I, device=dev)
+        ops.linear(dtype=dt, M=M, N=I, K=C, w0=w0, w1=w1, prologue=PRO_SCALED, epilogue=EPI_SWIGLU, x_packed=pk, x_ssq=ssq, eps=1e-5, y=outs["glu"],
+                   workspace=ws, sum_order=order)
+        outs["store"] = torch.zeros(M, I, device=dev)
+        ops.linear(dtype=dt, M=M, N=I, K=C, w0=w0, prologue=PRO_SCALED, epilogue=EPI_STORE, x_packed=pk, x_ssq=ssq, eps=1e-5, y=outs["store"],
+                   workspace=ws, sum_order=order)
+        kp = torch.zeros(npg, nkv, 64, hs, dtype=dt, device=dev)
+        vp = torch.zeros_like(kp)
+        outs["q"] = torch.zeros(M, nh * hs, device=dev)
+        ops.linear(dtype=dt, M=M, N=nq, K=C, w0=wq, prologue=PRO_SCALED, epilogue=EPI_QKV_ROPE, x_packed=pk, x_ssq=ssq, eps=1e-5, row_pos=pos,
+                   row_seq=seq, rope_cos=cos, rope_sin=sin, q_out=outs["q"], kv=ops.kv_geom(kp, vp, pt, nh, nkv, hs), workspace=ws, sum_order=order)
+        outs["k"], outs["v"] = kp, vp
+        torch.cuda.synchronize()
+        return outs
+
+    for epi in (EPI_RESIDUAL, EPI_STORE):
+        g2env()
+        y0, pk0, ssq0 = produce(0, epi)
+        g2env(UA2_GEMM2_BMT=bmt)
+        n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+        y1, pk1, ssq1 = produce(SUM_ORDER_FREE, epi)
+        assert lib.ua2_debug_kernel_launches(b"gemm2") - n0 == 1
+        _close(y1, y0, Kp, ("producer y", epi))
+        assert not torch.equal(y1, y0)
+        assert ((ssq1 - ssq0).abs() <= 1e-5 * ssq0.abs() + 1e-6).all(), float((ssq1 - ssq0).abs().max())
+        _close(pk1.view(torch.bfloat16), pk0.view(torch.bfloat16), Kp, ("producer operand", epi))
+        assert pk1.view(torch.bfloat16).float().abs().sum() > 0
+    # consumers: the invariant kernels on the invariant hand-over vs the order-free kernel on the SAME hand-over
+    g2env()
+    want = consume(0, pk0, ssq0)
+    g2env(UA2_GEMM2_BMT=bmt)
+    n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+    got, again = consume(SUM_ORDER_FREE, pk0, ssq0), consume(SUM_ORDER_FREE, pk0, ssq0)
+    assert lib.ua2_debug_kernel_launches(b"gemm2") - n0 == 6
+    for k in want:
+        assert torch.equal(got[k], again[k]), k
+        _close(got[k], want[k], C, ("consumer", k))
+        assert got[k].float().abs().sum() > 0
+    assert not torch.equal(got["glu"], want["glu"])
+
+
+@pytest.mark.parametrize("N,bmt", [(12296, 16), (12296, 8), (4096, 8)])
+def test_argmax_partials_and_an_edge_column_count(N, bmt, g2env):
+    """Round 6: UA2_EPI_STORE with per-16-column (max, index) partials on the order-free kernel — lm_head / audio_head at many rows
+    (model_new.py:617,631-632 + :146-187 at topk = 1) — with a column count that is not a multiple of the wave's 64-column span
+    (audio_head: 12 296 = 768 x 16 + 8) and a per-row forbidden prefix.  The partials must be EXACTLY the masked maxima of the logits
+    the same launch stored (ties to the lowest index), and the logits agree with the invariant kernel's to summation noise."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_STORE, PRO_CAST, SUM_ORDER_FREE, lib
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(N + bmt)
+    M, K = 700, 2048
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt, transposed=False)
+    x = torch.randn(M, K, generator=g).to(dev)
+    forbid = torch.randint(0, 4096, (M,), generator=g).to(torch.int32).to(dev)
+    forbid[::3] = 0
+    nb = (N + 15) // 16
+
+    def run(order, **env):
+        g2env(**env)
+        y = torch.zeros(M, N, device=dev)
+        pm, pi = torch.full((M, nb), float("nan"), device=dev), torch.full((M, nb), -7, dtype=torch.int32, device=dev)
+        n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+        ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_STORE, x=x, y=y, part_max=pm, part_idx=pi, forbid=forbid,
+                   workspace=ops.linear_workspace(dt, M, K, dev), sum_order=order)
+        torch.cuda.synchronize()
+        return y, pm, pi, lib.ua2_debug_kernel_launches(b"gemm2") - n0
+
+    y0, pm0, pi0, n_inv = run(0)
+    y1, pm1, pi1, n_free = run(SUM_ORDER_FREE, UA2_GEMM2_BMT=bmt)
+    assert n_inv == 0 and n_free == 1
+    _close(y1, y0, K, "logits")
+    assert not torch.equal(y1, y0)
+    # the partials of each launch describe that launch's own logits exactly
+    for y, pm, pi in ((y0, pm0, pi0), (y1, pm1, pi1)):
+        pad = torch.full((M, nb * 16 - N), float("-inf"), device=dev)
+        cols = torch.arange(nb * 16, device=dev)[None]
+        masked = torch.where(cols >= forbid[:, None].long(), torch.cat([y, pad], 1), torch.full_like(torch.cat([y, pad], 1), float("-inf")))
+        t = masked.view(M, nb, 16)
+        assert torch.equal(pm, t.max(-1).values)
+        first = (t == t.max(-1, keepdim=True).values).float().argmax(-1) + 16 * torch.arange(nb, device=dev)[None]
+        live = torch.isfinite(pm)
+        assert torch.equal(pi[live].long(), first[live])
+    # ... and the rows' winners agree wherever the invariant launch's margin exceeds the summation noise
+    best0 = pm0.max(-1)
+    top2 = torch.topk(pm0, 2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+    assert clear.float().mean() > 0.9
+    win0 = pi0.gather(1, best0.indices[:, None])[:, 0]
+    win1 = pi1.gather(1, pm1.max(-1).indices[:, None])[:, 0]
+    assert torch.equal(win0[clear], win1[clear])
+
+
+def test_tail_split_of_a_grid_with_a_thin_last_round(g2env):
+    """Round 6: 17 x 16 = 272 tiles of 256 x 256 on 256 CUs would run a second round of 16 workgroups; with scratch the launcher runs
+    256 tiles whole and the last 16 as K slabs on a second launch + a combine over those tiles (the trunk's o- / down-projection at
+    6272 rows: 300 tiles).  Deterministic, fp32-noise-close to the unsplit launch, identical outside the tail tiles, and the
+    scaled-norm hand-over of the tail tiles comes from the combine."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST, SUM_ORDER_FREE, lib
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 4352, 4096, 4096
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt)
+    x, res, nw = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev), (1.0 + 0.1 * torch.randn(N, generator=g)).to(dev)
+    ws = ops.linear_workspace(dt, M, K, dev)
+
+    def run(split, handover, **env):
+        g2env(**env)
+        y = torch.zeros(M, N, device=dev)
+        sw = torch.full((8 * 16 * 256 * 256,), float("nan"), device=dev) if split else None
+        kw = {}
+        pk = ssq = None
+        if handover:
+            pk, ssq = ops.linear_workspace(dt, M, N, dev).zero_(), torch.zeros(M, N // 16, device=dev)
+            kw = dict(y_norm_w=nw, y_packed=pk, y_ssq=ssq)
+        n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+        ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x, y=y, resid=res, workspace=ws, split_ws=sw,
+                   sum_order=SUM_ORDER_FREE, **kw)
+        torch.cuda.synchronize()
+        return y, pk, ssq, lib.ua2_debug_kernel_launches(b"gemm2") - n0
+
+    whole, _, _, n1 = run(False, False)
+    split, _, _, n2 = run(True, False)
+    again, _, _, _ = run(True, False)
+    off, _, _, n3 = run(True, False, UA2_GEMM2_NO_TAIL=1)
+    assert (n1, n2, n3) == (1, 2, 1)
+    assert torch.equal(split, again) and torch.equal(off, whole) and not torch.isnan(split).any()
+    diff = (split - whole).abs()
+    assert 0 < diff.max().item() < 2e-5 * K ** 0.5
+    changed = (diff > 0).view(M // 256, 256, N // 256, 256).any(3).any(1)        # which 256 x 256 tiles differ at all
+    assert int(changed.sum()) <= 16, int(changed.sum())
+    yh, pk, ssq, _ = run(True, True)
+    yw, pkw, ssqw, _ = run(False, True)
+    assert torch.equal(yh, split) and torch.equal(yw, whole)
+    assert ((ssq - ssqw).abs() <= 1e-5 * ssqw.abs() + 1e-6).all()
+    _close(pk.view(torch.bfloat16), pkw.view(torch.bfloat16), K, "tail hand-over operand")
+    assert (ssq > 0).all()

@@ -40,7 +40,11 @@
 // ring and walks it by rows, 4 consecutive columns per lane — with the same operations per value, so a launch differs from
 // ua2_gemm.hip's only by the order of the K sum (fp32 rounding noise, ~1e-6 relative).  STORE, RESIDUAL (+ bias, out_scale, K slabs),
 // SWIGLU, GELU (+ packed hand-off), q|k|v with half-split RoPE at head size 128 (the LM) or no rotation + bias at head size 64 (the
-// DiT).  Anything else (partial arg-max outputs, scaled-norm hand-over, other head sizes) stays on ua2_gemm.hip.
+// DiT).  Round 6: the scaled-norm hand-over on both sides (UA2_PRO_SCALED consumers read one row scale per row, reduced from the
+// producer's partials by a small launch in front; y_norm_w producers emit the bf16 operand + per-16-column sums of squares from the
+// RESIDUAL / STORE epilogue and from the K-split combine), the arg-max partials of STORE (lm_head / audio_head; N % 4 == 0 is
+// enough: 12 296 columns), and a TAIL SPLIT for RESIDUAL launches whose last round of tiles would leave most CUs idle (300 tiles on
+// 256 CUs: 256 tiles whole, the other 44 as K slabs on a second launch + combine).  Other head sizes stay on ua2_gemm.hip.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -110,9 +114,93 @@ extern "C" int ua2_g2_stamps(unsigned long long* out) {
 
 // VAR (same bits, a cost choice): 0 = plain, 1 = s_setprio 1 around the MFMAs (measured 1-3 % behind).  A third form — the requests
 // of chunk c + NB - 1 issued inside C(c), spread among its MFMAs — was measured 10 % behind and removed (profiles/r5_notes.md §1).
+// workgroup id -> (row-block pm, column-block pn), as ua2_gemm.hip: an XCD gets a contiguous id range, row-blocks fastest inside
+// patches of group_m.  `pid` counts over ALL tiles of the problem (a tail launch starts at pid0), `total` = mblocks * nblocks.
+__device__ __forceinline__ void g2_tile_of(int pid, const int total, const int mblocks, const int nblocks, const int group_m, int& pm, int& pn) {
+  if (total % 8 == 0) pid = (pid & 7) * (total >> 3) + (pid >> 3);
+  const int per_group = group_m * nblocks;
+  const int group = pid / per_group, first_m = group * group_m;
+  const int gsz = min(mblocks - first_m, group_m);
+  pm = first_m + (pid % per_group) % gsz;
+  pn = (pid % per_group) / gsz;
+}
+
+// The part of the RESIDUAL / STORE / SWIGLU / GELU epilogues that runs on 4 consecutive columns n0 .. n0 + 3 of row m: row scale
+// (UA2_PRO_SCALED), bias, LayerScale + residual | activation, stores, packed hand-off, scaled-norm hand-over, arg-max partials.
+// Called by every lane of a 4-lane group (16-column tile) together: the hand-over and the arg-max exchange across the group; `live`
+// = this lane's columns exist (n0 < N) and the row exists.  One definition for the kernel's epilogue and the K-split combines.
+template <int EPI>
+__device__ __forceinline__ void g2_finish(const ua2_linear_args& a, const int m, const int n0, float4 v0, float4 v1, const float4& cb0, const float4& cb1,
+                                          const float4& cos4, const float rs, const float4& res, const bool live, const int forbid) {
+  constexpr int KC = 32;
+  if (a.prologue == UA2_PRO_SCALED) {
+    v0.x = __fmul_rn(v0.x, rs); v0.y = __fmul_rn(v0.y, rs); v0.z = __fmul_rn(v0.z, rs); v0.w = __fmul_rn(v0.w, rs);
+    if constexpr (EPI == UA2_EPI_SWIGLU) { v1.x = __fmul_rn(v1.x, rs); v1.y = __fmul_rn(v1.y, rs); v1.z = __fmul_rn(v1.z, rs); v1.w = __fmul_rn(v1.w, rs); }
+  }
+  if (a.bias) {
+    v0.x = __fadd_rn(v0.x, cb0.x); v0.y = __fadd_rn(v0.y, cb0.y); v0.z = __fadd_rn(v0.z, cb0.z); v0.w = __fadd_rn(v0.w, cb0.w);
+    if constexpr (EPI == UA2_EPI_SWIGLU) { v1.x = __fadd_rn(v1.x, cb1.x); v1.y = __fadd_rn(v1.y, cb1.y); v1.z = __fadd_rn(v1.z, cb1.z); v1.w = __fadd_rn(v1.w, cb1.w); }
+  }
+  float4 out = v0;
+  if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    if (a.out_scale) { out.x = __fmul_rn(cos4.x, v0.x); out.y = __fmul_rn(cos4.y, v0.y); out.z = __fmul_rn(cos4.z, v0.z); out.w = __fmul_rn(cos4.w, v0.w); }
+    out.x = __fadd_rn(out.x, res.x); out.y = __fadd_rn(out.y, res.y); out.z = __fadd_rn(out.z, res.z); out.w = __fadd_rn(out.w, res.w);
+  } else if constexpr (EPI == UA2_EPI_SWIGLU) {
+    out.x = ua2_act_glu(a, v0.x, v1.x); out.y = ua2_act_glu(a, v0.y, v1.y); out.z = ua2_act_glu(a, v0.z, v1.z); out.w = ua2_act_glu(a, v0.w, v1.w);
+  } else if constexpr (EPI == UA2_EPI_GELU) {
+    out.x = ua2_act_gelu(a, v0.x); out.y = ua2_act_gelu(a, v0.y); out.z = ua2_act_gelu(a, v0.z); out.w = ua2_act_gelu(a, v0.w);
+  }
+  if (live && a.y) *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n0) = out;
+  if constexpr (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_GELU) {
+    if (live && a.y_packed) store_packed4<UA2_BF16>(a.y_packed, m, n0, a.N / KC, out);
+  }
+  if constexpr (EPI == UA2_EPI_STORE || EPI == UA2_EPI_RESIDUAL) {
+    if (a.y_norm_w) {     // producer half of the scaled-norm hand-over: the 16-column tile = this lane's 4 columns + 3 neighbours
+      float s = live ? __fadd_rn(__fmaf_rn(out.x, out.x, __fmul_rn(out.y, out.y)), __fmaf_rn(out.z, out.z, __fmul_rn(out.w, out.w))) : 0.f;
+      s = __fadd_rn(s, __shfl_xor(s, 1));
+      s = __fadd_rn(s, __shfl_xor(s, 2));
+      if (live) {
+        if (a.y_ssq && ((n0 >> 2) & 3) == 0) a.y_ssq[(size_t)m * ((a.N + 15) >> 4) + (n0 >> 4)] = s;
+        const float4 nw4 = *reinterpret_cast<const float4*>(a.y_norm_w + n0);
+        const float4 hh = make_float4(__fmul_rn(out.x, nw4.x), __fmul_rn(out.y, nw4.y), __fmul_rn(out.z, nw4.z), __fmul_rn(out.w, nw4.w));
+        if (a.y_h) store_row4<UA2_BF16>(a.y_h, (size_t)m * a.ldh + n0, hh);
+        if (a.y_packed) store_packed4<UA2_BF16>(a.y_packed, m, n0, a.N / KC, hh);
+      }
+    }
+  }
+  if constexpr (EPI == UA2_EPI_STORE) {
+    if (a.part_max) {     // per-16-column (max, index) for the greedy tail, ties -> lowest index, columns below forbid[m] masked (linear_epilogue's rule)
+      float bv = -INFINITY;
+      int bi = n0;
+      if (live) {
+        const float vv[4] = {out.x, out.y, out.z, out.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = (n0 + e >= forbid) ? vv[e] : -INFINITY;
+          if (t > bv) { bv = t; bi = n0 + e; }              // ascending scan: a tie keeps the lower index
+        }
+      }
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (live && ((n0 >> 2) & 3) == 0) {
+        const int nb = (a.N + 15) / 16;
+        a.part_max[(size_t)m * nb + (n0 >> 4)] = bv;
+        a.part_idx[(size_t)m * nb + (n0 >> 4)] = bi;
+      }
+    }
+  }
+}
+
+// flags: 2 = K slabs over the whole grid (gridDim.y slabs, raw sums into split_ws [S][M][N]); 4 = TAIL launch: workgroup x is tile
+// pid0 + x, gridDim.y slabs, raw sums into the compact scratch [S][tail tiles][BMT * 16 rows][256] (gemm2_tail_combine_kernel)
 template <int EPI, int BMT, int NB, int VAR>
 __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kernel(const ua2_linear_args a, const char* __restrict__ apack, const int mblocks,
-                                                       const int nblocks, const int group_m, const int flags) {
+                                                       const int nblocks, const int group_m, const int flags, const int pid0,
+                                                       const float* __restrict__ rstd) {
   constexpr int KC = 32;
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int WM = BMT / 2;            // row tiles per wave (two groups of four waves split the rows)
@@ -133,16 +221,8 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
   const int nchunks = c_hi - c_lo;
   const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
 
-  // workgroup id -> (row-block pm, column-block pn), as ua2_gemm.hip: an XCD gets a contiguous id range, row-blocks fastest inside
-  // patches of group_m
-  int pid = blockIdx.x;
-  const int total = gridDim.x;
-  if (total % 8 == 0) pid = (pid & 7) * (total >> 3) + (pid >> 3);
-  const int per_group = group_m * nblocks;
-  const int group = pid / per_group, first_m = group * group_m;
-  const int gsz = min(mblocks - first_m, group_m);
-  const int pm = first_m + (pid % per_group) % gsz;
-  const int pn = (pid % per_group) / gsz;
+  int pm, pn;
+  g2_tile_of((int)blockIdx.x + pid0, mblocks * nblocks, mblocks, nblocks, group_m, pm, pn);
 
   // this wave's LOADS fragment streams: block j * 8 + wave of the chunk
   const char* tb[LOADS];
@@ -256,7 +336,12 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
 
   // ---- epilogues: the wave's patch goes through its share of the ring PM row tiles at a time ----
   constexpr int SHARE = NB * TILES * 1024 / 8;                       // bytes of LDS per wave
-  constexpr int PM = (SHARE / 4096 >= WM) ? WM : ((SHARE / 4096 >= WM / 2) ? WM / 2 : WM / 4);
+  constexpr int PM0 = (SHARE / 4096 >= WM) ? WM : ((SHARE / 4096 >= WM / 2) ? WM / 2 : WM / 4);
+  // RESIDUAL requests every residual piece of a pass before its first store (PM x 4 float4 per lane): two row tiles per pass keep the
+  // 256-row-tile form inside its registers now that the epilogue also carries the hand-over
+  // (one per pass in the 128-register form, whose unrolled pass would not fit otherwise)
+  constexpr bool kSmallRegs = BMT == 8 && NB <= 3 && (EPI == UA2_EPI_RESIDUAL || EPI == UA2_EPI_STORE);   // the hand-over / arg-max epilogues in 128 registers
+  constexpr int PM = kSmallRegs ? 1 : ((EPI == UA2_EPI_RESIDUAL && PM0 > 2) ? 2 : PM0);
   static_assert(PM >= 1 && WM % PM == 0 && PM * 4096 <= SHARE, "patch does not fit the wave's share of the ring");
   float* patch = reinterpret_cast<float*>(g2_smem + (size_t)wave * SHARE);
   const int colq = lane & 15, gq = lane >> 4;
@@ -305,8 +390,13 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
             const int prow = it * 4 + gq;
             const int m = mwave + p0 * 16 + prow;
             if (m >= a.M) continue;
-            const float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
-            const float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
+            float4 own = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 32 : 0) + 4 * jj);
+            float4 oth = *reinterpret_cast<const float4*>(patch + prow * 64 + (hi ? 0 : 32) + 4 * jj);
+            if (a.prologue == UA2_PRO_SCALED) {          // the row scale first, as linear_epilogue does
+              const float rs = rstd[m];
+              own.x = __fmul_rn(own.x, rs); own.y = __fmul_rn(own.y, rs); own.z = __fmul_rn(own.z, rs); own.w = __fmul_rn(own.w, rs);
+              oth.x = __fmul_rn(oth.x, rs); oth.y = __fmul_rn(oth.y, rs); oth.z = __fmul_rn(oth.z, rs); oth.w = __fmul_rn(oth.w, rs);
+            }
             const int pos = a.row_pos[m];
             float4 out = own;
             if (rot) {
@@ -380,26 +470,28 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
     constexpr int LPR = SPAN / 4;                        // lanes per row
     constexpr int RPI = 64 / LPR;                        // rows per iteration
     constexpr int ITERS = PM * 16 / RPI;
-    const bool slab = (flags & 2) != 0;                  // K split: raw partial sums into this slab of split_ws
+    const bool slab = (flags & 2) != 0, tail = (flags & 4) != 0;   // K split: raw partial sums into split_ws
     const int j = lane & (LPR - 1), rsub = lane / LPR;
     const int n0 = (pn * BNM + wn * WNT) * 16 + 4 * j;   // this lane's 4 columns (of each matrix)
-    const bool live = n0 < a.N;                          // wave-uniform (N % SPAN == 0)
+    const bool clive = n0 < a.N;                         // (N % 4 == 0: a lane's four columns exist together)
+    if (n0 - 4 * j >= a.N) return;                       // the wave's whole span is past N (wave-uniform)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 b0 = zero4, b1 = zero4, os4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (live) {
-      if (a.bias) b0 = *reinterpret_cast<const float4*>(a.bias + n0);
-      if constexpr (NT == 2) { if (a.bias && a.bias1) b1 = *reinterpret_cast<const float4*>(a.bias1 + n0); }
-      if constexpr (EPI == UA2_EPI_RESIDUAL) { if (a.out_scale) os4 = *reinterpret_cast<const float4*>(a.out_scale + n0); }
+    constexpr bool PRE = !(BMT == 8 && NB <= 3);         // the two-workgroups-per-CU form has 128 registers: request per row instead
+    float4 cb0 = zero4, cb1 = zero4, cos4 = make_float4(1.f, 1.f, 1.f, 1.f);      // per-lane column constants
+    if (clive) {
+      if (a.bias) cb0 = *reinterpret_cast<const float4*>(a.bias + n0);
+      if constexpr (NT == 2) { if (a.bias && a.bias1) cb1 = *reinterpret_cast<const float4*>(a.bias1 + n0); }
+      if constexpr (EPI == UA2_EPI_RESIDUAL) { if (a.out_scale) cos4 = *reinterpret_cast<const float4*>(a.out_scale + n0); }
     }
-#pragma unroll 1
-    for (int p0 = 0; p0 < WM; p0 += PM) {
+    auto pass = [&](auto p0v) {                          // one pass of PM row tiles; p0v: int, or an integral_constant (fully static accumulator indices)
+      const int p0 = p0v;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);   // (a local: capturing the outer constant by reference gave it a stack slot)
       park(p0, [&](int ci) { return ci * 16 + colq; });
-      if (live) {
+      {
         const int mbase = mwave + p0 * 16;
-        constexpr bool PRE = !(BMT == 8 && NB <= 3);     // the two-workgroups-per-CU form has 128 registers: request per row instead
         float4 res[PRE ? ITERS : 1];
         if constexpr (EPI == UA2_EPI_RESIDUAL && PRE) {  // every residual piece of the pass requested before the first store
-          if (!slab) {
+          if (!slab && !tail && clive) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
               const int m = mbase + it * RPI + rsub;
@@ -411,67 +503,107 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
         for (int it = 0; it < ITERS; ++it) {
           const int prow = it * RPI + rsub;
           const int m = mbase + prow;
-          if (m >= a.M) continue;
+          if (m >= a.M) continue;                        // uniform over the row's lanes
           float4 v0 = *reinterpret_cast<const float4*>(patch + prow * 64 + 4 * j);
           if constexpr (EPI == UA2_EPI_RESIDUAL) {
             if (slab) {
-              *reinterpret_cast<float4*>(a.split_ws + ((size_t)blockIdx.y * a.M + m) * a.N + n0) = v0;
+              if (clive) *reinterpret_cast<float4*>(a.split_ws + ((size_t)blockIdx.y * a.M + m) * a.N + n0) = v0;
+              continue;
+            }
+            if (tail) {                                  // compact scratch: [slab][tail tile][row of the tile][256 columns]
+              const int trow = (grp * WM + p0) * 16 + prow;
+              *reinterpret_cast<float4*>(a.split_ws + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BMT * 16) + trow) * 256 + wn * 64 + 4 * j) = v0;
               continue;
             }
           }
-          float4 v1 = zero4;
+          float4 v1 = z4;
           if constexpr (NT == 2) v1 = *reinterpret_cast<const float4*>(patch + prow * 64 + SPAN + 4 * j);
-          if (a.bias) {
-            v0.x = __fadd_rn(v0.x, b0.x); v0.y = __fadd_rn(v0.y, b0.y); v0.z = __fadd_rn(v0.z, b0.z); v0.w = __fadd_rn(v0.w, b0.w);
-            if constexpr (NT == 2) { v1.x = __fadd_rn(v1.x, b1.x); v1.y = __fadd_rn(v1.y, b1.y); v1.z = __fadd_rn(v1.z, b1.z); v1.w = __fadd_rn(v1.w, b1.w); }
-          }
-          float4 out = v0;
+          float4 r4 = z4;
           if constexpr (EPI == UA2_EPI_RESIDUAL) {
-            if (a.out_scale) { out.x = __fmul_rn(os4.x, v0.x); out.y = __fmul_rn(os4.y, v0.y); out.z = __fmul_rn(os4.z, v0.z); out.w = __fmul_rn(os4.w, v0.w); }
-            float4 r4;
             if constexpr (PRE) r4 = res[it];
-            else r4 = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n0);
-            out.x = __fadd_rn(out.x, r4.x); out.y = __fadd_rn(out.y, r4.y); out.z = __fadd_rn(out.z, r4.z); out.w = __fadd_rn(out.w, r4.w);
-          } else if constexpr (EPI == UA2_EPI_SWIGLU) {
-            out.x = ua2_act_glu(a, v0.x, v1.x); out.y = ua2_act_glu(a, v0.y, v1.y); out.z = ua2_act_glu(a, v0.z, v1.z); out.w = ua2_act_glu(a, v0.w, v1.w);
-          } else if constexpr (EPI == UA2_EPI_GELU) {
-            out.x = ua2_act_gelu(a, v0.x); out.y = ua2_act_gelu(a, v0.y); out.z = ua2_act_gelu(a, v0.z); out.w = ua2_act_gelu(a, v0.w);
+            else if (clive) r4 = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n0);
           }
-          if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n0) = out;
-          if constexpr (EPI == UA2_EPI_SWIGLU || EPI == UA2_EPI_GELU) {
-            if (a.y_packed) store_packed4<UA2_BF16>(a.y_packed, m, n0, a.N / KC, out);
-          }
+          const float rs = (a.prologue == UA2_PRO_SCALED) ? rstd[m] : 1.f;
+          int forbid = 0;
+          if constexpr (EPI == UA2_EPI_STORE) { if (a.part_max && a.forbid) forbid = a.forbid[m]; }
+          g2_finish<EPI>(a, m, n0, v0, v1, cb0, cb1, cos4, rs, r4, clive, forbid);
         }
       }
       done();
+    };
+    if constexpr (kSmallRegs) {
+      // the 128-register form walks its four row tiles one per pass; written out, so that no accumulator is selected at run time
+      // (as a loop the compiler parked the accumulators in scratch: 208 bytes per lane)
+      static_assert(WM == 4 && PM == 1, "passes below");
+      using std::integral_constant;
+      pass(integral_constant<int, 0>{}); pass(integral_constant<int, 1>{}); pass(integral_constant<int, 2>{}); pass(integral_constant<int, 3>{});
+    } else {
+#pragma unroll 1
+      for (int p0 = 0; p0 < WM; p0 += PM) pass(p0);
     }
   }
 }
 
-// y = resid + out_scale (.) ((((s0 + s1) + s2) + s3) + bias): the slabs of a K split in index order (as ua2_gemm.hip's combine)
+// y = resid + out_scale (.) ((((s0 + s1) + s2) + s3) + bias): the slabs of a K split in index order (as ua2_gemm.hip's combine),
+// then everything the RESIDUAL epilogue does (g2_finish: stores, scaled-norm hand-over).  N % 64 == 0: whole 4-lane groups.
 __global__ __launch_bounds__(256) void gemm2_combine_kernel(const ua2_linear_args a, const int slabs) {
   const int n4 = a.N >> 2;
   const size_t total = (size_t)a.M * n4, slab_elems = (size_t)a.M * a.N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < total; i0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = i0 + threadIdx.x;
+    const bool live = i < total;                           // (total % 4 == 0 and blockDim % 4 == 0: a 4-lane group is live together)
+    const size_t ic = live ? i : total - 1;
+    const int m = (int)(ic / n4), n = (int)(ic - (size_t)m * n4) * 4;
     const float* p = a.split_ws + (size_t)m * a.N + n;
     float4 t = *reinterpret_cast<const float4*>(p);
     for (int k = 1; k < slabs; ++k) {
       const float4 u = *reinterpret_cast<const float4*>(p + (size_t)k * slab_elems);
       t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
     }
-    if (a.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-      t.x = __fadd_rn(t.x, b.x); t.y = __fadd_rn(t.y, b.y); t.z = __fadd_rn(t.z, b.z); t.w = __fadd_rn(t.w, b.w);
-    }
-    if (a.out_scale) {
-      const float4 g = *reinterpret_cast<const float4*>(a.out_scale + n);
-      t.x = __fmul_rn(g.x, t.x); t.y = __fmul_rn(g.y, t.y); t.z = __fmul_rn(g.z, t.z); t.w = __fmul_rn(g.w, t.w);
-    }
+    float4 cb0 = zero4, cos4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.bias) cb0 = *reinterpret_cast<const float4*>(a.bias + n);
+    if (a.out_scale) cos4 = *reinterpret_cast<const float4*>(a.out_scale + n);
     const float4 r = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n);
-    t.x = __fadd_rn(t.x, r.x); t.y = __fadd_rn(t.y, r.y); t.z = __fadd_rn(t.z, r.z); t.w = __fadd_rn(t.w, r.w);
-    *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = t;
+    g2_finish<UA2_EPI_RESIDUAL>(a, m, n, t, zero4, cb0, zero4, cos4, 1.f, r, live, 0);
   }
+}
+
+// The tail launch's slabs (compact scratch [S][ntail][rows][256]) -> the tiles pid0 .. pid0 + ntail - 1: a workgroup = 4 rows of a tile
+__global__ __launch_bounds__(256) void gemm2_tail_combine_kernel(const ua2_linear_args a, const int slabs, const int ntail, const int pid0, const int mblocks,
+                                                                 const int nblocks, const int group_m, const int bmt) {
+  const int rows = bmt * 16;
+  const int t = blockIdx.x / (rows / 4), r = (blockIdx.x % (rows / 4)) * 4 + (threadIdx.x >> 6), c4 = threadIdx.x & 63;
+  int pm, pn;
+  g2_tile_of(pid0 + t, mblocks * nblocks, mblocks, nblocks, group_m, pm, pn);
+  const int m = pm * rows + r, n = pn * 256 + c4 * 4;
+  const bool rlive = m < a.M;                              // uniform over the row's 64 threads
+  if (!rlive) return;
+  const bool live = n < a.N;
+  const float* p = a.split_ws + (((size_t)t) * rows + r) * 256 + c4 * 4;
+  const size_t slab_elems = (size_t)ntail * rows * 256;
+  float4 s4 = *reinterpret_cast<const float4*>(p);
+  for (int k = 1; k < slabs; ++k) {
+    const float4 u = *reinterpret_cast<const float4*>(p + (size_t)k * slab_elems);
+    s4.x = __fadd_rn(s4.x, u.x); s4.y = __fadd_rn(s4.y, u.y); s4.z = __fadd_rn(s4.z, u.z); s4.w = __fadd_rn(s4.w, u.w);
+  }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cb0 = zero4, cos4 = make_float4(1.f, 1.f, 1.f, 1.f), r4 = zero4;
+  if (live) {
+    if (a.bias) cb0 = *reinterpret_cast<const float4*>(a.bias + n);
+    if (a.out_scale) cos4 = *reinterpret_cast<const float4*>(a.out_scale + n);
+    r4 = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + n);
+  }
+  g2_finish<UA2_EPI_RESIDUAL>(a, m, n, s4, zero4, cb0, zero4, cos4, 1.f, r4, live, 0);
+}
+
+// UA2_PRO_SCALED consumers: one scale per row, reduced from the producer's per-16-column partials in the one order every kernel uses
+// (scaled_rstd_row: 16 interleaved chains + butterfly) — a launch of M / 16 workgroups in front of the GEMM instead of 16 lanes per
+// row and column block inside it
+__global__ __launch_bounds__(256) void gemm2_rstd_kernel(const ua2_linear_args a, float* __restrict__ rstd) {
+  const int m = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const float rs = scaled_rstd_row(a, min(m, a.M - 1), threadIdx.x & 15);
+  if (m < a.M && (threadIdx.x & 15) == 0) rstd[m] = rs;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -479,13 +611,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning / A-B knobs: read once (ua2_common.h Ua2EnvInt; ua2_debug_refresh_env re-reads them — the tests toggle some)
 Ua2EnvInt g_group_m{"UA2_GEMM2_GROUP_M", 8}, g_ks_min_chunks{"UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96}, g_ks_max_grid{"UA2_GEMM2_KSPLIT_MAX_GRID", 128},
     g_no_ksplit{"UA2_GEMM_NO_KSPLIT", 0}, g_bmt{"UA2_GEMM2_BMT", 0}, g_deep_max_grid{"UA2_GEMM2_DEEP_MAX_GRID", 256}, g_no_deep{"UA2_GEMM2_NO_DEEP", 0},
-    g_off{"UA2_GEMM2_OFF", 0}, g_min_rows{"UA2_GEMM2_MIN_ROWS", 256};
+    g_off{"UA2_GEMM2_OFF", 0}, g_min_rows{"UA2_GEMM2_MIN_ROWS", 256}, g_no_tail{"UA2_GEMM2_NO_TAIL", 0}, g_tail_min_chunks{"UA2_GEMM2_TAIL_MIN_CHUNKS", 128}, g_no_new{"UA2_GEMM2_R5_FORMS", 0};
 
 // Instantiations: BMT = 16 / four slots (one workgroup per CU), BMT = 8 / three slots (two per CU, 128 registers) and BMT = 8 / six
 // slots (small grids), all without s_setprio.  -DUA2_G2_EXPERIMENTS adds the s_setprio variant and free choice of the ring behind
 // the UA2_GEMM2_VAR / UA2_GEMM2_NB hooks (tools/ubench/gemm2_variants.py).
 template <int EPI>
-int launch2(const ua2_linear_args& a, hipStream_t s) {
+int launch2(const ua2_linear_args& a, hipStream_t s, const float* rstd, const bool dry = false) {
   constexpr int NT = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
   constexpr int BNM = 16 / NT;
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16), nblocks = ua2_ceil_div(ntiles, BNM);
@@ -506,46 +638,69 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
     }
     return 1;
   };
+  // TAIL SPLIT (RESIDUAL with scratch): 256-row tiles whose last round would fill less than 70 % of the CUs — the trunk's o- and
+  // down-projection at 6272 rows are 25 x 12 = 300 tiles: a second round of 44 — run as whole rounds + the remaining tiles cut
+  // into K slabs on a second launch (+ a combine over those tiles only): 334 -> ~230 us for the down-projection.
+  int tail = 0, tail_ks = 1;
+  if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    const int64_t rem = t16 % 256;
+    // (long K only: at K = 3072 the o-projection's three launches — 130 us — lose to the 128-row tiles' 121 us, profiles/r6_notes.md §3)
+    if (!g_bmt.get() && !g_no_tail.get() && !g_no_ksplit.set() && a.split_ws && nchunks >= g_tail_min_chunks.get() && t16 > 256 && rem > 0 && rem * 10 < 256 * 7) {
+      int ks = (int)std::min<int64_t>(8, 256 / rem);
+      while (ks > 1 && nchunks / ks < 12) --ks;                                  // a slab must keep the ring busy (>= 12 chunks)
+      while (ks > 1 && (size_t)ks * rem * 256 * 256 * sizeof(float) > a.split_ws_bytes) --ks;
+      if (ks >= 2) { tail = (int)rem; tail_ks = ks; }
+    }
+  }
   int bmt = g_bmt.get();
   if (!bmt) {
     const double e16 = (double)t16 / (double)(((t16 + 255) / 256) * 256);
-    if (t16 >= 128 && e16 >= 0.70) bmt = 16;
+    if (tail || (t16 >= 128 && e16 >= 0.70)) bmt = 16;
     else if (t8 * slabs_for(t8) >= 128) bmt = 8;
     else return 1;
   }
+  if (dry) return 0;                                   // the launch fits: the caller may issue what has to precede it
   const int mblocks = ua2_ceil_div(mtiles, bmt);
-  const int64_t grid1 = (int64_t)mblocks * nblocks;
-  const int ks = slabs_for(grid1), flags = ks > 1 ? 2 : 0;
+  const int64_t grid_all = (int64_t)mblocks * nblocks;
+  const int64_t grid1 = grid_all - tail;
+  const int ks = tail ? 1 : slabs_for(grid_all), flags = ks > 1 ? 2 : 0;
   const char* ap = reinterpret_cast<const char*>(a.x_packed ? a.x_packed : a.workspace);
-  auto go = [&](auto bmt_c, auto nb_c, auto var_c) {
+  auto go = [&](auto bmt_c, auto nb_c, auto var_c, int64_t gx, int gy, int fl, int pid0) {
     constexpr int B = decltype(bmt_c)::value, NBUF = decltype(nb_c)::value, V = decltype(var_c)::value;
     constexpr auto kern = gemm2_kernel<EPI, B, NBUF, V>;
     ua2_allow_big_lds<kern>();
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid1, ks), dim3(512), (size_t)NBUF * (B + 16) * 1024, s, a, ap, mblocks, nblocks, group_m, flags);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(512), (size_t)NBUF * (B + 16) * 1024, s, a, ap, mblocks, nblocks, group_m, fl, pid0, rstd);
     ua2_count_launch(UA2_CNT_GEMM2);
   };
   using std::integral_constant;
+  auto launch_form = [&](int64_t gx, int gy, int fl, int pid0) {
 #ifdef UA2_G2_EXPERIMENTS
-  static Ua2EnvInt g_var{"UA2_GEMM2_VAR", 0}, g_nb{"UA2_GEMM2_NB", 0};
-  const int var = g_var.get() == 1, nbx = g_nb.get();
-  auto pick_var = [&](auto bmt_c, auto nb_c) {
-    if (var) go(bmt_c, nb_c, integral_constant<int, 1>{}); else go(bmt_c, nb_c, integral_constant<int, 0>{});
-  };
-  if (bmt == 16) pick_var(integral_constant<int, 16>{}, integral_constant<int, 4>{});
-  else if (nbx == 6) pick_var(integral_constant<int, 8>{}, integral_constant<int, 6>{});
-  else pick_var(integral_constant<int, 8>{}, integral_constant<int, 3>{});
+    static Ua2EnvInt g_var{"UA2_GEMM2_VAR", 0}, g_nb{"UA2_GEMM2_NB", 0};
+    const int var = g_var.get() == 1, nbx = g_nb.get();
+    auto pick_var = [&](auto bmt_c, auto nb_c) {
+      if (var) go(bmt_c, nb_c, integral_constant<int, 1>{}, gx, gy, fl, pid0); else go(bmt_c, nb_c, integral_constant<int, 0>{}, gx, gy, fl, pid0);
+    };
+    if (bmt == 16) pick_var(integral_constant<int, 16>{}, integral_constant<int, 4>{});
+    else if (nbx == 6) pick_var(integral_constant<int, 8>{}, integral_constant<int, 6>{});
+    else pick_var(integral_constant<int, 8>{}, integral_constant<int, 3>{});
 #else
-  // 128-row tiles: three slots and two workgroups per CU when the grid has more workgroups than CUs; six slots (five chunks in flight)
-  // when every workgroup has a CU to itself anyway — the small launches of the DiT's single window start on weights that are in no
-  // cache, and with two chunks in flight a workgroup advances one chunk per HBM round trip (measured in situ: profiles/r5_notes.md §3)
-  const bool deep = grid1 * ks <= g_deep_max_grid.get() && !g_no_deep.get();
-  if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{});
-  else if (deep) go(integral_constant<int, 8>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{});
-  else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 0>{});
+    // 128-row tiles: three slots and two workgroups per CU when the grid has more workgroups than CUs; six slots (five chunks in flight)
+    // when every workgroup has a CU to itself anyway — the small launches of the DiT's single window start on weights that are in no
+    // cache, and with two chunks in flight a workgroup advances one chunk per HBM round trip (measured in situ: profiles/r5_notes.md §3)
+    const bool deep = gx * gy <= g_deep_max_grid.get() && !g_no_deep.get();
+    if (bmt == 16) go(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, gx, gy, fl, pid0);
+    else if (deep) go(integral_constant<int, 8>{}, integral_constant<int, 6>{}, integral_constant<int, 0>{}, gx, gy, fl, pid0);
+    else go(integral_constant<int, 8>{}, integral_constant<int, 3>{}, integral_constant<int, 0>{}, gx, gy, fl, pid0);
 #endif
+  };
+  launch_form(grid1, ks, flags, 0);
   if (flags & 2) {
     const size_t total4 = (size_t)a.M * (a.N / 4);
     hipLaunchKernelGGL(gemm2_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
+  }
+  if (tail) {
+    launch_form(tail, tail_ks, 4, (int)grid1);
+    hipLaunchKernelGGL(gemm2_tail_combine_kernel, dim3((unsigned)(tail * (bmt * 16 / 4))), dim3(256), 0, s, a, tail_ks, tail, (int)grid1, mblocks, nblocks, group_m, bmt);
   }
   UA2_LAUNCH_CHECK();
   return 0;
@@ -557,31 +712,53 @@ int launch2(const ua2_linear_args& a, hipStream_t s) {
 // already packed (x_packed, or the prep launch into workspace).
 int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
   if (a.dtype != UA2_BF16 || g_off.set()) return 1;
-  if (a.prologue == UA2_PRO_SCALED || a.part_max || a.y_norm_w) return 1;
   if (a.M < g_min_rows.get() || a.K % 32 != 0) return 1;
   const bool glu = a.epilogue == UA2_EPI_SWIGLU;
-  if (a.N % (glu ? 32 : 64) != 0) return 1;
+  const bool r5 = g_no_new.set();                               // A/B hook: only the launches round 5's kernel took
+  if (r5 && (a.prologue == UA2_PRO_SCALED || a.part_max || a.y_norm_w || a.N % (glu ? 32 : 64) != 0)) return 1;
+  // columns: whole wave spans (64; 32 per matrix for SWIGLU) — except STORE, whose per-lane column guard takes any N % 4 == 0
+  // (audio_head: 12 296)
+  if (a.epilogue == UA2_EPI_STORE ? (a.N % 4 != 0) : (a.N % (glu ? 32 : 64) != 0)) return 1;
   if (a.bias && !aligned16(a.bias)) return 1;
   if (glu && a.bias1 && !aligned16(a.bias1)) return 1;
+  if (a.part_max && a.epilogue != UA2_EPI_STORE) return 1;
+  if (a.y_norm_w) {                                             // producer half of the hand-over: RESIDUAL / STORE, whole 16-column tiles
+    if ((a.epilogue != UA2_EPI_RESIDUAL && a.epilogue != UA2_EPI_STORE) || a.N % 16 != 0 || !a.y_ssq || !aligned16(a.y_norm_w)) return 1;
+    if ((a.y_h && (a.ldh % 4 != 0 || (reinterpret_cast<uintptr_t>(a.y_h) & 7))) || (a.y_packed && !aligned16(a.y_packed))) return 1;
+  }
+  const float* rstd = nullptr;
+  if (a.prologue == UA2_PRO_SCALED) {                           // consumer half: one scale per row, reduced by a launch in front, into the workspace
+    if (!a.x_packed || !a.x_ssq || !a.workspace || a.workspace == a.x_packed || a.workspace_bytes < (size_t)a.M * sizeof(float)) return 1;
+    if (a.epilogue == UA2_EPI_QKV_ROPE && a.rope_mode != UA2_ROPE_HALF_SPLIT) return 1;     // (the un-rotated q|k|v form writes un-scaled sums)
+    rstd = reinterpret_cast<const float*>(a.workspace);
+  }
+  auto with_rstd = [&](auto launch) -> int {
+    if (!rstd) return launch(false);
+    if (launch(true)) return 1;                                 // the grid rule turns the problem down: nothing issued
+    hipLaunchKernelGGL(gemm2_rstd_kernel, dim3(ua2_ceil_div(a.M, 16)), dim3(256), 0, s, a, reinterpret_cast<float*>(a.workspace));
+    return launch(false);
+  };
   switch (a.epilogue) {
     case UA2_EPI_QKV_ROPE: {
       const bool lm = a.rope_mode == UA2_ROPE_HALF_SPLIT && a.kv.head_size == 128 && !a.bias;
       const bool dit = a.rope_mode == UA2_ROPE_NONE && a.kv.head_size == 64;
       if (!(lm || dit) || !aligned16(a.q_out) || !aligned16(a.kv.k_pool) || !aligned16(a.kv.v_pool)) return 1;
       if (lm && (!aligned16(a.rope_cos) || !aligned16(a.rope_sin))) return 1;
-      return launch2<UA2_EPI_QKV_ROPE>(a, s);
+      return with_rstd([&](bool dry) { return launch2<UA2_EPI_QKV_ROPE>(a, s, rstd, dry); });
     }
     case UA2_EPI_STORE:
-      if (!a.y || a.ldy % 4 || !aligned16(a.y)) return 1;
-      return launch2<UA2_EPI_STORE>(a, s);
+      if (!a.y && !a.part_max) return 1;
+      if (a.y && (a.ldy % 4 || !aligned16(a.y))) return 1;
+      return with_rstd([&](bool dry) { return launch2<UA2_EPI_STORE>(a, s, rstd, dry); });
     case UA2_EPI_RESIDUAL:
+      if (rstd) return 1;
       if (a.ldy % 4 || a.ldr % 4 || !aligned16(a.y) || !aligned16(a.resid) || (a.out_scale && !aligned16(a.out_scale))) return 1;
-      return launch2<UA2_EPI_RESIDUAL>(a, s);
+      return launch2<UA2_EPI_RESIDUAL>(a, s, nullptr);
     case UA2_EPI_SWIGLU:
     case UA2_EPI_GELU:
       if (a.y && (a.ldy % 4 || !aligned16(a.y))) return 1;
       if (a.y_packed && !aligned16(a.y_packed)) return 1;
-      return glu ? launch2<UA2_EPI_SWIGLU>(a, s) : launch2<UA2_EPI_GELU>(a, s);
+      return with_rstd([&](bool dry) { return glu ? launch2<UA2_EPI_SWIGLU>(a, s, rstd, dry) : launch2<UA2_EPI_GELU>(a, s, rstd, dry); });
     default: return 1;
   }
 }

@@ -34,6 +34,8 @@ struct ua2_stage3 {
   // per-16-column sums of squares — no prep launch and no in-kernel statistics between a residual update and its consumer
   void *xh, *xpk;
   float* ssq;
+  float* split_ws = nullptr;   // K-slab scratch of the order-free GEMM (ua2_linear_args.split_ws): handed to launches under UA2_SUM_ORDER_FREE only
+  size_t split_ws_bytes = 0;
   bool scaled = false;
   int32_t npart_t, npart_a;
   int32_t topk = 1;            // 1 = greedy (fused arg-max partials); > 1 = ua2_sample_topk
@@ -53,7 +55,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -80,6 +82,10 @@ Carve carve(const ua2_stage3_desc& d) {
   c.xh = take(R * Cw / 2);                                       // bf16 rows
   c.xpk = take(ua2_linear_workspace_bytes(UA2_BF16, (int64_t)R, (int64_t)Cw) / sizeof(float));
   c.ssq = take(R * (Cw / 16 + 1));
+  // K-slab scratch for order-free launches of a few hundred to a few thousand rows (tail tiles of a 300-tile grid; whole-grid slabs of
+  // the narrow projections at ~1000 rows): plans that can hold such launches only
+  c.split_floats = (d.dtype == UA2_BF16 && R >= 256) ? (size_t)16 << 20 : 0;
+  c.split = take(c.split_floats);
   c.total = off;
   return c;
 }
@@ -112,6 +118,19 @@ struct Handover {
     return ho;
   }
 };
+
+// launches of R rows under the plan's order-free opt-in (ua2_stage3_set_order_free_rows; bf16 plans)
+bool order_free(const ua2_stage3* h, int R) { return h->d.dtype == UA2_BF16 && h->order_free_rows > 0 && R >= h->order_free_rows; }
+// ... run the scaled hand-over whatever the plan's decode form (the order-free GEMM's epilogues carry it at any row count, and the
+// two prep launches per layer go: profiles/r6_notes.md); the widths must be whole bf16 chunks as for h->scaled
+bool order_free_scaled(const ua2_stage3* h, int R, bool prefill = false) {
+  // Measured (profiles/r6_notes.md §3): the hand-over through ua2_gemm2.hip's epilogues does not pay in the frame — config-3 prefill
+  // 46.43 (prep launches) vs 46.45 ms, B = 1024 decode 22.99 vs 24.55 ms per frame — and in prefill it doubles the distance to the
+  // pinned plan (two different bf16 forms of the norm).  Default 0 = never; UA2_OF_SCALED = 1 decode frames, 2 prefill chunks too.
+  static Ua2EnvInt mode{"UA2_OF_SCALED", 0};
+  if (mode.get() < (prefill ? 2 : 1)) return false;
+  return order_free(h, R) && h->d.backbone.n_embd % 32 == 0 && h->d.decoder.n_embd % 32 == 0 && getenv("UA2_NO_SCALED") == nullptr;
+}
 
 bool no_local_fuse() {
   static const bool v = getenv("UA2_NO_LOCAL_FUSE") != nullptr;   // A/B hook (profiles/r1_notes.md)
@@ -156,7 +175,10 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
   const Handover ho(h, R, C);
   // ua2_stage3_set_order_free_rows: many-row launches of the trunk on the 256-row-tile kernel (one chain over K); the launcher falls
   // back to the invariant kernels for anything outside that kernel's forms (scaled hand-over, small grids)
-  const int order = (dt == UA2_BF16 && h->order_free_rows > 0 && R >= h->order_free_rows) ? UA2_SUM_ORDER_FREE : UA2_SUM_ORDER_INVARIANT;
+  const int order = order_free(h, R) ? UA2_SUM_ORDER_FREE : UA2_SUM_ORDER_INVARIANT;
+  auto free_scratch = [&](ua2_linear_args& a) {           // K slabs are an order-free option: the invariant launches never see the scratch
+    if (order == UA2_SUM_ORDER_FREE) { a.split_ws = h->split_ws; a.split_ws_bytes = h->split_ws_bytes; }
+  };
   for (int l = 0; l < g.n_layer; ++l) {
     ua2_kv_geom kv{};                      // ring_pages = 0: the LM's caches are linear
     kv.k_pool = h->pools[gi][0][l]; kv.v_pool = h->pools[gi][1][l]; kv.page_table = g.page_table;
@@ -197,7 +219,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     if (fuse_attn) { a.row_pos = row_pos; a.row_seq = row_seq; a.kv = kv; }
     if (pack_o && !fuse_attn) a.x_packed = h->gemm_ws;
     if (scaled) ho.produce(a, h->norms[gi][1][l]);              // x after attention -> norm_2 + fc_1 / fc_2
-    a.sum_order = order;
+    a.sum_order = order; free_scratch(a);
     if (int rc = launch(a, 1)) return rc;
 
     fresh_args(h, a);
@@ -215,7 +237,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.y = x; a.ldy = C; a.resid = x; a.ldr = C;
     if (pack_act) a.x_packed = h->act_ws;
     if (scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
-    a.sum_order = order;
+    a.sum_order = order; free_scratch(a);
     if (int rc = launch(a, 2)) return rc;
   }
   return 0;
@@ -289,6 +311,7 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->gemm_ws = b + c.gemm_ws; h->gemm_ws_bytes = c.gemm_ws_floats * sizeof(float);
   h->act_ws = b + c.act_ws;
   h->xh = b + c.xh; h->xpk = b + c.xpk; h->ssq = b + c.ssq;
+  h->split_ws = c.split_floats ? b + c.split : nullptr; h->split_ws_bytes = c.split_floats * sizeof(float);
   // the scaled contract is the bf16 executor's (fp32 keeps the reference's operation order); A/B hook: UA2_NO_SCALED=1
   // Plans for more than 64 live sequences keep the prep form as well: at 256 rows the consumers' per-pass row-scale work and
   // the producers' fragment-order stores cost more than the 140 prep launches they replace (12.6 vs 13.7 ms per frame).  The
@@ -319,7 +342,10 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   // and there the hand-over's epilogue costs more than the prep launches it saves (the tiled kernel's RESIDUAL epilogue
   // with the emission spills its accumulators: 8192-row prefill 82 -> 131 ms, profiles/r3_notes.md)
   const bool grouped = !identity;   // prefill chunks (ua2_stage3_trunk) may carry row groups; decode frames never do
-  const bool scaled = h->scaled && !(grouped && (h->n_groups > 0 || R > h->d.max_batch));   // ua2_stage3_trunk with row groups, or with more rows than sequences: a prefill chunk
+  // (under the order-free opt-in the hand-over rides in ua2_gemm2.hip's epilogues at any row count: prefill chunks and plans for more
+  // than 64 sequences take it too)
+  const bool prefill = grouped && (h->n_groups > 0 || R > h->d.max_batch);   // ua2_stage3_trunk with row groups, or with more rows than sequences: a prefill chunk
+  const bool scaled = (h->scaled && !prefill) || order_free_scaled(h, R, prefill);
   const Handover ho(h, R, C);
   ua2_handover e0{}, e1{}, e2{};
   if (scaled) { e0 = ho.rowwise(h->norms[0][0][0]); e1 = ho.rowwise(h->norms[1][0][0]); e2 = ho.rowwise(h->norms[2][0][0]); }
@@ -398,12 +424,16 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
   hipStream_t s = (hipStream_t)stream;
   const ua2_stage3_desc& d = h->d;
   const int C = d.backbone.n_embd, Cd = d.decoder.n_embd, w = d.n_cb + 1;
+  // the plan's order-free opt-in covers the heads and the projection as well (arg-max partials and the hand-over are forms of
+  // ua2_gemm2.hip since round 6); `scaled` as in trunk_impl
+  const int order = order_free(h, R) ? UA2_SUM_ORDER_FREE : UA2_SUM_ORDER_INVARIANT;
+  const bool scaled = h->scaled || order_free_scaled(h, R);
   ua2_linear_args a;
   // text_logits = lm_head(last_h); greedy text sample             (model_new.py:617,623)
   fresh_args(h, a);
   a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
   a.M = R; a.N = d.vt; a.K = C; a.x = h->hfin; a.ldx = C; a.w0 = d.lm_head; a.y = h->text_logits; a.ldy = d.vt;
-  a.part_max = h->pmax_t; a.part_idx = h->pidx_t;
+  a.part_max = h->pmax_t; a.part_idx = h->pidx_t; a.sum_order = order;
   UA2_CHECK(!(skip_text && text_only), "ua2_stage3_heads: nothing left to compute");
   // lm_head does not feed the depth decoder (model_new.py:617 vs :629-640).  A forked graph branch for it replays 0.4 ms per frame
   // SLOWER than the linear chain on ROCm 7.2 (3.49 vs 3.09 ms, re-measured in round 6), so it stays in the chain — but not as a
@@ -418,7 +448,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
     const int qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size;
     ua2_linear_args hs[3];
     for (auto& v : hs) { fresh_args(h, v); v.dtype = d.dtype; v.M = R; v.x = h->act; }
-    hs[0].prologue = h->scaled ? UA2_PRO_SCALED : UA2_PRO_NORM; hs[0].epilogue = UA2_EPI_QKV_ROPE; hs[0].N = nqkv; hs[0].K = Cd;
+    hs[0].prologue = scaled ? UA2_PRO_SCALED : UA2_PRO_NORM; hs[0].epilogue = UA2_EPI_QKV_ROPE; hs[0].N = nqkv; hs[0].K = Cd;
     hs[1].prologue = (R == 1 && d.n_cb <= 8 && !no_local_fuse()) ? UA2_PRO_LOCAL_ATTN : UA2_PRO_CAST; hs[1].epilogue = UA2_EPI_RESIDUAL; hs[1].N = Cd; hs[1].K = qn;
     hs[2].prologue = UA2_PRO_CAST; hs[2].epilogue = UA2_EPI_RESIDUAL; hs[2].N = Cd; hs[2].K = g.inter;
     const double wk[3] = {0.0, 0.0, 1.0};    // the down-projections only: riders on the 6-us q|k|v / o launches made the frame slower (profiles/r6_notes.md)
@@ -458,16 +488,18 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
     a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
     const Handover hod(h, R, Cd);
-    if (h->scaled) hod.produce(a, h->norms[3][0][0]);
+    if (scaled) hod.produce(a, h->norms[3][0][0]);
+    a.sum_order = order;
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8, false,
-                         h->scaled ? d.decoder.ln_f : nullptr, h->scaled, ride ? &rp : nullptr)) return rc;
+                         scaled ? d.decoder.ln_f : nullptr, scaled, ride ? &rp : nullptr)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
     a.w0 = h->audio_head[i]; a.y = h->audio_logits + (size_t)i * d.va; a.ldy = d.n_cb * d.va;
     a.part_max = h->pmax_a; a.part_idx = h->pidx_a; a.forbid = d.forbid;
-    if (h->scaled) hod.consume(a);
+    if (scaled) hod.consume(a);
+    a.sum_order = order;
     if (int rc = ua2_linear_launch(a, s)) return rc;
     if (cfg)   // model_new.py:634-637
       if (int rc = ua2_cfg_mix(h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->cfg_scale, d.forbid, h->pmax_a,
