@@ -118,10 +118,10 @@ def test_every_epilogue_agrees_with_the_invariant_kernels(bmt, g2env):
 
 
 @pytest.mark.parametrize("bmt", [16, 8])
-@pytest.mark.parametrize("nh,nkv,hs,C,M", [(24, 8, 128, 3072, 700), (24, 24, 64, 1536, 1000)])
+@pytest.mark.parametrize("nh,nkv,hs,C,M", [(24, 8, 128, 3072, 700), (24, 24, 64, 1536, 1000), (32, 8, 64, 2048, 700)])
 def test_qkv_epilogues_agree(nh, nkv, hs, C, M, bmt, g2env):
-    """Fused norm + q|k|v + (RoPE) + paged K/V append: the LM's form (half-split rotation, head size 128) and the DiT's (no
-    rotation, bias, head size 64).  Rows of three sequences at scattered positions."""
+    """Fused norm + q|k|v + (RoPE) + paged K/V append: the LM's forms (half-split rotation: head size 128 in the trunk, 64 in the
+    depth decoder) and the DiT's (no rotation, bias, head size 64).  Rows of three sequences at scattered positions."""
     from uniaudio2_amd import ops
     from uniaudio2_amd._lib import EPI_QKV_ROPE, PRO_NORM, ROPE_NONE, SUM_ORDER_FREE
     dev, dt = torch.device("cuda"), torch.bfloat16

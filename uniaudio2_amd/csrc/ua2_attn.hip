@@ -295,10 +295,17 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   constexpr int DC = HS / 32;                 // 32-dim chunks of the QK product
   constexpr int DTL = HS / 16;                // 16-dim tiles of the output
   constexpr int KROW = HS * 2 + 16;           // bytes per key row of the K image (pad: conflict-free 16-byte reads)
-  constexpr int VROW = UA2_PAGE * 2 + 16;     // bytes per dim row of the V^T image
+  // V image: the page as it lies in the pool, [64 keys][HS dims] — a 16-byte copy per thread and piece; the V^T operand of the second
+  // product comes out of ds_read_b64_tr_b16 (gfx950's transposing LDS read: each 16-lane group reads a [4 keys][16 dims] block
+  // through per-lane 8-byte addresses and lane ql receives dim ql's four keys).  Round 6: before, the staging writes transposed —
+  // 16 ds_write_b16 per thread and key block, most of a block's LDS time (profiles/r5_notes.md §5).  Row pitch = 32 x odd bytes:
+  // the 8 rows two lane groups touch in one LDS cycle fall on 8 disjoint bank octets (HS = 64: 160 B -> bank steps of 40).
+  constexpr int VROW = HS * 2 + 32;           // bytes per key row of the V image
   extern __shared__ __attribute__((aligned(16))) char smf[];
-  char* k_lds = smf;                          // [64 keys][KROW]
-  char* v_lds = smf + UA2_PAGE * KROW;        // [HS dims][VROW]
+  // two (K, V) images, used in turn: block kb + 1 is written into the other one while slower waves may still read block kb, so ONE
+  // workgroup barrier per key block (image complete) is enough — every thread has finished reading image b before it passes the
+  // barrier that publishes image b ^ 1, and image b is next written only after that barrier (round 6: was two barriers per block)
+  constexpr int IMG = UA2_PAGE * (KROW + VROW);
   const int grp = blockIdx.x, kvh = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = wave / G, head = kvh * G + (wave % G);
@@ -355,19 +362,15 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   };
   if (nkb > 0) request(0);
   for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();                          // the previous block's readers are done
+    char* k_lds = smf + (kb & 1) * IMG;       // [64 keys][KROW]
+    char* v_lds = k_lds + UA2_PAGE * KROW;    // [64 keys][VROW]
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int i = tid + u * 64 * NW;
       if (i < PIECES) {
         const int key = i / (HS / 8), oct = i % (HS / 8);
         *reinterpret_cast<u32x4*>(k_lds + key * KROW + oct * 16) = kk[u];
-        unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds + (size_t)(oct * 8) * VROW + key * 2);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {         // V^T: dim row oct*8 + 2e (+1), column = key
-          vt[(size_t)(2 * e) * (VROW / 2)] = (unsigned short)(vv[u][e] & 0xffffu);
-          vt[(size_t)(2 * e + 1) * (VROW / 2)] = (unsigned short)(vv[u][e] >> 16);
-        }
+        *reinterpret_cast<u32x4*>(v_lds + key * VROW + oct * 16) = vv[u];
       }
     }
     __syncthreads();
@@ -448,8 +451,14 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
     for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
       for (int dt = 0; dt < DTL; ++dt) {
-        const char* vr = v_lds + (size_t)(dt * 16 + ql) * VROW + (kc * 32 + 4 * g) * 2;
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vr), v1 = *reinterpret_cast<const uint2*>(vr + 32);   // keys 4g..4g+3 | 16+4g..
+        // this lane's piece of its group's [4 keys][16 dims] block: key kc*32 + 4g + (ql >> 2), dims dt*16 + 4 (ql & 3) .. + 3;
+        // the read hands lane ql the four keys 4g .. 4g + 3 (and, 16 rows on, 16 + 4g ..) of dim dt*16 + ql
+        typedef short tr4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) tr4* lds_tr4;
+        const char* vr = v_lds + (size_t)(kc * 32 + 4 * g + (ql >> 2)) * VROW + (dt * 16 + 4 * (ql & 3)) * 2;
+        const tr4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)vr);
+        const tr4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr4)(vr + 16 * VROW));
+        const uint2 v0 = __builtin_bit_cast(uint2, t0), v1 = __builtin_bit_cast(uint2, t1);                     // keys 4g..4g+3 | 16+4g..
         const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4{v0.x, v0.y, v1.x, v1.y});
         if constexpr (SPLIT) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pl[kc]), o[dt], 0, 0, 0);
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, ph[kc]), o[dt], 0, 0, 0);
@@ -477,7 +486,7 @@ template <int HS, int G, int QT, bool SPLIT = true>
 void launch_flash_one(const ua2_attn_args& a, hipStream_t s) {
   constexpr auto kern = attn_flash_kernel<HS, G, QT, SPLIT>;
   ua2_allow_big_lds<kern>();
-  const size_t smem = (size_t)UA2_PAGE * (HS * 2 + 16) + (size_t)HS * (UA2_PAGE * 2 + 16);
+  const size_t smem = 2 * ((size_t)UA2_PAGE * (HS * 2 + 16) + (size_t)UA2_PAGE * (HS * 2 + 32));    // two (K, V) images
   hipLaunchKernelGGL(kern, dim3(a.n_groups, a.kv.n_kv), dim3(64 * G * QT), smem, s, a);
 }
 

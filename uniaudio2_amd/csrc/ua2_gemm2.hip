@@ -368,12 +368,13 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
 
   if constexpr (EPI == UA2_EPI_QKV_ROPE) {
     if (a.rope_mode == UA2_ROPE_HALF_SPLIT) {
-      // head size 128, no bias (the LM): the workgroup's 256 columns are two heads, a wave holds half a head in the packed
-      // (permuted) order — tile r of a head carries dims [8r, 8r + 8) and their rotation partners [64 + 8r, ..).  Parked in natural
-      // dim order ([0, 32): dims 32 half + .., [32, 64): 64 + 32 half + ..) a lane owns 4 consecutive dims of a row and finds its
+      // half-split rotation, no bias (the LM): head size 128 (trunk: the workgroup's 256 columns are two heads, a wave holds half a
+      // head) or 64 (depth decoder: four heads, a wave holds one).  In the packed (permuted) order tile r of a head carries dims
+      // [8r, 8r + 8) and their rotation partners [hs/2 + 8r, ..): a wave's four tiles are 32 low dims and their 32 partners.  Parked in
+      // natural dim order ([0, 32): the low dims, [32, 64): the partners) a lane owns 4 consecutive dims of a row and finds its
       // rotation partner 32 columns away.  Same operations as ua2_gemm.hip's staged form.
-      const int h = pn * 2 + (wn >> 1), half_id = wn & 1;
-      const int hs = 128, half = 64;
+      const int hs = a.kv.head_size, half = hs >> 1;            // 128 / 64 (the launcher admits nothing else)
+      const int h = (hs == 128) ? pn * 2 + (wn >> 1) : pn * 4 + wn, half_id = (hs == 128) ? (wn & 1) : 0;
       const bool is_q = h < a.kv.n_head, is_k = !is_q && h < a.kv.n_head + a.kv.n_kv;
       const bool rot = is_q || is_k;
       const int kvh = is_q ? 0 : (is_k ? h - a.kv.n_head : h - a.kv.n_head - a.kv.n_kv);
@@ -740,7 +741,7 @@ int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
   };
   switch (a.epilogue) {
     case UA2_EPI_QKV_ROPE: {
-      const bool lm = a.rope_mode == UA2_ROPE_HALF_SPLIT && a.kv.head_size == 128 && !a.bias;
+      const bool lm = a.rope_mode == UA2_ROPE_HALF_SPLIT && (a.kv.head_size == 128 || a.kv.head_size == 64) && !a.bias;
       const bool dit = a.rope_mode == UA2_ROPE_NONE && a.kv.head_size == 64;
       if (!(lm || dit) || !aligned16(a.q_out) || !aligned16(a.kv.k_pool) || !aligned16(a.kv.v_pool)) return 1;
       if (lm && (!aligned16(a.rope_cos) || !aligned16(a.rope_sin))) return 1;
