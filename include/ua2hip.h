@@ -200,9 +200,25 @@ typedef struct ua2_linear_args {
      outside the LM's row-invariance contract (codec DiT, AudioThinking, Mimi) and, as a plan option, LM launches of >= 2048
      rows.  bf16 only; launches outside the fast kernel's forms silently take the invariant kernels. */
   int32_t sum_order;
+  /* [v9] LayerNorm hand-over (UA2_SUM_ORDER_FREE, UA2_EPI_RESIDUAL, UA2_BF16; the codec DiT: attention.py:311-319 / :388-390 behind
+     :345-349 / :401-405).  With y_ln_w != NULL the launch also writes, for the K = N GEMM that follows,
+         y_packed = RNE_bf16( (y[m] - mean_m) * rstd_m * y_ln_w + y_ln_b ),   mean / rstd over the N columns of y[m] (eps = y_ln_eps),
+     in fragment order — F.layer_norm(y) * w + b, the operand its consumer's UA2_PRO_NORM prep launch would build (the consumer then
+     takes it as x_packed with UA2_PRO_CAST).  Where the launch runs as K slabs the combine forms it in the same pass (one launch
+     instead of combine + prep); otherwise a row pass follows the GEMM.  Only the order-free kernel implements it (N % 4 == 0,
+     N <= 2048): ua2_linear_order_free_accepts() tells a caller beforehand whether a launch will be taken; a launch that carries
+     y_ln_w and is not is an error.  The statistics are summed in this kernel's own order (fp32): same value as the prep launch's to
+     rounding, not to the bit — the order-free contract. */
+  const float* y_ln_w;
+  const float* y_ln_b;
+  float y_ln_eps;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
+/* [v9] 1 when a launch with these arguments (sum_order = UA2_SUM_ORDER_FREE) will run on the order-free kernel (csrc/ua2_gemm2.hip) as it
+ * stands — shape, alignment, the tile-count rule, scratch for K slabs; 0 when ua2_linear would take the row-invariant kernels instead.
+ * Nothing is launched. */
+int ua2_linear_order_free_accepts(const ua2_linear_args* a);
 /* Bytes of ua2_linear_args.workspace that a launch with these M, K needs (the operand rows in MFMA
  * fragment order, rows padded to 16, K padded to the chunk size). */
 size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K);

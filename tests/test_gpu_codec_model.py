@@ -448,3 +448,33 @@ def test_audio2token_skips_discarded_segments_with_identical_tokens():
     assert results[True][2] == 1 and results[False][2] == 2            # rows encoded: 1 instead of 2
     assert torch.equal(results[True][0], results[False][0]) and torch.equal(results[True][1], results[False][1])
     assert results[True][1].shape == (1, 8, plan["output_len"]) and results[True][0].shape[-1] == min(plan["output_len_reason"], 6)
+
+
+def test_dit_layernorm_handover_equals_the_prep_route_to_bf16_noise():
+    """Round 6: at one released-width window (2 x 500 rows, D = 1536) the DiT's o-projection and FF2 run as K slabs whose combine also
+    builds the next GEMM's LayerNorm-ed operand (BasicTransformerBlock.ln_handover; transformer_1d_flow.py / attention.py:311-405).
+    Against the same model with the consumers' own LayerNorm prep launches: the velocity field agrees to the DiT's bf16 noise, two
+    launches per block fewer, and the hand-over really ran (gemm2 launch count)."""
+    from uniaudio2_amd._lib import lib
+    from uniaudio2_amd.tools.tokenizer.ReasoningCodec_film.models.transformer_1d_flow import BasicTransformerBlock, Transformer1DModel
+    from codec_model_stub import module_state_dict
+    import dit_toy
+    cfg = dict(heads=24, head_dim=64, layers=3, in_channels=2 * 136 + 768, out_channels=136)
+    m = Transformer1DModel(num_attention_heads=24, attention_head_dim=64, in_channels=cfg["in_channels"], out_channels=136, num_layers=3)
+    m.load_state_dict(dit_toy.state_dict(7, cfg))
+    x = seeded_tensor((2, 500, cfg["in_channels"]), 23, std=1.0).cuda()
+    outs, counts = [], []
+    for on in (True, False):
+        BasicTransformerBlock.ln_handover = on
+        try:
+            mm = m.cuda().prepare(torch.bfloat16)
+            n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+            outs.append(mm(x, 0.4, use_graph=False).float().cpu().numpy())
+            counts.append(lib.ua2_debug_kernel_launches(b"gemm2") - n0)
+        finally:
+            BasicTransformerBlock.ln_handover = True
+    a, b = outs
+    rel = float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    print(f"DiT 2 x 500 rows, LayerNorm hand-over vs prep launches: relative rms {rel:.3e}; gemm2 launches {counts}")
+    assert rel < 1e-2, rel
+    assert counts[0] == counts[1] + 3, counts             # the o-projection (48 tiles: ua2_gemm.hip without the hand-over) joins as K slabs, once per block

@@ -405,3 +405,66 @@ def test_tail_split_of_a_grid_with_a_thin_last_round(g2env):
     assert ((ssq - ssqw).abs() <= 1e-5 * ssqw.abs() + 1e-6).all()
     _close(pk.view(torch.bfloat16), pkw.view(torch.bfloat16), K, "tail hand-over operand")
     assert (ssq > 0).all()
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1000, 1536, 1536, True), (1000, 1536, 6144, True), (4100, 1536, 1536, False)])
+def test_layernorm_handover_of_residual_launches(M, N, K, split, g2env):
+    """Round 6 (ua2hip.h y_ln_w): a RESIDUAL launch under the order-free contract also writes the LayerNorm-ed, modulated, bf16-packed
+    operand of the GEMM that follows — from the K-split combine where the launch runs as slabs (the DiT's o-projection and FF2 at one
+    window: attention.py:345-349 -> :388-390, :401-405 -> the next block's :311-319), from a row pass otherwise.  y equals the plain
+    launch's bit for bit; a consumer fed the packed operand (PRO_CAST) agrees with the same consumer running its own LayerNorm prep
+    (PRO_NORM) on y to a bf16 rounding flip; ua2_linear_order_free_accepts agrees with what the launcher then does."""
+    import ctypes
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, EPI_STORE, NORM_LAYERNORM, PRO_CAST, PRO_NORM, SUM_ORDER_FREE, lib
+    dev, dt = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator().manual_seed(M + K)
+    mk = lambda *shape, s=1.0: (s * torch.randn(*shape, generator=g)).to(dev)
+    w = ops.pack_linear(mk(N, K, s=K ** -0.5), dt)
+    wc = ops.pack_linear(mk(1024, N, s=N ** -0.5), dt)
+    x, res, bias, gate = mk(M, K), mk(M, N, s=2.0), mk(N, s=0.3), mk(N, s=0.5)
+    lw, lb = 1.0 + mk(N, s=0.2), mk(N, s=0.2)
+    xp = ops.linear_workspace(dt, M, K, dev)
+    g2env()
+    ops.linear(dtype=dt, M=M, N=64, K=K, w0=ops.pack_linear(mk(64, K), dt), prologue=PRO_CAST, epilogue=EPI_STORE, x=x, y=torch.empty(M, 64, device=dev),
+               workspace=xp)                                                  # leaves the packed operand in xp
+
+    def run(ln):
+        y = torch.zeros(M, N, device=dev)
+        sw = torch.full((4 * M * N,), float("nan"), device=dev)
+        pk = ops.linear_workspace(dt, M, N, dev).zero_() if ln else None
+        kw = dict(y_ln=(lw, lb, 1e-6), y_packed=pk) if ln else {}
+        a = ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x_packed=xp, y=y, resid=res, bias=bias, out_scale=gate,
+                       split_ws=sw, sum_order=SUM_ORDER_FREE, launch=False, **kw)
+        # without the hand-over 48 tiles of K = 1536 are too few for the kernel and too short for slabs: ua2_gemm.hip takes the launch
+        takes = 0 if (not ln and M == 1000 and K == 1536) else 1
+        assert lib.ua2_linear_order_free_accepts(ctypes.byref(a)) == takes
+        n0 = lib.ua2_debug_kernel_launches(b"gemm2")
+        ops.linear(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x_packed=xp, y=y, resid=res, bias=bias, out_scale=gate,
+                   split_ws=sw, sum_order=SUM_ORDER_FREE, **kw)
+        torch.cuda.synchronize()
+        assert lib.ua2_debug_kernel_launches(b"gemm2") - n0 == takes
+        return y, pk, bool((~torch.isnan(sw)).any())
+
+    y0, _, used0 = run(False)
+    y1, pk, used1 = run(True)
+    assert used1 == split                                                     # the K slabs ran (or, at 4100 rows, did not)
+    if used0 == used1:
+        assert torch.equal(y0, y1)                                            # same slabs, same combine arithmetic
+    else:
+        assert (y0 - y1).abs().max().item() < 2e-5 * K ** 0.5                 # the hand-over lowered the split's K threshold (K = 1536)
+    z_pk, z_ln = torch.zeros(M, 1024, device=dev), torch.zeros(M, 1024, device=dev)
+    ops.linear(dtype=dt, M=M, N=1024, K=N, w0=wc, prologue=PRO_CAST, epilogue=EPI_STORE, x_packed=pk, y=z_pk, sum_order=SUM_ORDER_FREE)
+    ops.linear(dtype=dt, M=M, N=1024, K=N, w0=wc, prologue=PRO_NORM, epilogue=EPI_STORE, x=y1, norm_w=lw, norm_b=lb, eps=1e-6, norm_kind=NORM_LAYERNORM,
+               y=z_ln, workspace=ops.linear_workspace(dt, M, N, dev), sum_order=SUM_ORDER_FREE)
+    torch.cuda.synchronize()
+    d = (z_pk - z_ln).abs()
+    assert d.max().item() < 0.25 and d.double().pow(2).mean().sqrt().item() < 1e-2, (d.max().item(), d.double().pow(2).mean().sqrt().item())
+    assert z_pk.abs().sum() > 0 and torch.isfinite(z_pk).all()
+    # a launch the order-free kernel does not take refuses the hand-over instead of dropping it
+    a = ops.linear(dtype=dt, M=64, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x[:64].contiguous(), y=y0[:64], resid=res[:64].contiguous(),
+                   y_ln=(lw, lb, 1e-6), y_packed=pk, workspace=ops.linear_workspace(dt, 64, K, dev), sum_order=SUM_ORDER_FREE, launch=False)
+    assert lib.ua2_linear_order_free_accepts(ctypes.byref(a)) == 0
+    with pytest.raises(Exception, match="y_ln_w"):
+        ops.linear(dtype=dt, M=64, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x[:64].contiguous(), y=y0[:64].contiguous(), resid=res[:64].contiguous(),
+                   y_ln=(lw, lb, 1e-6), y_packed=pk, workspace=ops.linear_workspace(dt, 64, K, dev), sum_order=SUM_ORDER_FREE)

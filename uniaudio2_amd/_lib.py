@@ -44,7 +44,8 @@ class LinearArgs(C.Structure):
                 ("workspace", vp), ("workspace_bytes", C.c_size_t), ("y_packed", vp), ("x_packed", vp),
                 ("bias", vp), ("bias1", vp), ("act_kind", i32),
                 ("y_norm_w", vp), ("y_h", vp), ("ldh", i32), ("y_ssq", vp), ("x_h", vp), ("x_ssq", vp),
-                ("split_ws", vp), ("split_ws_bytes", C.c_size_t), ("sum_order", i32)]
+                ("split_ws", vp), ("split_ws_bytes", C.c_size_t), ("sum_order", i32),
+                ("y_ln_w", vp), ("y_ln_b", vp), ("y_ln_eps", f32)]
 
 
 class AttnArgs(C.Structure):
@@ -96,6 +97,7 @@ _EXPORTS = {
     "ua2_packed_elems": (C.c_size_t, [C.c_int, i64, i64]),
     "ua2_pack_linear": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, vp, C.c_int, C.c_int, vp]),
     "ua2_linear": (C.c_int, [C.POINTER(LinearArgs), vp]),
+    "ua2_linear_order_free_accepts": (C.c_int, [C.POINTER(LinearArgs)]),
     "ua2_debug_force_general_linear": (C.c_int, [C.c_int]),
     "ua2_debug_kernel_launches": (i64, [C.c_char_p]),
     "ua2_debug_refresh_env": (None, []),

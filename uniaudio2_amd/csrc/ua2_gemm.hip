@@ -1165,6 +1165,8 @@ int launch_dt(const ua2_linear_args& a, hipStream_t s, int force) {
 #endif
   if (order_free)
     if (const int rc = ua2_gemm2_try_launch(a, s); rc <= 0) return rc;
+  UA2_CHECK(!a.y_ln_w, "ua2_linear: the LayerNorm hand-over (y_ln_w) is a form of the order-free kernel, which does not take this launch "
+                       "(M=%d N=%d K=%d: ask ua2_linear_order_free_accepts first)", a.M, a.N, a.K);
   const bool skinny_ok = geo.waves * nt * kSkinnyMT * 1024 <= 128 * 1024;
   // The weights-stationary form (ua2_skinny.hip) serves the model's bf16 shapes up to a few hundred rows: measured against
   // the tiled kernel it wins up to 256 rows everywhere except the 128k-column lm_head (profiles/r3_skinny_sweep.txt).

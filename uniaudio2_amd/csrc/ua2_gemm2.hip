@@ -598,6 +598,69 @@ __global__ __launch_bounds__(256) void gemm2_tail_combine_kernel(const ua2_linea
   g2_finish<UA2_EPI_RESIDUAL>(a, m, n, s4, zero4, cb0, zero4, cos4, 1.f, r4, live, 0);
 }
 
+// LayerNorm hand-over (ua2hip.h y_ln_w).  slabs > 0: the K-split combine and the next GEMM's LayerNorm prep in ONE pass — y = resid +
+// out_scale (.) (sum of the slabs in index order + bias), stored, and RNE_bf16(LayerNorm(y) * w + b) written in fragment order (the
+// DiT's o-projection / FF2: the prep launch of FF1 / the next block's q|k|v disappears).  slabs == 0: y is already complete (no K split,
+// or a tail split): the LayerNorm pass alone.  A WORKGROUP per row — one 4-column piece per thread, N / 4 threads rounded up to whole
+// waves, statistics through LDS; norm_stat / norm_apply's formulas.  (A wave per row, six pieces per lane, was measured first: 14 us
+// for 1000 rows against ~5.5 — each of a row's steps is a memory round trip (the slabs were written by other XCDs' workgroups: every
+// load misses this XCD's L2) and with one wave per SIMD nothing overlapped them: DiT step 5.17 vs 4.89 ms, profiles/r6_notes.md §6.)
+__global__ __launch_bounds__(512) void gemm2_combine_ln_row_kernel(const ua2_linear_args a, const int slabs) {
+  __shared__ float red_s[2][8];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int n = 4 * tid;
+  const bool live = n < a.N;
+  const int nc = min(n, a.N - 4);
+  const size_t slab_elems = (size_t)a.M * a.N;
+  float4 t;
+  if (slabs > 0) {
+    const float* q = a.split_ws + (size_t)m * a.N + nc;
+    t = *reinterpret_cast<const float4*>(q);
+    float4 u[3];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) u[k - 1] = (k < slabs) ? *reinterpret_cast<const float4*>(q + (size_t)k * slab_elems) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 r = *reinterpret_cast<const float4*>(a.resid + (size_t)m * a.ldr + nc);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      if (k >= slabs) break;
+      t.x = __fadd_rn(t.x, u[k - 1].x); t.y = __fadd_rn(t.y, u[k - 1].y); t.z = __fadd_rn(t.z, u[k - 1].z); t.w = __fadd_rn(t.w, u[k - 1].w);
+    }
+    if (a.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + nc);
+      t.x = __fadd_rn(t.x, b.x); t.y = __fadd_rn(t.y, b.y); t.z = __fadd_rn(t.z, b.z); t.w = __fadd_rn(t.w, b.w);
+    }
+    if (a.out_scale) {
+      const float4 g = *reinterpret_cast<const float4*>(a.out_scale + nc);
+      t.x = __fmul_rn(g.x, t.x); t.y = __fmul_rn(g.y, t.y); t.z = __fmul_rn(g.z, t.z); t.w = __fmul_rn(g.w, t.w);
+    }
+    t.x = __fadd_rn(t.x, r.x); t.y = __fadd_rn(t.y, r.y); t.z = __fadd_rn(t.z, r.z); t.w = __fadd_rn(t.w, r.w);
+    if (live) *reinterpret_cast<float4*>(a.y + (size_t)m * a.ldy + n) = t;
+  } else {
+    t = *reinterpret_cast<const float4*>(a.y + (size_t)m * a.ldy + nc);
+  }
+  if (!live) t = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the norm weights of this thread's columns travel while the statistics are reduced
+  const float4 w = *reinterpret_cast<const float4*>(a.y_ln_w + nc);
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.y_ln_b) b = *reinterpret_cast<const float4*>(a.y_ln_b + nc);
+  float sm = sum4(0.f, t), ss = sumsq4(0.f, t);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { sm += __shfl_xor(sm, o); ss += __shfl_xor(ss, o); }
+  if (lane == 0) { red_s[0][wave] = sm; red_s[1][wave] = ss; }
+  __syncthreads();
+  sm = 0.f; ss = 0.f;
+  for (int i = 0; i < nw; ++i) { sm += red_s[0][i]; ss += red_s[1][i]; }       // every thread, wave order
+  const float mean = sm / (float)a.N;
+  const float rstd = 1.0f / sqrtf(fmaxf(__fsub_rn(ss / (float)a.N, __fmul_rn(mean, mean)), 0.f) + a.y_ln_eps);
+  if (!live) return;
+  float4 o4;
+  o4.x = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t.x, mean), rstd), w.x), b.x);
+  o4.y = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t.y, mean), rstd), w.y), b.y);
+  o4.z = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t.z, mean), rstd), w.z), b.z);
+  o4.w = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t.w, mean), rstd), w.w), b.w);
+  store_packed4<UA2_BF16>(a.y_packed, m, n, a.N / 32, o4);
+}
+
 // UA2_PRO_SCALED consumers: one scale per row, reduced from the producer's per-16-column partials in the one order every kernel uses
 // (scaled_rstd_row: 16 interleaved chains + butterfly) — a launch of M / 16 workgroups in front of the GEMM instead of 16 lanes per
 // row and column block inside it
@@ -612,7 +675,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Tuning / A-B knobs: read once (ua2_common.h Ua2EnvInt; ua2_debug_refresh_env re-reads them — the tests toggle some)
 Ua2EnvInt g_group_m{"UA2_GEMM2_GROUP_M", 8}, g_ks_min_chunks{"UA2_GEMM2_KSPLIT_MIN_CHUNKS", 96}, g_ks_max_grid{"UA2_GEMM2_KSPLIT_MAX_GRID", 128},
     g_no_ksplit{"UA2_GEMM_NO_KSPLIT", 0}, g_bmt{"UA2_GEMM2_BMT", 0}, g_deep_max_grid{"UA2_GEMM2_DEEP_MAX_GRID", 256}, g_no_deep{"UA2_GEMM2_NO_DEEP", 0},
-    g_off{"UA2_GEMM2_OFF", 0}, g_min_rows{"UA2_GEMM2_MIN_ROWS", 256}, g_no_tail{"UA2_GEMM2_NO_TAIL", 0}, g_tail_min_chunks{"UA2_GEMM2_TAIL_MIN_CHUNKS", 128}, g_no_new{"UA2_GEMM2_R5_FORMS", 0};
+    g_off{"UA2_GEMM2_OFF", 0}, g_min_rows{"UA2_GEMM2_MIN_ROWS", 256}, g_no_tail{"UA2_GEMM2_NO_TAIL", 0}, g_ks_max{"UA2_GEMM2_KSPLIT_MAX", 4}, g_tail_min_chunks{"UA2_GEMM2_TAIL_MIN_CHUNKS", 128}, g_no_new{"UA2_GEMM2_R5_FORMS", 0};
 
 // Instantiations: BMT = 16 / four slots (one workgroup per CU), BMT = 8 / three slots (two per CU, 128 registers) and BMT = 8 / six
 // slots (small grids), all without s_setprio.  -DUA2_G2_EXPERIMENTS adds the s_setprio variant and free choice of the ring behind
@@ -631,8 +694,11 @@ int launch2(const ua2_linear_args& a, hipStream_t s, const float* rstd, const bo
   const int64_t t16 = (int64_t)ua2_ceil_div(mtiles, 16) * nblocks, t8 = (int64_t)ua2_ceil_div(mtiles, 8) * nblocks;
   auto slabs_for = [&](int64_t grid) {
     if constexpr (EPI == UA2_EPI_RESIDUAL) {
-      if (a.split_ws && nchunks >= g_ks_min_chunks.get() && grid <= g_ks_max_grid.get() && !g_no_ksplit.set()) {
-        const int want = (int)std::min<int64_t>(4, (256 + grid - 1) / grid);
+      // (with the LayerNorm hand-over the combine also replaces the consumer's prep launch: the split pays from 36 chunks of K — the DiT's
+      // o-projection, K = 1536 — where without it it does not, profiles/r4_notes.md §13)
+      const int min_chunks = a.y_ln_w ? std::min(36, g_ks_min_chunks.get()) : g_ks_min_chunks.get();
+      if (a.split_ws && nchunks >= min_chunks && grid <= g_ks_max_grid.get() && !g_no_ksplit.set()) {
+        const int want = (int)std::min<int64_t>(std::min(g_ks_max.get(), nchunks / 12), (256 + grid - 1) / grid);
         const int fit = (int)std::min<size_t>(4, a.split_ws_bytes / ((size_t)a.M * a.N * sizeof(float)));
         return std::max(1, std::min(want, fit));
       }
@@ -695,13 +761,23 @@ int launch2(const ua2_linear_args& a, hipStream_t s, const float* rstd, const bo
 #endif
   };
   launch_form(grid1, ks, flags, 0);
-  if (flags & 2) {
-    const size_t total4 = (size_t)a.M * (a.N / 4);
-    hipLaunchKernelGGL(gemm2_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
-  }
-  if (tail) {
-    launch_form(tail, tail_ks, 4, (int)grid1);
-    hipLaunchKernelGGL(gemm2_tail_combine_kernel, dim3((unsigned)(tail * (bmt * 16 / 4))), dim3(256), 0, s, a, tail_ks, tail, (int)grid1, mblocks, nblocks, group_m, bmt);
+  auto ln_pass = [&](int slabs) {                       // ua2hip.h y_ln_w: combine + LayerNorm prep in one launch (slabs > 0), or the LayerNorm pass alone
+    hipLaunchKernelGGL(gemm2_combine_ln_row_kernel, dim3((unsigned)a.M), dim3((unsigned)(ua2_ceil_div(a.N / 4, 64) * 64)), 0, s, a, slabs);
+  };
+  bool ln_done = false;
+  if constexpr (EPI == UA2_EPI_RESIDUAL) {
+    if (flags & 2) {
+      if (a.y_ln_w) { ln_pass(ks); ln_done = true; }
+      else {
+        const size_t total4 = (size_t)a.M * (a.N / 4);
+        hipLaunchKernelGGL(gemm2_combine_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s, a, ks);
+      }
+    }
+    if (tail) {
+      launch_form(tail, tail_ks, 4, (int)grid1);
+      hipLaunchKernelGGL(gemm2_tail_combine_kernel, dim3((unsigned)(tail * (bmt * 16 / 4))), dim3(256), 0, s, a, tail_ks, tail, (int)grid1, mblocks, nblocks, group_m, bmt);
+    }
+    if (a.y_ln_w && !ln_done) ln_pass(0);
   }
   UA2_LAUNCH_CHECK();
   return 0;
@@ -711,7 +787,7 @@ int launch2(const ua2_linear_args& a, hipStream_t s, const float* rstd, const bo
 
 // 0 = launched, 1 = this launch is outside the kernel's forms (the caller goes on to ua2_gemm.hip's kernels).  The operand is
 // already packed (x_packed, or the prep launch into workspace).
-int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
+static int gemm2_try(const ua2_linear_args& a, hipStream_t s, const bool dry_run) {
   if (a.dtype != UA2_BF16 || g_off.set()) return 1;
   if (a.M < g_min_rows.get() || a.K % 32 != 0) return 1;
   const bool glu = a.epilogue == UA2_EPI_SWIGLU;
@@ -727,6 +803,11 @@ int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
     if ((a.epilogue != UA2_EPI_RESIDUAL && a.epilogue != UA2_EPI_STORE) || a.N % 16 != 0 || !a.y_ssq || !aligned16(a.y_norm_w)) return 1;
     if ((a.y_h && (a.ldh % 4 != 0 || (reinterpret_cast<uintptr_t>(a.y_h) & 7))) || (a.y_packed && !aligned16(a.y_packed))) return 1;
   }
+  if (a.y_ln_w) {                                               // LayerNorm hand-over: RESIDUAL, a wave per row of up to 2048 columns
+    if (a.epilogue != UA2_EPI_RESIDUAL || a.y_norm_w || a.N > 2048 || a.N % 32 != 0 || !a.y_packed || !aligned16(a.y_packed) || !aligned16(a.y_ln_w) ||
+        (a.y_ln_b && !aligned16(a.y_ln_b)))
+      return 1;
+  }
   const float* rstd = nullptr;
   if (a.prologue == UA2_PRO_SCALED) {                           // consumer half: one scale per row, reduced by a launch in front, into the workspace
     if (!a.x_packed || !a.x_ssq || !a.workspace || a.workspace == a.x_packed || a.workspace_bytes < (size_t)a.M * sizeof(float)) return 1;
@@ -734,6 +815,7 @@ int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
     rstd = reinterpret_cast<const float*>(a.workspace);
   }
   auto with_rstd = [&](auto launch) -> int {
+    if (dry_run) return launch(true);
     if (!rstd) return launch(false);
     if (launch(true)) return 1;                                 // the grid rule turns the problem down: nothing issued
     hipLaunchKernelGGL(gemm2_rstd_kernel, dim3(ua2_ceil_div(a.M, 16)), dim3(256), 0, s, a, reinterpret_cast<float*>(a.workspace));
@@ -754,7 +836,7 @@ int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
     case UA2_EPI_RESIDUAL:
       if (rstd) return 1;
       if (a.ldy % 4 || a.ldr % 4 || !aligned16(a.y) || !aligned16(a.resid) || (a.out_scale && !aligned16(a.out_scale))) return 1;
-      return launch2<UA2_EPI_RESIDUAL>(a, s, nullptr);
+      return launch2<UA2_EPI_RESIDUAL>(a, s, nullptr, dry_run);
     case UA2_EPI_SWIGLU:
     case UA2_EPI_GELU:
       if (a.y && (a.ldy % 4 || !aligned16(a.y))) return 1;
@@ -762,4 +844,14 @@ int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) {
       return with_rstd([&](bool dry) { return glu ? launch2<UA2_EPI_SWIGLU>(a, s, rstd, dry) : launch2<UA2_EPI_GELU>(a, s, rstd, dry); });
     default: return 1;
   }
+}
+
+int ua2_gemm2_try_launch(const ua2_linear_args& a, hipStream_t s) { return gemm2_try(a, s, false); }
+
+// ua2hip.h: would ua2_linear run this launch on the order-free kernel?  (The operand must be given packed or a workspace for the prep
+// launch supplied, as for every many-row launch.)
+extern "C" int ua2_linear_order_free_accepts(const ua2_linear_args* a) {
+  if (!a || a->sum_order != UA2_SUM_ORDER_FREE || a->M <= 0 || a->N <= 0 || a->K <= 0) return 0;
+  if (!a->x_packed && (!a->workspace || a->workspace_bytes < ua2_linear_workspace_bytes(a->dtype, a->M, a->K))) return 0;
+  return gemm2_try(*a, nullptr, true) == 0 ? 1 : 0;
 }

@@ -66,6 +66,9 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
                   (a.y_h || a.y_packed) && (!a.y_h || a.ldh % 8 == 0),
               "ua2_linear: y_norm_w hand-over needs UA2_BF16, a RESIDUAL / STORE epilogue, N %% 32 == 0, y_ssq and y_h (ldh %% 8 == 0) or y_packed");
   }
+  if (a.y_ln_w)     // LayerNorm hand-over: the order-free kernel's form only (ua2_linear_order_free_accepts tells a caller beforehand)
+    UA2_CHECK(a.dtype == UA2_BF16 && a.sum_order == UA2_SUM_ORDER_FREE && a.epilogue == UA2_EPI_RESIDUAL && a.y_packed && !a.y_norm_w && a.N % 32 == 0,
+              "ua2_linear: y_ln_w needs UA2_BF16, UA2_SUM_ORDER_FREE, a RESIDUAL epilogue, y_packed and N %% 32 == 0");
   if (a.prologue == UA2_PRO_SCALED) {
     UA2_CHECK(a.dtype == UA2_BF16 && a.K % 32 == 0 && a.K <= 4096 && a.x_ssq && (a.x_h || a.x_packed) && (!a.x_h || a.ldh % 8 == 0),
               "ua2_linear: UA2_PRO_SCALED needs UA2_BF16, K %% 32 == 0, K <= 4096, x_ssq and x_h (ldh %% 8 == 0) or x_packed");
@@ -105,7 +108,7 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s) {
     UA2_CHECK(a.w1 != nullptr && (a.y != nullptr || a.y_packed != nullptr), "ua2_linear: SWIGLU needs w1 and y or y_packed");
     UA2_CHECK(!a.y_packed || a.N % (a.dtype == UA2_BF16 ? 32 : 16) == 0, "ua2_linear: y_packed needs N %% chunk == 0");
   } else if (a.epilogue != UA2_EPI_GELU) {
-    UA2_CHECK(!a.y_packed || a.y_norm_w, "ua2_linear: y_packed is a SWIGLU / GELU output (or, with y_norm_w, a RESIDUAL / STORE hand-over)");
+    UA2_CHECK(!a.y_packed || a.y_norm_w || a.y_ln_w, "ua2_linear: y_packed is a SWIGLU / GELU output (or, with y_norm_w / y_ln_w, a RESIDUAL / STORE hand-over)");
   }
   if (a.epilogue == UA2_EPI_RESIDUAL) UA2_CHECK(a.resid != nullptr && a.y != nullptr, "ua2_linear: RESIDUAL needs resid, y");
   if (a.epilogue == UA2_EPI_STORE) UA2_CHECK(a.y != nullptr || a.part_max != nullptr, "ua2_linear: STORE needs y or part_max");

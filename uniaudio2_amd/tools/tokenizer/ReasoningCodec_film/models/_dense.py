@@ -46,8 +46,14 @@ class PackedLinear:
         if w1 is not None:
             extra.update(w1=w1.w, bias1=w1.b)
         kw.setdefault("sum_order", self.sum_order)
-        ops.linear(dtype=self.dtype, M=M, N=self.N, K=self.K, w0=self.w, epilogue=epilogue, x=x, ldx=self.K, y=y, ldy=(self.N if y is not None else 0), resid=resid,
-                   ldr=(self.N if resid is not None else None), out_scale=out_scale, bias=self.b, act_kind=act_kind, workspace=ws, **extra, **kw)
+        probe = kw.pop("probe", False)     # True: launch nothing, return whether the order-free kernel would take this launch (ua2hip.h)
+        a = ops.linear(dtype=self.dtype, M=M, N=self.N, K=self.K, w0=self.w, epilogue=epilogue, x=x, ldx=self.K, y=y, ldy=(self.N if y is not None else 0), resid=resid,
+                       ldr=(self.N if resid is not None else None), out_scale=out_scale, bias=self.b, act_kind=act_kind, workspace=ws, launch=not probe,
+                       **extra, **kw)
+        if probe:
+            import ctypes
+            from ....._lib import lib
+            return bool(lib.ua2_linear_order_free_accepts(ctypes.byref(a)))
         return y if y is not None else kw.get("q_out")
 
 

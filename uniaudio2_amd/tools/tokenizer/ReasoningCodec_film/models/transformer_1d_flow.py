@@ -108,20 +108,28 @@ class BasicTransformerBlock(nn.Module):
                        ff2=PackedLinear(self.ff.net[2].weight, self.ff.net[2].bias, dtype),
                        table=self.scale_shift_table.detach().float().contiguous().view(-1), dtype=dtype)
 
-    def run(self, h, ts, kv: DenseKV, mod=None, mod1=None):
+    ln_handover = True         # tests / A-B: False keeps the consumer's own LayerNorm prep launches (env UA2_DIT_NO_LN_HANDOVER=1 likewise)
+
+    def run(self, h, ts, kv: DenseKV, mod=None, mod1=None, x_packed=None, nxt=None):
         """h [B*T, D] fp32 rows (in place); ts [6*D] = adaln_single.linear(silu(t_emb)) of this step (one timestep for the
         whole batch, as solve_euler passes it).  mod / mod1: this block's (6, D) slices of `table + ts` and `1 + (table + ts)`
-        when the caller computed them for all blocks in two launches (same operations, same order)."""
+        when the caller computed them for all blocks in two launches (same operations, same order).
+        x_packed: this block's q|k|v operand, LayerNorm-ed and packed by the previous block's FF2 launch (LayerNorm hand-over,
+        ua2hip.h y_ln_w); nxt = (1 + scale, shift) of the NEXT block's first LayerNorm: this block's FF2 then builds that operand.
+        Returns (h, operand for the next block or None)."""
         p, D = self._p, self.dim
         if mod is None:
             mod = ops.ew_fma(p["table"], c=ts)                               # table + timestep  -> (6, D)
             mod1 = ops.ew_fma(mod, beta=1.0)
         sh_a, _, g_a, sh_m, _, g_m = (mod[i * D:(i + 1) * D] for i in range(6))
         w_a, w_m = mod1[D:2 * D], mod1[4 * D:5 * D]                          # 1 + scale
-        q = torch.empty(h.shape[0], D, dtype=torch.float32, device=h.device)
-        p["qkv"](h, epilogue=EPI_QKV_ROPE, norm=(w_a, sh_a, self.eps), rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq,
-                 q_out=q, kv=kv.geom)
         M = h.shape[0]
+        q = torch.empty(M, D, dtype=torch.float32, device=h.device)
+        if x_packed is not None:
+            p["qkv"](None, M=M, x_packed=x_packed, epilogue=EPI_QKV_ROPE, rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq, q_out=q, kv=kv.geom)
+        else:
+            p["qkv"](h, epilogue=EPI_QKV_ROPE, norm=(w_a, sh_a, self.eps), rope_mode=ROPE_NONE, row_pos=kv.row_pos, row_seq=kv.row_seq,
+                     q_out=q, kv=kv.geom)
         # scratch for the K split of FF2 (ua2hip.h split_ws: K = 4 D on a 1000-row problem leaves 3/4 of the device's workgroup slots
         # empty; four slabs side by side + a combine launch, fixed order).  One buffer per K/V plan, shared by the blocks.
         if getattr(kv, "split_ws", None) is None or kv.split_ws.numel() < 4 * M * D:
@@ -131,15 +139,38 @@ class BasicTransformerBlock(nn.Module):
             # the consumer's own prep launch would apply: identical bits, two launches less per layer)
             ws_o, ws_f = ops.linear_workspace(p["dtype"], M, D, h.device), ops.linear_workspace(p["dtype"], M, p["ff2"].K, h.device)
             kv.attend(q, y_packed=ws_o)
+            # LayerNorm hand-over (order-free plan; round 6): the o-projection and FF2 run as K slabs whose combine ALSO normalises,
+            # modulates and packs the rows for FF1 / the next block's q|k|v — the two LayerNorm prep launches per block go.  Asked
+            # of the library once per (plan, launch shape): ua2_linear_order_free_accepts.
+            want = bool(self.ln_handover and p["out"].sum_order != 0 and not os.environ.get("UA2_DIT_NO_LN_HANDOVER"))
+            cached = getattr(kv, "ln_ok", None)
+            if cached is None or cached[0] != want:
+                probe = dict(M=M, epilogue=EPI_RESIDUAL, resid=h, y=h, split_ws=kv.split_ws, y_ln=(w_m, sh_m, self.eps), probe=True)
+                cached = kv.ln_ok = (want, bool(want and p["out"](None, x_packed=ws_o, out_scale=g_a, y_packed=ws_o, **probe) and
+                                               p["ff2"](None, x_packed=ws_f, out_scale=g_m, y_packed=ws_o, **probe)))
+            ok = cached[1]
+            nxt_packed = None
+            if ok:
+                ws_n = ops.linear_workspace(p["dtype"], M, D, h.device)
+                p["out"](None, M=M, x_packed=ws_o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h, split_ws=kv.split_ws,
+                         y_ln=(w_m, sh_m, self.eps), y_packed=ws_n)
+                p["ff1"](None, M=M, x_packed=ws_n, epilogue=EPI_GELU, act_kind=GELU_TANH, y_packed=ws_f)
+                if nxt is not None:
+                    nxt_packed = ops.linear_workspace(p["dtype"], M, D, h.device)
+                    p["ff2"](None, M=M, x_packed=ws_f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h, split_ws=kv.split_ws,
+                             y_ln=(nxt[0], nxt[1], self.eps), y_packed=nxt_packed)
+                else:
+                    p["ff2"](None, M=M, x_packed=ws_f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h, split_ws=kv.split_ws)
+                return h, nxt_packed
             p["out"](None, M=M, x_packed=ws_o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
             p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH, y_packed=ws_f)
             p["ff2"](None, M=M, x_packed=ws_f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h, split_ws=kv.split_ws)
-            return h
+            return h, None
         o = kv.attend(q)
         p["out"](o, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_a, y=h)
         f = p["ff1"](h, epilogue=EPI_GELU, norm=(w_m, sh_m, self.eps), act_kind=GELU_TANH)
         p["ff2"](f, epilogue=EPI_RESIDUAL, resid=h, out_scale=g_m, y=h, split_ws=kv.split_ws)
-        return h
+        return h, None
 
 
 class _TimestepEmbedding(nn.Module):
@@ -256,8 +287,14 @@ class Transformer1DModel(nn.Module):
         ts, e = self.adaln_single.run(emb)
         mod_all = ops.ew_fma(self._table_all, c=ts)                           # every block's table + timestep in one launch (was 3 per block)
         mod1_all = ops.ew_fma(mod_all, beta=1.0)
+        xp = None
+        nb = len(self.transformer_blocks)
         for l, blk in enumerate(self.transformer_blocks):
-            blk.run(h, ts, self._kv, mod_all[l * 6 * D:(l + 1) * 6 * D], mod1_all[l * 6 * D:(l + 1) * 6 * D])
+            nxt = None
+            if l + 1 < nb:                                                    # (1 + scale, shift) of the next block's first LayerNorm
+                o = (l + 1) * 6 * D
+                nxt = (mod1_all[o + D:o + 2 * D], mod_all[o:o + D])
+            _, xp = blk.run(h, ts, self._kv, mod_all[l * 6 * D:(l + 1) * 6 * D], mod1_all[l * 6 * D:(l + 1) * 6 * D], x_packed=xp, nxt=nxt)
         mod = ops.ew_fma(self._table, c=e)                                    # (2, D): scale_shift_table + embedded_timestep  :378
         shift, scale = mod[:D], mod[D:]
         hn = ops.layernorm_rows(h, None, None, 1e-6)                          # norm_out :379
