@@ -30,7 +30,7 @@ PROMPT_LEN = 33
 FRAMES = 74
 SEM_CARD, REASON_CARD = 8196, 4100          # V_a = 12296 (placeholder sizes; the real ones live in a yaml not in the repo)
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-PMC_SWIGLU_TRAFFIC = 100815040              # bytes per launch, profiles/r5_pmc_swiglu.txt (refreshed every round by tools/final_round_run.sh)
+PMC_SWIGLU_TRAFFIC = 100813552              # bytes per launch, profiles/r6_pmc_swiglu.txt (refreshed every round by tools/final_round_run.sh)
 
 
 SCALAR_CFG = dict(num_bands=1, sample_rate=24000, causal=True, num_samples=2, downsample_factors=[2, 4, 4, 5, 3],
@@ -118,9 +118,9 @@ def roofline_leg(model):
     achieved = per_launch_bytes / (ms * 1e-3) / 1e9
     return {"kernel": "gemv_kernel<1, 4, 2, 4, true> (scaled-RMSNorm + fc_1/fc_2 + SwiGLU GEMV, 3072 -> 2x8192, bf16)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # HBM read bytes per launch from a separate PMC pass on this kernel and shape (profiles/r5_pmc_swiglu.txt:
+            # HBM read bytes per launch from a separate PMC pass on this kernel and shape (profiles/r6_pmc_swiglu.txt:
             # rocprofv3 --pmc FETCH_SIZE, x 1024 x 2 — the gfx950 half-count correction of MI355X_MICROARCH.md §HBM)
-            "traffic": PMC_SWIGLU_TRAFFIC, "traffic_source": "profiles/r5_pmc_swiglu.txt (rocprofv3 --pmc FETCH_SIZE pass of round 5 on this kernel and shape, tools/final_round_run.sh; "
+            "traffic": PMC_SWIGLU_TRAFFIC, "traffic_source": "profiles/r6_pmc_swiglu.txt (rocprofv3 --pmc FETCH_SIZE pass of round 6 on this kernel and shape, tools/final_round_run.sh; "
                                                               "counters are collected in their own run, not inside bench.py)",
             "launches_per_frame": len(args), "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_bytes_per_launch": int(per_launch_bytes)}

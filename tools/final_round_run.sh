@@ -25,13 +25,19 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -- python $R/bench.py --no-c
 for leg in batched batched256 config3 stage2; do
   rocprofv3 --kernel-trace --stats -d $OUT/prof_$leg -- python $R/tools/ubench/prof_legs.py $leg > $OUT/leg_$leg.log 2>&1
 done
+# round 6: the order-free legs and the one-window DiT step, launch by launch
+UA2_ORDER_FREE_ROWS=2048 rocprofv3 --kernel-trace --stats -d $OUT/prof_config3_of -- python $R/tools/ubench/prof_legs.py config3 > $OUT/leg_config3_of.log 2>&1
+UA2_ORDER_FREE_ROWS=1024 rocprofv3 --kernel-trace --stats -d $OUT/prof_batched1024_of -- python $R/tools/ubench/prof_legs.py batched1024 > $OUT/leg_batched1024_of.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_dit -- python $R/tools/ubench/dit_step_profile.py 20 > $OUT/leg_dit.log 2>&1
 cd $R
 python tools/rocpd_stats.py $(find $OUT/prof_codec -name "*.db" | head -1) > $OUT/codec_kernel_stats.txt 2>/dev/null
 python tools/rocpd_stats.py $(find $OUT/prof_bench -name "*.db" | head -1) > $OUT/bench_kernel_stats.txt 2>/dev/null
-for leg in batched batched256 config3 stage2; do
+for leg in batched batched256 config3 stage2 config3_of batched1024_of; do
   python tools/rocpd_stats.py $(find $OUT/prof_$leg -name "*.db" | head -1) > $OUT/${leg}_kernel_stats.txt 2>/dev/null
   rm -rf $OUT/prof_$leg
 done
+python tools/rocpd_stats.py $(find $OUT/prof_dit -name "*.db" | head -1) --by-grid > $OUT/dit_step_kernel_stats.txt 2>/dev/null
+rm -rf $OUT/prof_dit
 python tools/ubench/pmc_codec.py $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) > $OUT/pmc_codec.txt 2>&1
 python tools/ubench/pmc_swiglu_report.py $(find $OUT/pmc_sw_fetch -name "*.db" | head -1) $(find $OUT/pmc_sw_write -name "*.db" | head -1) > $OUT/pmc_swiglu.txt 2>&1
 { echo "# pass 1: SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; python tools/pmc_parse.py $(find $OUT/pmc_g2_a -name "*.db" | head -1) gemm2_kernel;
