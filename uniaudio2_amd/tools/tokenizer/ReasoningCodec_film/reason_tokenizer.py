@@ -329,7 +329,10 @@ class ReasoningTokenizer:
         `detokenize_no_reason` consumes the two generators in — and handed to the windows, so a seeded batch run produces the
         utterances' one-by-one noise.  With the row-invariant GEMM contract (Transformer1DModel.sum_order = 0, no K slabs) the
         waves are then bit-identical to the one-by-one ones (tests/test_gpu_codec_model.py); with the default order-free DiT they
-        agree to the DiT's own bf16 noise."""
+        agree to the DiT's own bf16 noise.
+        `guidance_scale` is accepted and NOT used, exactly as in the reference: its token2audio_no_reason passes the literal 1.5 to
+        inference_codes whatever the caller asked for (reason_tokenizer.py:274,282) — the one-by-one path here does the same, and the
+        batch path must produce the one-by-one waves."""
         if self.latent_fn is not None or self.model is None or not hasattr(self.model, "cfm_wrapper"):
             return [self.detokenize_no_reason(c, steps=steps, guidance_scale=guidance_scale) for c in rec_codecs]
         dev = self.device
