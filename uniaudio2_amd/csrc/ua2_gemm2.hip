@@ -341,7 +341,9 @@ __global__ __launch_bounds__(512, (BMT == 8 && NB <= 3) ? 4 : 2) void gemm2_kern
   // 256-row-tile form inside its registers now that the epilogue also carries the hand-over
   // (one per pass in the 128-register form, whose unrolled pass would not fit otherwise)
   constexpr bool kSmallRegs = BMT == 8 && NB <= 3 && (EPI == UA2_EPI_RESIDUAL || EPI == UA2_EPI_STORE);   // the hand-over / arg-max epilogues in 128 registers
-  constexpr int PM = kSmallRegs ? 1 : ((EPI == UA2_EPI_RESIDUAL && PM0 > 2) ? 2 : PM0);
+  // (the 128-row form with the deep ring — one workgroup per CU, the small-M launches of the DiT — has the registers for a whole-patch
+  // pass: every pass more is one more exposed residual round trip on a launch whose fixed cost is half its time, profiles/r6_notes.md §9)
+  constexpr int PM = kSmallRegs ? 1 : ((EPI == UA2_EPI_RESIDUAL && BMT == 16 && PM0 > 2) ? 2 : PM0);
   static_assert(PM >= 1 && WM % PM == 0 && PM * 4096 <= SHARE, "patch does not fit the wave's share of the ring");
   float* patch = reinterpret_cast<float*>(g2_smem + (size_t)wave * SHARE);
   const int colq = lane & 15, gq = lane >> 4;
