@@ -577,7 +577,10 @@ int ua2_stage3_set_cfg(ua2_stage3* h, float cfg_scale);
  * described by tokens/mask/row_pos/row_seq.  Used for prefill (forward_prefix, :456-497; the
  * discarded lm_head/local-decoder work :498-506 is skipped) and as the first half of a frame. */
 int ua2_stage3_trunk(ua2_stage3* h, int32_t R, void* stream);
-/* model_new.py:617-641: lm_head + greedy text sample, then the 8-step local decoder. */
+/* model_new.py:617-641: lm_head + greedy text sample, then the 8-step local decoder.  [r6] On bf16 plans of up to 6 rows lm_head has no
+ * launch of its own: its column tiles ride on workgroups past the grid of the local decoder's down-projection launches (which fill
+ * half of the CUs; csrc/ua2_gemv.hip gemv_rider_kernel) and the text sample is taken behind the decoder — the same logits and ids
+ * bit for bit (lm_head reads only the trunk's output, :617 vs :629-640).  UA2_NO_RIDER=1: lm_head as a launch, as before. */
 int ua2_stage3_heads(ua2_stage3* h, int32_t R, void* stream);
 /* Feedback for the next frame, on device (evaluation/tts_task.py:259-280 mode 0 "audio";
  * evaluation/asr_task.py:668-682 mode 1 "text"; mode 2 = "audio" with every row continuing from row 0's
