@@ -281,3 +281,30 @@ def test_gemm2_no_scratch_in_the_phase_loop(gemm2_asm):
         first = next(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
         last = max(i for i, (t, _) in enumerate(ins) if t.startswith("v_mfma"))
         assert not any(t.startswith("scratch_") for t, _ in ins[first:last]), name
+
+
+# ---- the weights-stationary batched-decode kernel (ua2_skinny.hip) -------------------------------------------------------
+# Its variants are admitted by a register ESTIMATE (regs_needed); an instantiation the estimate lets through and the compiler
+# spills runs at half speed without failing any numerics test.  Round 6 added the weight-ring forms (two column tiles per wave for
+# SwiGLU): the six-chunk ring under the scaled prologue spilled 44-92 B when the estimate was relaxed — this is the check that found it.
+
+@pytest.fixture(scope="module")
+def skinny_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "skinny.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           os.path.join(CSRC, "ua2_skinny.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def test_skinny2_instantiations_do_not_spill(skinny_asm):
+    md = skinny_asm[skinny_asm.index("amdhsa.kernels"):]
+    seen = ring = 0
+    for ent in re.split(r"\n  - ", md):
+        n = re.search(r"\.name:\s+(\S+)", ent)
+        if not n or "skinny2_kernel" not in n.group(1):
+            continue
+        seen += 1
+        ring += bool(re.search(r"Lb[01]ELi[1-9]\d*EEEv", n.group(1)))        # WD > 0
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", ent).group(1)) == 0, f"{n.group(1)} spills"
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", ent).group(1)) <= 256, n.group(1)
+    assert seen >= 40 and ring >= 4, (seen, ring)

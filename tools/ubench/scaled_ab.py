@@ -27,4 +27,18 @@ for M in [int(v) for v in sys.argv[1:]] or [64, 256]:
             args = [ops.linear(dtype=dt, M=M, N=N, K=K, w0=a, w1=b, epilogue=epi, x_packed=ws, y=y, launch=False, **kw) for a, b in zip(w0, w1)]
             ops.linear_chain_timed(args, 3)
             out[tag] = ops.linear_chain_timed(args, 20) * 1e3
-        print(f"M={M:4d} {name:16s} cast {out['cast']:6.1f} us   scaled {out['scaled']:6.1f} us   (+{out['scaled'] - out['cast']:.1f})", flush=True)
+        line = f"M={M:4d} {name:16s} cast {out['cast']:6.1f} us   scaled {out['scaled']:6.1f} us   (+{out['scaled'] - out['cast']:.1f})"
+        if epi == EPI_SWIGLU:                    # round 6: the weight-ring forms (ct,mt,la,passes,wd) of the scaled consumer, bits checked against auto
+            args = [ops.linear(dtype=dt, M=M, N=N, K=K, w0=a, w1=b, epilogue=epi, x_packed=ws, y=y, launch=False, prologue=PRO_SCALED, x_ssq=ssq, eps=1e-5) for a, b in zip(w0, w1)]
+            ops.linear_chain_timed(args[:1], 1); torch.cuda.synchronize(); ref = y.clone()
+            for v in ("2,4,1,1,6", "2,4,1,1,4", "2,4,1,1,3", "2,4,2,1,6"):
+                os.environ["UA2_SKINNY2"] = v
+                try:
+                    y.zero_(); ops.linear_chain_timed(args[:1], 1); torch.cuda.synchronize()
+                    same = bool(torch.equal(y, ref))
+                    ops.linear_chain_timed(args, 3)
+                    line += f"  | {v}: {ops.linear_chain_timed(args, 20) * 1e3:.1f}{'' if same else ' DIFF'}"
+                except Exception:
+                    line += f"  | {v}: n/a"
+                os.environ.pop("UA2_SKINNY2", None)
+        print(line, flush=True)

@@ -28,6 +28,10 @@ def variants(M):
             ps = sorted({1, max(1, (mt + mtw - 1) // mtw), max(1, (mt + 2 * mtw - 1) // (2 * mtw)), max(1, (mt + 4 * mtw - 1) // (4 * mtw))})
             for p in ps:
                 out.append(f"{ct},{mtw},{la},{p}")
+    # round 6: weight-ring forms (one pass, grid.y = row tiles / mt): "ct,mt,la,1,wd"
+    out += ["2,4,1,1,6", "2,4,2,1,6", "2,4,1,1,4", "2,4,1,1,3", "2,2,2,1,4",                       # SwiGLU
+            "2,2,2,1,8", "2,4,1,1,8", "3,2,2,1,4", "4,2,2,1,4",                                   # RESIDUAL (+ 2,2,2,1,4 / 2,4,1,1,4)
+            "3,2,2,1,6", "4,2,2,1,6", "4,2,2,1,4", "4,4,1,1,4", "3,4,1,1,6", "3,4,1,1,4"]         # STORE / q|k|v
     return out
 
 

@@ -34,12 +34,20 @@ constexpr int kRsrcFlags = 0x00020000;   // raw buffer, dword data format (gfx9 
 
 // SC: the launch is a UA2_PRO_SCALED consumer (row scales from the producer's partials) — a template flag, not a runtime
 // test: the partials' registers must not exist in the other instantiations (as a runtime branch they spilled all of them)
-template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC>
+// WD (round 6): 0 = the wave's weight fragments all resident (above); WD > 0 = a register RING of WD chunks per stream, refilled as the
+// chunks are consumed — one pass only (nothing is re-used), which is the 17-64-row case.  It trades nothing in bytes in flight when CT
+// doubles with it (SwiGLU at K = 3072: 2 matrices x 2 column tiles x 6 chunks = the 24 KiB per wave of the resident CT = 1 form), and
+// it is what lets SwiGLU take two column tiles per wave at all: resident, 2 x 2 x 12 fragments are 192 of a wave's 256 registers.
+// Refills go out BEHIND the operand refill of the same chunk (a wave's loads retire in order: the operand is needed next chunk, the
+// weights WD chunks on).
+template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC, int WD = 0>
 __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int passes) {
   constexpr int DT = UA2_BF16;
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;   // weight matrices
   constexpr int NS = NM * CT;                           // weight streams per wave: stream s = matrix s / CT, column tile s % CT
   static_assert(CH % LA == 0 && LA <= CH, "the operand ring must tile a range");
+  constexpr int WR = WD > 0 ? WD : CH;                  // weight chunks a wave holds at a time
+  static_assert(WR <= CH && CH % WR == 0, "the weight ring must tile a range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);          // [NWV][NS][MT][256]
   float* rstd_l = red + NWV * NS * MT * 256;            // [MT * passes * 16] row scales (UA2_PRO_SCALED)
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
   // burst (HBM).  (A "rolling window" form — weights and operand of a chunk travelling together through a ring, consumed in
   // issue order — was measured and lost 5-20 %: it caps the weight bytes in flight per wave at the ring depth,
   // profiles/r3_skinny_sweep.txt.)
-  u32x4 af[LA][MT], wf[NS][CH];
+  u32x4 af[LA][MT], wf[NS][WR];
   {
     unsigned o[MT];
 #pragma unroll
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
   }
   __builtin_amdgcn_sched_barrier(0);                    // the machine scheduler may not hoist the weight burst above these
 #pragma unroll
-  for (int u = 0; u < CH; ++u)
+  for (int u = 0; u < WR; ++u)
 #pragma unroll
     for (int s = 0; s < NS; ++s) wf[s][u] = ldw(s, u);
   __builtin_amdgcn_sched_barrier(0);
@@ -131,13 +139,19 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
         AFrag<DT> f;
         f.v = af[u % LA][mi];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) f.mma(wf[s][u], acc[s][mi]);
+        for (int s = 0; s < NS; ++s) f.mma(wf[s][u % WR], acc[s][mi]);
       }
       // refill the slot just consumed: chunk u + LA of this pass, or the first chunks of the next pass (always requested —
       // a branch around a load costs a full vmcnt(0) somewhere; past the last pass the clamped tile is read and dropped)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
         af[u % LA][mi] = (u + LA < CH) ? lda(oc[mi], u + LA) : lda(on[mi], u + LA - CH);
+      if constexpr (WD > 0) {                            // the weight ring: chunk u's slot takes chunk u + WD (behind the operand refill)
+        if (u + WR < CH) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) wf[s][u % WR] = ldw(s, u + WR);
+        }
+      }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -203,12 +217,24 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 
 // VGPRs a variant needs: resident weights + operand ring + accumulators + addressing / epilogue slack.  Variants over the
 // per-wave budget (512 per SIMD shared by NWV / 4 waves) spill and are not built.
-constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false) {
+constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false, int wd = 0) {
   const int sw = (mt * 16 + nwv * 4 - 1) / (nwv * 4), npl = (nwv * ch + 7) / 8;      // the scaled consumer's sum-of-squares partials
-  return nm * ct * ch * 4 + la * mt * 4 + nm * ct * mt * 4 + 20 + (sc ? sw * npl + 40 : 0);
+  return nm * ct * (wd > 0 ? wd : ch) * 4 + la * mt * 4 + nm * ct * mt * 4 + 20 + (sc ? sw * npl + 40 : 0);   // (the ring forms with six chunks spill under SC: 44-92 B, checked on the ISA)
 }
 
-struct Variant { int ct, mt, la, passes; };
+// Instantiations the estimate admits and hipcc spills (12-60 B of scratch per lane; tests/test_isa_waits.py compiles the file and
+// fails on any skinny2_kernel with scratch): not built, and the picker steps to the next smaller row tile instead.
+constexpr bool known_spill(int epi, int ct, int mt, int ch, int nwv, int la, bool sc) {
+  struct S { int epi, ct, mt, ch, nwv, la; bool sc; };
+  constexpr S k[] = {{UA2_EPI_QKV_ROPE, 2, 2, 8, 12, 2, true}, {UA2_EPI_RESIDUAL, 2, 4, 8, 12, 2, false}, {UA2_EPI_STORE, 1, 4, 8, 12, 2, true},
+                     {UA2_EPI_STORE, 2, 4, 8, 12, 2, false},   {UA2_EPI_STORE, 2, 2, 8, 12, 2, true},     {UA2_EPI_QKV_ROPE, 1, 4, 4, 16, 1, true},
+                     {UA2_EPI_RESIDUAL, 2, 4, 4, 16, 2, false}, {UA2_EPI_STORE, 2, 4, 4, 16, 2, false}};
+  for (const S& e : k)
+    if (e.epi == epi && e.ct == ct && e.mt == mt && e.ch == ch && e.nwv == nwv && e.la == la && e.sc == sc) return true;
+  return false;
+}
+
+struct Variant { int ct, mt, la, passes, wd = 0; };
 
 // experiment hook: UA2_SKINNY2="ct,mt,la,passes" (read per call); "off" disables the kernel
 bool env_variant(Variant& v, bool& off) {
@@ -216,13 +242,14 @@ bool env_variant(Variant& v, bool& off) {
   off = false;
   if (!e) return false;
   if (e[0] == 'o') { off = true; return false; }
-  return sscanf(e, "%d,%d,%d,%d", &v.ct, &v.mt, &v.la, &v.passes) == 4;
+  v.wd = 0;
+  return sscanf(e, "%d,%d,%d,%d,%d", &v.ct, &v.mt, &v.la, &v.passes, &v.wd) >= 4;
 }
 
-template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC>
+template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC, int WD = 0>
 int launch_one(const ua2_linear_args& a, int passes, hipStream_t s) {
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
-  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA, SC>;
+  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA, SC, WD>;
   constexpr size_t red_bytes = (size_t)NWV * NM * CT * MT * 1024;
   if constexpr (red_bytes > 156 * 1024) return 1;
   const size_t smem = red_bytes + (size_t)passes * MT * 16 * sizeof(float);
@@ -239,14 +266,33 @@ int launch_variant(const ua2_linear_args& a, const Variant& v, hipStream_t s) {
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
 #define UA2_SK(CT_, MT_, LA_)                                                                            \
   if (v.ct == CT_ && v.mt == MT_ && v.la == LA_) {                                                       \
-    if constexpr (EPI != UA2_EPI_RESIDUAL && CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_, NWV, true) <= 2048 / NWV) { \
+    if constexpr (EPI != UA2_EPI_RESIDUAL && CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_, NWV, true) <= 2048 / NWV && \
+                  !known_spill(EPI, CT_, MT_, CH, NWV, LA_, true)) {                                     \
       if (a.prologue == UA2_PRO_SCALED) return launch_one<EPI, CT_, MT_, CH, NWV, LA_, true>(a, v.passes, s);             \
     }                                                                                                    \
     if (a.prologue == UA2_PRO_SCALED) return 1;                                                          \
-    if constexpr (CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_) <= 2048 / NWV)                     \
+    if constexpr (CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_) <= 2048 / NWV && !known_spill(EPI, CT_, MT_, CH, NWV, LA_, false)) \
       return launch_one<EPI, CT_, MT_, CH, NWV, LA_, false>(a, v.passes, s);                              \
     return 1;                                                                                            \
   }
+  // weight-ring forms (one pass): the ring buys the registers for more column tiles per wave than fit resident — fewer operand
+  // bytes into the CU per weight byte, which is what a 33-64-row launch waits for
+#define UA2_SKR(CT_, MT_, LA_, WD_)                                                                                              \
+  if (v.wd == WD_ && v.passes == 1 && v.ct == CT_ && v.mt == MT_ && v.la == LA_) {                                                 \
+    if constexpr (EPI != UA2_EPI_RESIDUAL && WD_ < CH && CH % WD_ == 0 && CH % LA_ == 0 &&                                         \
+                  regs_needed(NM, CT_, MT_, CH, LA_, NWV, true, WD_) <= 2048 / NWV) {                                              \
+      if (a.prologue == UA2_PRO_SCALED) return launch_one<EPI, CT_, MT_, CH, NWV, LA_, true, WD_>(a, 1, s);                        \
+    }                                                                                                                            \
+    if (a.prologue == UA2_PRO_SCALED) return 1;                                                                                  \
+    if constexpr (WD_ < CH && CH % WD_ == 0 && CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_, NWV, false, WD_) <= 2048 / NWV)     \
+      return launch_one<EPI, CT_, MT_, CH, NWV, LA_, false, WD_>(a, 1, s);                                                         \
+    return 1;                                                                                                                    \
+  }
+  if constexpr (EPI == UA2_EPI_SWIGLU) {
+    UA2_SKR(2, 4, 1, 6) UA2_SKR(2, 4, 2, 6) UA2_SKR(2, 4, 1, 4) UA2_SKR(2, 4, 1, 3)
+  }
+#undef UA2_SKR
+  if (v.wd != 0) return 1;
   UA2_SK(1, 4, 1) UA2_SK(1, 4, 2) UA2_SK(1, 2, 2)
   UA2_SK(2, 4, 1) UA2_SK(2, 4, 2) UA2_SK(2, 2, 2)
 #undef UA2_SK
@@ -268,9 +314,15 @@ Variant pick_variant(const ua2_linear_args& a, int waves, int ch, int nm) {
   const int groups = ua2_ceil_div(ntiles, v.ct);
   const int ysplit = std::max(1, std::min(256 / groups, ua2_ceil_div(mtiles, 2)));
   const int rows = ua2_ceil_div(mtiles, ysplit);            // row tiles per workgroup
-  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1, waves, sc) <= budget) ? 4 : 2;
+  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1, waves, sc) <= budget && !known_spill(a.epilogue, v.ct, 4, ch, waves, 1, sc)) ? 4 : 2;
   v.la = (v.mt == 2 && ch % 2 == 0) ? 2 : 1;
   v.passes = ua2_ceil_div(rows, v.mt);
+  // 33-64 rows of a SwiGLU launch (round 6, profiles/r6_notes.md §10): one pass of four row tiles, so nothing re-uses the weights and a
+  // register RING of them frees the registers for two column tiles per wave — the operand crosses into half as many workgroups
+  // (trunk, 64 rows: 28.5 -> 22.5 us under the scaled prologue; K = 2048: 18.0 -> 16.7).  The ring is a third of the range, four chunks.
+  static const bool no_ring = getenv("UA2_SKINNY_NO_RING") != nullptr;     // A/B of the round-6 form (read once)
+  if (!no_ring && nm == 2 && mtiles >= 3 && mtiles <= 4 && ntiles >= 192 && ch % 4 == 0 && ch > 4 && regs_needed(nm, 2, 4, ch, 1, waves, sc, 4) <= budget)
+    v = Variant{2, 4, 1, 1, 4};
   return v;
 }
 
@@ -306,8 +358,8 @@ int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipS
   UA2_GEO(UA2_EPI_QKV_ROPE, 4, 16) UA2_GEO(UA2_EPI_RESIDUAL, 4, 16) UA2_GEO(UA2_EPI_STORE, 4, 16)
   UA2_GEO(UA2_EPI_SWIGLU, 8, 8) UA2_GEO(UA2_EPI_STORE, 8, 8)
 #undef UA2_GEO
-  UA2_CHECK(!(forced && rc == 1), "UA2_SKINNY2=%d,%d,%d,%d is not built for this geometry (epilogue %d, %d ranges x %d chunks)", v.ct, v.mt,
-            v.la, v.passes, a.epilogue, geo.waves, ch);
+  UA2_CHECK(!(forced && rc == 1), "UA2_SKINNY2=%d,%d,%d,%d,%d is not built for this geometry (epilogue %d, %d ranges x %d chunks)", v.ct, v.mt,
+            v.la, v.passes, v.wd, a.epilogue, geo.waves, ch);
   if (rc == 0) UA2_LAUNCH_CHECK();
   return rc;
 }
