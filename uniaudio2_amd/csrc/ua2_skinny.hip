@@ -120,8 +120,6 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
   // lookahead: vmcnt(1) instead of vmcnt(3) per refill, +3 us per pass)
   if constexpr (SC) ssq_reduce(0);
 
-  const int row = tid >> 4, col = tid & 15;
-  const int srcl = (((row >> 2) << 4) + col) * 4 + (row & 3);
   for (int pass = 0;;) {                                 // the first pass is unconditional (the launcher never starts a workgroup past M):
     const int mtp = mt_first + pass * MT;               // a guard in front of it lets the compiler sink the first operand loads below the burst
     unsigned oc[MT], on[MT];
@@ -157,56 +155,56 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(&red[(((wave * NS + s) * MT) + mi) * 256 + lane * 4]) = acc[s][mi];
-    // the first column tile's epilogue loads (residual values; position -> RoPE table entry / page id) go out BEFORE the barrier:
-    // issued behind it they were a dependent L2 round trip or two in front of every store of the launch
-    EpiPre pre0[MT];
-    if (tid < 256) {
-      const int nt0 = min((int)blockIdx.x * CT, ntiles - 1);
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt0, row, col, pre0[mi], (mtp + mi) * 16);
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt0, row, col, pre0[mi], (mtp + mi) * 16);
-    }
+    // Epilogue: the (column tile, row tile) items of the pass are dealt round-robin to the workgroup's NG = NWV / 4 thread groups of 256
+    // (round 6: before, threads 0-255 walked all of them while the other waves idled at the barrier — at 64 rows that is 4-8
+    // items of LDS reduction + stores in a row).  Every item's epilogue loads (residual values; position -> RoPE table entry /
+    // page id; norm weight) go out one item ahead — the first before the barrier: issued where they are needed they are a dependent L2 round
+    // trip or two in front of the stores (all items ahead at once cost 8-140 B of scratch in the multi-pass forms, whose weights stay resident).
+#ifdef UA2_SKINNY_ONE_GROUP                              // A/B build: the round-3 form (threads 0-255 walk every item)
+    constexpr int NG = 1, NI = CT * MT, IPG = NI;
+#else
+    constexpr int NG = NWV / 4, NI = CT * MT, IPG = (NI + NG - 1) / NG;
+#endif
+    // a thread's element of a 16 x 16 tile, from an OPAQUE copy of its id: derived from `tid` itself the compiler hoists the epilogue's
+    // per-thread addresses (64-bit, loop-invariant over the passes) above the chunk loop and spills them across it
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int grp = tl >> 8, row = (tl & 255) >> 4, col = tl & 15;
+    const int srcl = (((row >> 2) << 4) + col) * 4 + (row & 3);
+    auto prefetch = [&](int it, EpiPre& p) {             // both stages of item `it` (a no-op past the last item)
+      if (it >= NI || grp >= NG) return;
+      const int nt = min((int)blockIdx.x * CT + it / MT, ntiles - 1), m0 = (mtp + it % MT) * 16;
+      epilogue_prefetch_a<DT, EPI>(a, nt, row, col, p, m0);
+      epilogue_prefetch_b<DT, EPI>(a, nt, row, col, p, m0);
+    };
+    EpiPre pre;
+    prefetch(grp, pre);
     ua2_lds_barrier();                                   // LDS-only hand-off: the operand prefetch of the next pass stays in flight
     const bool more_passes = pass + 1 < passes && mt_first + (pass + 1) * MT < mtiles;    // uniform
     if constexpr (SC) { if (more_passes) ssq_request(pass + 1); }                         // lands under the epilogue below
-    if (tid < 256) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int nt = blockIdx.x * CT + ct;
-        if (nt >= ntiles) break;                         // uniform
+    for (int k = 0; k < IPG; ++k) {
+      const int it = grp + k * NG;                        // uniform over the group's four waves
+      EpiPre nxt;                                        // the next item's loads travel under this item's reduction and stores
+      if (k + 1 < IPG) prefetch(it + NG, nxt);
+      const int ct = it / MT, mi = it % MT;
+      const int nt = blockIdx.x * CT + ct, m0 = (mtp + mi) * 16;
+      if (it < NI && grp < NG && nt < ntiles && m0 < a.M) {
         int tile[NM];
 #pragma unroll
         for (int t = 0; t < NM; ++t) tile[t] = nt;
-        EpiPre pre[MT];                                  // every row tile's epilogue loads before any store
-        if (ct == 0) {
+        if constexpr (SC) pre.rstd = rstd_l[min((mtp - mt_first + mi) * 16 + row, passes * MT * 16 - 1)];
+        float v[NM];
 #pragma unroll
-          for (int mi = 0; mi < MT; ++mi) pre[mi] = pre0[mi];
-        } else {
+        for (int t = 0; t < NM; ++t) {
+          float sacc = 0.f;
 #pragma unroll
-          for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_a<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) epilogue_prefetch_b<DT, EPI>(a, nt, row, col, pre[mi], (mtp + mi) * 16);
+          for (int w = 0; w < NWV; ++w) sacc += red[(((w * NS + t * CT + ct) * MT) + mi) * 256 + srcl];
+          v[t] = sacc;
         }
-        if constexpr (SC) {
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) pre[mi].rstd = rstd_l[min((mtp - mt_first + mi) * 16 + row, passes * MT * 16 - 1)];
-        }
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int m0 = (mtp + mi) * 16;
-          if (m0 >= a.M) break;                          // uniform over the workgroup
-          float v[NM];
-#pragma unroll
-          for (int t = 0; t < NM; ++t) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWV; ++w) sacc += red[(((w * NS + t * CT + ct) * MT) + mi) * 256 + srcl];
-            v[t] = sacc;
-          }
-          linear_epilogue<DT, EPI, NM>(a, v, tile, row, col, pre[mi], m0, min(16, a.M - m0));
-        }
+        linear_epilogue<DT, EPI, NM>(a, v, tile, row, col, pre, m0, min(16, a.M - m0));
       }
+      if (k + 1 < IPG) pre = nxt;
     }
     if (!more_passes) break;
     ++pass;
@@ -219,19 +217,10 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 // per-wave budget (512 per SIMD shared by NWV / 4 waves) spill and are not built.
 constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false, int wd = 0) {
   const int sw = (mt * 16 + nwv * 4 - 1) / (nwv * 4), npl = (nwv * ch + 7) / 8;      // the scaled consumer's sum-of-squares partials
-  return nm * ct * (wd > 0 ? wd : ch) * 4 + la * mt * 4 + nm * ct * mt * 4 + 20 + (sc ? sw * npl + 40 : 0);   // (the ring forms with six chunks spill under SC: 44-92 B, checked on the ISA)
-}
-
-// Instantiations the estimate admits and hipcc spills (12-60 B of scratch per lane; tests/test_isa_waits.py compiles the file and
-// fails on any skinny2_kernel with scratch): not built, and the picker steps to the next smaller row tile instead.
-constexpr bool known_spill(int epi, int ct, int mt, int ch, int nwv, int la, bool sc) {
-  struct S { int epi, ct, mt, ch, nwv, la; bool sc; };
-  constexpr S k[] = {{UA2_EPI_QKV_ROPE, 2, 2, 8, 12, 2, true}, {UA2_EPI_RESIDUAL, 2, 4, 8, 12, 2, false}, {UA2_EPI_STORE, 1, 4, 8, 12, 2, true},
-                     {UA2_EPI_STORE, 2, 4, 8, 12, 2, false},   {UA2_EPI_STORE, 2, 2, 8, 12, 2, true},     {UA2_EPI_QKV_ROPE, 1, 4, 4, 16, 1, true},
-                     {UA2_EPI_RESIDUAL, 2, 4, 4, 16, 2, false}, {UA2_EPI_STORE, 2, 4, 4, 16, 2, false}};
-  for (const S& e : k)
-    if (e.epi == epi && e.ct == ct && e.mt == mt && e.ch == ch && e.nwv == nwv && e.la == la && e.sc == sc) return true;
-  return false;
+  // ring forms: the partials are dead before the accumulators come alive (reduced behind the burst, in front of the chunk loop): only
+  // what they need beyond the accumulators' registers counts
+  const int acc = nm * ct * mt * 4, scx = sc ? sw * npl + 40 : 0;
+  return nm * ct * (wd > 0 ? wd : ch) * 4 + la * mt * 4 + acc + 20 + (wd > 0 ? (scx > acc ? scx - acc : 0) : scx);
 }
 
 struct Variant { int ct, mt, la, passes, wd = 0; };
@@ -266,12 +255,11 @@ int launch_variant(const ua2_linear_args& a, const Variant& v, hipStream_t s) {
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
 #define UA2_SK(CT_, MT_, LA_)                                                                            \
   if (v.ct == CT_ && v.mt == MT_ && v.la == LA_) {                                                       \
-    if constexpr (EPI != UA2_EPI_RESIDUAL && CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_, NWV, true) <= 2048 / NWV && \
-                  !known_spill(EPI, CT_, MT_, CH, NWV, LA_, true)) {                                     \
+    if constexpr (EPI != UA2_EPI_RESIDUAL && CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_, NWV, true) <= 2048 / NWV) { \
       if (a.prologue == UA2_PRO_SCALED) return launch_one<EPI, CT_, MT_, CH, NWV, LA_, true>(a, v.passes, s);             \
     }                                                                                                    \
     if (a.prologue == UA2_PRO_SCALED) return 1;                                                          \
-    if constexpr (CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_) <= 2048 / NWV && !known_spill(EPI, CT_, MT_, CH, NWV, LA_, false)) \
+    if constexpr (CH % LA_ == 0 && regs_needed(NM, CT_, MT_, CH, LA_) <= 2048 / NWV) \
       return launch_one<EPI, CT_, MT_, CH, NWV, LA_, false>(a, v.passes, s);                              \
     return 1;                                                                                            \
   }
@@ -314,15 +302,21 @@ Variant pick_variant(const ua2_linear_args& a, int waves, int ch, int nm) {
   const int groups = ua2_ceil_div(ntiles, v.ct);
   const int ysplit = std::max(1, std::min(256 / groups, ua2_ceil_div(mtiles, 2)));
   const int rows = ua2_ceil_div(mtiles, ysplit);            // row tiles per workgroup
-  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1, waves, sc) <= budget && !known_spill(a.epilogue, v.ct, 4, ch, waves, 1, sc)) ? 4 : 2;
+  v.mt = (rows >= 4 && regs_needed(nm, v.ct, 4, ch, 1, waves, sc) <= budget) ? 4 : 2;
   v.la = (v.mt == 2 && ch % 2 == 0) ? 2 : 1;
   v.passes = ua2_ceil_div(rows, v.mt);
   // 33-64 rows of a SwiGLU launch (round 6, profiles/r6_notes.md §10): one pass of four row tiles, so nothing re-uses the weights and a
   // register RING of them frees the registers for two column tiles per wave — the operand crosses into half as many workgroups
-  // (trunk, 64 rows: 28.5 -> 22.5 us under the scaled prologue; K = 2048: 18.0 -> 16.7).  The ring is a third of the range, four chunks.
-  static const bool no_ring = getenv("UA2_SKINNY_NO_RING") != nullptr;     // A/B of the round-6 form (read once)
-  if (!no_ring && nm == 2 && mtiles >= 3 && mtiles <= 4 && ntiles >= 192 && ch % 4 == 0 && ch > 4 && regs_needed(nm, 2, 4, ch, 1, waves, sc, 4) <= budget)
-    v = Variant{2, 4, 1, 1, 4};
+  // (trunk, 64 rows: 30.2 -> 23.9 us in the frame with a four-chunk ring).  Ring = half of the range where it fits, else four chunks.
+  static const char* ring_env = getenv("UA2_SKINNY_RING");                 // A/B (read once): "off" or "wd,la"
+  if (!(ring_env && ring_env[0] == 'o') && nm == 2 && mtiles >= 3 && mtiles <= 4 && ntiles >= 192) {
+    int wd = 0, la = 1;
+    if (ring_env && sscanf(ring_env, "%d,%d", &wd, &la) == 2) {
+    } else if (ch == 12 && regs_needed(nm, 2, 4, ch, 2, waves, sc, 6) <= budget) { wd = 6; la = 2; }
+    else if (ch == 12 && regs_needed(nm, 2, 4, ch, 1, waves, sc, 6) <= budget) { wd = 6; la = 1; }
+    else if (ch % 4 == 0 && ch > 4 && regs_needed(nm, 2, 4, ch, 1, waves, sc, 4) <= budget) { wd = 4; la = 1; }
+    if (wd > 0 && wd < ch && ch % wd == 0) v = Variant{2, 4, la, 1, wd};
+  }
   return v;
 }
 
