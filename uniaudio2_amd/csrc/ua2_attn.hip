@@ -8,6 +8,8 @@
 // MI355X design: one workgroup per (row, kv-head) walks positions 0..row_pos once; the K and V rows
 // are read with 16-byte lane loads and shared by the q_per_kv query heads of the group (no repeat_interleave
 // copies); the summation order depends only on the position, never on the batch.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ua2_common.h"
@@ -46,8 +48,13 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 
 // kG = query heads per kv head, a template parameter: with a run-time G padded to kMaxG = 4 the Llama trunk (G = 3) spent a
 // quarter of its vector-ALU work on a head that does not exist (the launch is ALU-bound from 64 rows up, profiles/r3_notes.md)
-template <int DT, int HS, int kG>
-__global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_attn_args a) {
+// PF (round 6): true = K / V of step t + 1 requested before the arithmetic of step t (the B = 1 form: one workgroup per CU, latency
+// is everything); false = loads at the top of their own step and the kernel capped at 128 registers (bf16, HS = 128, G = 3 needs 164
+// with the prefetch), so that TWO workgroups share a CU — batched decode launches more workgroups than the device has CUs (64 rows x 8
+// kv heads = 512, 1024 rows = 8192) and each of them is a chain of dependent round trips (position -> page id -> K / V -> states
+// through LDS): occupancy, not lookahead, is what such a launch waits for.  Same arithmetic, same order: same bits.
+template <int DT, int HS, int kG, bool PF = true>
+__global__ __launch_bounds__(kFusedWaves * 64, PF ? 2 : 4) void attn_fused_kernel(const ua2_attn_args a) {
   constexpr int EPL = Elem<DT>::EPL, BYTES = Elem<DT>::BYTES;
   constexpr int LPR = HS / EPL, RPW = 64 / LPR;   // lanes per cache row, row groups per wave
   constexpr int UNR = (DT == UA2_BF16) ? 4 : 2;   // wave instructions per step (K and V each)
@@ -106,11 +113,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
       vr[u] = *reinterpret_cast<const u32x4*>((const char*)a.kv.v_pool + off);
     }
   };
-  u32x4 kraw[UNR], vraw[UNR], knext[UNR], vnext[UNR];
-  if (j0 < j1) issue(j0, kraw, vraw);
+  u32x4 kraw[UNR], vraw[UNR], knext[PF ? UNR : 1], vnext[PF ? UNR : 1];
+  if constexpr (PF) { if (j0 < j1) issue(j0, kraw, vraw); }
   for (int jb = j0; jb < j1; jb += UNR * RPW) {
-    const bool more = jb + UNR * RPW < j1;
-    if (more) issue(jb + UNR * RPW, knext, vnext);
+    const bool more = PF && jb + UNR * RPW < j1;
+    if constexpr (PF) { if (more) issue(jb + UNR * RPW, knext, vnext); }
+    else issue(jb, kraw, vraw);
     bool ok[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) ok[u] = (jb + u * RPW + rin) < j1;
@@ -173,9 +181,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void attn_fused_kernel(const ua2_
         for (int e = 0; e < EPL; ++e) o_run[h][e] += p * vf[e];
       }
     }
-    if (more) {
+    if constexpr (PF) {
+      if (more) {
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) { kraw[u] = knext[u]; vraw[u] = vnext[u]; }
+        for (int u = 0; u < UNR; ++u) { kraw[u] = knext[u]; vraw[u] = vnext[u]; }
+      }
     }
   }
   // publish the state of this row group
@@ -240,6 +250,17 @@ template <int DT, int HS, int kG>
 void launch_fused_g(const ua2_attn_args& a, hipStream_t s) {
   constexpr int EPL = Elem<DT>::EPL, RPW = 64 / (HS / EPL), NS = kFusedWaves * RPW;
   const size_t smem = (size_t)(2 * NS * kMaxG + (size_t)NS * kG * HS) * sizeof(float);
+  // more workgroups than CUs: the two-per-CU form (bf16: the fp32 kernel already fits twice)
+  static const int dense_env = getenv("UA2_ATTN_DENSE") ? atoi(getenv("UA2_ATTN_DENSE")) : -1;      // A/B (read once): 0 = never, 1 = always
+  const bool dense = DT == UA2_BF16 && (dense_env >= 0 ? dense_env != 0 : (int64_t)a.R * a.kv.n_kv > 256);
+  if (dense) {
+    if constexpr (DT == UA2_BF16 && kG <= 3) {          // four query heads per kv head do not fit 128 registers (80-164 B of scratch)
+      constexpr auto kern2 = attn_fused_kernel<DT, HS, kG, false>;
+      ua2_allow_big_lds<kern2>();
+      hipLaunchKernelGGL(kern2, dim3(a.R, a.kv.n_kv), dim3(kFusedWaves * 64), smem, s, a);
+      return;
+    }
+  }
   constexpr auto kern = attn_fused_kernel<DT, HS, kG>;
   ua2_allow_big_lds<kern>();
   hipLaunchKernelGGL(kern, dim3(a.R, a.kv.n_kv), dim3(kFusedWaves * 64), smem, s, a);
