@@ -304,7 +304,7 @@ def test_skinny2_instantiations_do_not_spill(skinny_asm):
         if not n or "skinny2_kernel" not in n.group(1):
             continue
         seen += 1
-        ring += bool(re.search(r"Lb[01]ELi[1-9]\d*EEEv", n.group(1)))        # WD > 0
+        ring += bool(re.search(r"Lb[01]ELi[1-9]\d*ELi\d+EEEv", n.group(1)))   # WD > 0 (template tail: SC, WD, RPW)
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", ent).group(1)) == 0, f"{n.group(1)} spills"
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", ent).group(1)) <= 256, n.group(1)
     assert seen >= 40 and ring >= 4, (seen, ring)

@@ -32,6 +32,7 @@ def variants(M):
     out += ["2,4,1,1,6", "2,4,2,1,6", "2,4,1,1,4", "2,4,1,1,3", "2,2,2,1,4",                       # SwiGLU
             "2,2,2,1,8", "2,4,1,1,8", "3,2,2,1,4", "4,2,2,1,4",                                   # RESIDUAL (+ 2,2,2,1,4 / 2,4,1,1,4)
             "3,2,2,1,6", "4,2,2,1,6", "4,2,2,1,4", "4,4,1,1,4", "3,4,1,1,6", "3,4,1,1,4"]         # STORE / q|k|v
+    out += ["1,4,4,1,0,2", "1,4,1,1,0,2", "1,2,4,2,0,2", "1,2,4,1,0,2"]      # two ranges per wave (K = 8192)
     return out
 
 

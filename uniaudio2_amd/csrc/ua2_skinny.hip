@@ -40,21 +40,27 @@ constexpr int kRsrcFlags = 0x00020000;   // raw buffer, dword data format (gfx9 
 // it is what lets SwiGLU take two column tiles per wave at all: resident, 2 x 2 x 12 fragments are 192 of a wave's 256 registers.
 // Refills go out BEHIND the operand refill of the same chunk (a wave's loads retire in order: the operand is needed next chunk, the
 // weights WD chunks on).
-template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC, int WD = 0>
-__global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int passes) {
+// RPW (round 6): K ranges per wave.  NWV stays the number of RANGES (the bit contract: `red` holds one partial per range, added in range
+// order); with RPW = 2 a workgroup is NWV / 2 waves that walk two consecutive ranges each — all 2 x CH weight fragments in flight at once as
+// before, and twice the registers per wave for a deeper operand ring (K = 8192 at 16 ranges: 128 registers per wave leave LA = 1).
+template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC, int WD = 0, int RPW = 1>
+__global__ __launch_bounds__(NWV / RPW * 64) void skinny2_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, const int passes) {
   constexpr int DT = UA2_BF16;
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;   // weight matrices
   constexpr int NS = NM * CT;                           // weight streams per wave: stream s = matrix s / CT, column tile s % CT
-  static_assert(CH % LA == 0 && LA <= CH, "the operand ring must tile a range");
-  constexpr int WR = WD > 0 ? WD : CH;                  // weight chunks a wave holds at a time
-  static_assert(WR <= CH && CH % WR == 0, "the weight ring must tile a range");
+  constexpr int CHT = RPW * CH;                         // chunks a wave walks
+  constexpr int NWAVES = NWV / RPW;
+  static_assert(NWV % RPW == 0 && NWAVES % 4 == 0 && (RPW == 1 || WD == 0), "whole thread groups; the weight ring is a one-range form");
+  static_assert(CHT % LA == 0 && LA <= CHT, "the operand ring must tile a wave's chunks");
+  constexpr int WR = WD > 0 ? WD : CHT;                 // weight chunks a wave holds at a time
+  static_assert(WR <= CHT && CHT % WR == 0, "the weight ring must tile a range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);          // [NWV][NS][MT][256]
   float* rstd_l = red + NWV * NS * MT * 256;            // [MT * passes * 16] row scales (UA2_PRO_SCALED)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int nchunks = NWV * CH;                     // checked by the launcher: K / KC == NWV * CH
   const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
-  const int c0 = wave * CH;
+  const int c0 = wave * CHT;
 
   // Addressing: buffer loads — a scalar resource + a scalar offset (tile, chunk) + ONE per-lane 32-bit offset, so a load
   // costs no 64-bit vector address arithmetic and no address registers (with flat global loads the compiler kept a 64-bit
@@ -78,17 +84,17 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 
   // UA2_PRO_SCALED: sum-of-squares partials of the pass's rows — a 16-lane group per row, SW sweeps over the MT * 16 rows —
   // requested at the head of the pass (pass 0: before the weight burst), reduced after its chunk loop, into rstd_l
-  constexpr int SW = SC ? (MT * 16 + NWV * 4 - 1) / (NWV * 4) : 1;
+  constexpr int SW = SC ? (MT * 16 + NWAVES * 4 - 1) / (NWAVES * 4) : 1;
   constexpr int NPL = SC ? (nchunks + 7) / 8 : 1;         // K / 16 partials per row over 16 lanes
   float ssqv[SW][NPL];
   auto ssq_request = [&](int pass) {
 #pragma unroll
-    for (int w = 0; w < SW; ++w) scaled_ssq_request(a, (mt_first + pass * MT) * 16 + w * NWV * 4 + (tid >> 4), tid & 15, ssqv[w]);
+    for (int w = 0; w < SW; ++w) scaled_ssq_request(a, (mt_first + pass * MT) * 16 + w * NWAVES * 4 + (tid >> 4), tid & 15, ssqv[w]);
   };
   auto ssq_reduce = [&](int pass) {
 #pragma unroll
     for (int w = 0; w < SW; ++w) {
-      const int r = w * NWV * 4 + (tid >> 4);
+      const int r = w * NWAVES * 4 + (tid >> 4);
       const float rs = scaled_rstd_reduce(a, tid & 15, ssqv[w]);
       if ((tid & 15) == 0 && r < MT * 16) rstd_l[pass * MT * 16 + r] = rs;
     }
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) acc[s][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
+    for (int u = 0; u < CHT; ++u) {
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         AFrag<DT> f;
@@ -143,18 +149,23 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
       // a branch around a load costs a full vmcnt(0) somewhere; past the last pass the clamped tile is read and dropped)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
-        af[u % LA][mi] = (u + LA < CH) ? lda(oc[mi], u + LA) : lda(on[mi], u + LA - CH);
+        af[u % LA][mi] = (u + LA < CHT) ? lda(oc[mi], u + LA) : lda(on[mi], u + LA - CHT);
       if constexpr (WD > 0) {                            // the weight ring: chunk u's slot takes chunk u + WD (behind the operand refill)
-        if (u + WR < CH) {
+        if (u + WR < CHT) {
 #pragma unroll
           for (int s = 0; s < NS; ++s) wf[s][u % WR] = ldw(s, u + WR);
         }
       }
+      if (u % CH == CH - 1) {                            // end of a range: its partial chain goes to the range's slot of `red`
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            *reinterpret_cast<f32x4*>(&red[((((wave * RPW + u / CH) * NS + s) * MT) + mi) * 256 + lane * 4]) = acc[s][mi];
+            acc[s][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) *reinterpret_cast<f32x4*>(&red[(((wave * NS + s) * MT) + mi) * 256 + lane * 4]) = acc[s][mi];
     // Epilogue: the (column tile, row tile) items of the pass are dealt round-robin to the workgroup's NG = NWV / 4 thread groups of 256
     // (round 6: before, threads 0-255 walked all of them while the other waves idled at the barrier — at 64 rows that is 4-8
     // items of LDS reduction + stores in a row).  Every item's epilogue loads (residual values; position -> RoPE table entry /
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 #ifdef UA2_SKINNY_ONE_GROUP                              // A/B build: the round-3 form (threads 0-255 walk every item)
     constexpr int NG = 1, NI = CT * MT, IPG = NI;
 #else
-    constexpr int NG = NWV / 4, NI = CT * MT, IPG = (NI + NG - 1) / NG;
+    constexpr int NG = NWAVES / 4, NI = CT * MT, IPG = (NI + NG - 1) / NG;
 #endif
     // a thread's element of a 16 x 16 tile, from an OPAQUE copy of its id: derived from `tid` itself the compiler hoists the epilogue's
     // per-thread addresses (64-bit, loop-invariant over the passes) above the chunk loop and spills them across it
@@ -215,15 +226,15 @@ __global__ __launch_bounds__(NWV * 64) void skinny2_kernel(const ua2_linear_args
 
 // VGPRs a variant needs: resident weights + operand ring + accumulators + addressing / epilogue slack.  Variants over the
 // per-wave budget (512 per SIMD shared by NWV / 4 waves) spill and are not built.
-constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false, int wd = 0) {
-  const int sw = (mt * 16 + nwv * 4 - 1) / (nwv * 4), npl = (nwv * ch + 7) / 8;      // the scaled consumer's sum-of-squares partials
+constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false, int wd = 0, int rpw = 1) {
+  const int sw = (mt * 16 + nwv / rpw * 4 - 1) / (nwv / rpw * 4), npl = (nwv * ch + 7) / 8;      // the scaled consumer's sum-of-squares partials
   // ring forms: the partials are dead before the accumulators come alive (reduced behind the burst, in front of the chunk loop): only
   // what they need beyond the accumulators' registers counts
   const int acc = nm * ct * mt * 4, scx = sc ? sw * npl + 40 : 0;
-  return nm * ct * (wd > 0 ? wd : ch) * 4 + la * mt * 4 + acc + 20 + (wd > 0 ? (scx > acc ? scx - acc : 0) : scx);
+  return nm * ct * (wd > 0 ? wd : ch * rpw) * 4 + la * mt * 4 + acc + 20 + (wd > 0 ? (scx > acc ? scx - acc : 0) : scx);
 }
 
-struct Variant { int ct, mt, la, passes, wd = 0; };
+struct Variant { int ct, mt, la, passes, wd = 0, rpw = 1; };
 
 // experiment hook: UA2_SKINNY2="ct,mt,la,passes" (read per call); "off" disables the kernel
 bool env_variant(Variant& v, bool& off) {
@@ -231,21 +242,21 @@ bool env_variant(Variant& v, bool& off) {
   off = false;
   if (!e) return false;
   if (e[0] == 'o') { off = true; return false; }
-  v.wd = 0;
-  return sscanf(e, "%d,%d,%d,%d,%d", &v.ct, &v.mt, &v.la, &v.passes, &v.wd) >= 4;
+  v.wd = 0; v.rpw = 1;
+  return sscanf(e, "%d,%d,%d,%d,%d,%d", &v.ct, &v.mt, &v.la, &v.passes, &v.wd, &v.rpw) >= 4;
 }
 
-template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC, int WD = 0>
+template <int EPI, int CT, int MT, int CH, int NWV, int LA, bool SC, int WD = 0, int RPW = 1>
 int launch_one(const ua2_linear_args& a, int passes, hipStream_t s) {
   constexpr int NM = (EPI == UA2_EPI_SWIGLU) ? 2 : 1;
-  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA, SC, WD>;
+  constexpr auto kern = skinny2_kernel<EPI, CT, MT, CH, NWV, LA, SC, WD, RPW>;
   constexpr size_t red_bytes = (size_t)NWV * NM * CT * MT * 1024;
   if constexpr (red_bytes > 156 * 1024) return 1;
   const size_t smem = red_bytes + (size_t)passes * MT * 16 * sizeof(float);
   ua2_allow_big_lds<kern>();
   const int mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
   const dim3 grid(ua2_ceil_div(ntiles, CT), ua2_ceil_div(mtiles, MT * passes));
-  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), passes);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV / RPW * 64), smem, s, a, reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace), passes);
   ua2_count_launch(UA2_CNT_SKINNY2);
   return 0;
 }
@@ -281,6 +292,19 @@ int launch_variant(const ua2_linear_args& a, const Variant& v, hipStream_t s) {
   }
 #undef UA2_SKR
   if (v.wd != 0) return 1;
+  // two ranges per wave (K = 8192: 16 ranges of 16 chunks on 8 waves; RESIDUAL has no scaled consumer form)
+  if constexpr (EPI == UA2_EPI_RESIDUAL && CH == 16 && NWV == 16) {
+#define UA2_SK2(MT_, LA_)                                                                                   \
+    if (v.rpw == 2 && v.ct == 1 && v.mt == MT_ && v.la == LA_) {                                            \
+      if (a.prologue == UA2_PRO_SCALED) return 1;                                                           \
+      if constexpr (regs_needed(NM, 1, MT_, CH, LA_, NWV, false, 0, 2) <= 2048 / (NWV / 2))                 \
+        return launch_one<EPI, 1, MT_, CH, NWV, LA_, false, 0, 2>(a, v.passes, s);                          \
+      return 1;                                                                                             \
+    }
+    UA2_SK2(4, 4) UA2_SK2(2, 4) UA2_SK2(4, 1)          // experiment forms (tools/ubench/skinny_shapes.py)
+#undef UA2_SK2
+  }
+  if (v.rpw != 1) return 1;
   UA2_SK(1, 4, 1) UA2_SK(1, 4, 2) UA2_SK(1, 2, 2)
   UA2_SK(2, 4, 1) UA2_SK(2, 4, 2) UA2_SK(2, 2, 2)
 #undef UA2_SK
@@ -317,6 +341,9 @@ Variant pick_variant(const ua2_linear_args& a, int waves, int ch, int nm) {
     else if (ch % 4 == 0 && ch > 4 && regs_needed(nm, 2, 4, ch, 1, waves, sc, 4) <= budget) { wd = 4; la = 1; }
     if (wd > 0 && wd < ch && ch % wd == 0) v = Variant{2, 4, la, 1, wd};
   }
+  // (Two K ranges per wave — UA2_SKINNY2="1,2,4,p,0,2", K = 8192 on eight waves with a four-chunk operand ring — measured 5 % ahead in
+  // isolation, profiles/r6_skinny_rpw_sweep.txt, and level in the frame: 5.05 / 5.07 vs 5.07 / 5.08 ms at 64 rows.  Not picked.  What the
+  // sweep settles: ring depths 1 / 2 / 4 / 8 are within 0.5 us of each other — the launch does not wait for a per-wave chain of round trips.)
   return v;
 }
 
@@ -352,8 +379,8 @@ int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipS
   UA2_GEO(UA2_EPI_QKV_ROPE, 4, 16) UA2_GEO(UA2_EPI_RESIDUAL, 4, 16) UA2_GEO(UA2_EPI_STORE, 4, 16)
   UA2_GEO(UA2_EPI_SWIGLU, 8, 8) UA2_GEO(UA2_EPI_STORE, 8, 8)
 #undef UA2_GEO
-  UA2_CHECK(!(forced && rc == 1), "UA2_SKINNY2=%d,%d,%d,%d,%d is not built for this geometry (epilogue %d, %d ranges x %d chunks)", v.ct, v.mt,
-            v.la, v.passes, v.wd, a.epilogue, geo.waves, ch);
+  UA2_CHECK(!(forced && rc == 1), "UA2_SKINNY2=%d,%d,%d,%d,%d,%d is not built for this geometry (epilogue %d, %d ranges x %d chunks)", v.ct, v.mt,
+            v.la, v.passes, v.wd, v.rpw, a.epilogue, geo.waves, ch);
   if (rc == 0) UA2_LAUNCH_CHECK();
   return rc;
 }
