@@ -129,11 +129,12 @@ def roofline_leg(model):
 def scalar_decode_work(cfg, T):
     """Algorithmic bytes / flops of ScalarModel.decode for a (1, latent, T) input (see codec_leg): 1.80 GB and 181.5 GFLOP at the
     placeholder widths, T = 500 — the figures rounds 2-3 measured against."""
-    by = fl = 0.0
+    by = fl = wb = 0.0
 
     def conv(cin, cout, k, tin, tout, res=False):
-        nonlocal by, fl
+        nonlocal by, fl, wb
         by += 4.0 * (cin * tin + cout * tout + (cout * tout if res else 0)) + 4.0 * cin * cout * k
+        wb += 4.0 * cin * cout * k
         fl += 2.0 * cout * tout * cin * k
 
     c = cfg["init_channel"] * 2 ** len(cfg["upsample_factors"])
@@ -141,12 +142,14 @@ def scalar_decode_work(cfg, T):
     for s_, k in zip(cfg["upsample_factors"], cfg["upsample_kernel_sizes"]):
         taps = -(-k // s_)                                   # a transposed conv = s phase filters of ceil(k / s) taps
         by += 4.0 * (c * T + (c // 2) * T * s_) + 4.0 * (s_ * (c // 2)) * c * taps
+        wb += 4.0 * (s_ * (c // 2)) * c * taps
         fl += 2.0 * (c // 2) * (T * s_) * c * taps
         c //= 2
         T *= s_
         for _ in range(5):
             if c <= 128:
                 by += 4.0 * 3 * c * T + 4.0 * c * c * cfg["res_kernel_size"]
+                wb += 4.0 * c * c * cfg["res_kernel_size"]
                 fl += 2.0 * c * T * c * cfg["res_kernel_size"]
             else:
                 conv(c, c, cfg["res_kernel_size"], T, T)
@@ -155,7 +158,7 @@ def scalar_decode_work(cfg, T):
         conv(c, c, cfg["default_kernel_size"], T, T * cfg["num_samples"])
         T *= cfg["num_samples"]
     conv(c, cfg["num_bands"], cfg["default_kernel_size"], T, T)
-    return {"flop": fl, "bytes": by}
+    return {"flop": fl, "bytes": by, "weight_bytes": wb}
 
 
 def codec_leg(dev, cpu=False):
@@ -195,6 +198,19 @@ def codec_leg(dev, cpu=False):
         wav = sq.decode(lat)
     e1.record(); torch.cuda.synchronize()
     dec_ms = e0.elapsed_time(e1) / 3
+    # the same chain with EIGHT windows per launch — what `--codec_batch 8` hands ScalarModel.decode (reason_tokenizer.py
+    # detokenize_no_reason_batch: one decode per group of windows): the 512- / 256-channel stages of one window are 1500 / 7500 time
+    # steps, grids of 96-200 workgroups; eight windows fill the device.  Algorithmic bytes: activations x 8, filters once.
+    NW8 = 8
+    lat8 = torch.tanh(torch.randn(NW8, 136, 500, device=dev))
+    sq.decode(lat8)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        sq.decode(lat8)
+    e1.record(); torch.cuda.synchronize()
+    dec8_ms = e0.elapsed_time(e1) / 3
+    bytes8 = NW8 * (work["bytes"] - work["weight_bytes"]) + work["weight_bytes"]
     x = torch.randn(125, 32, device=dev)
     emb = torch.randn(6, 8192, 32, device=dev)
     embT = emb.transpose(1, 2).contiguous()
@@ -214,6 +230,8 @@ def codec_leg(dev, cpu=False):
            # against the 8 TB/s HBM peak: the roofline that bounds this stack (north_star bar: 0.60)
            "scalar_decode_algorithmic_GBps": round(work["bytes"] / (dec_ms * 1e-3) / 1e9, 1),
            "scalar_decode_frac_hbm": round(work["bytes"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "scalar_decode_8_windows_ms_per_window": round(dec8_ms / NW8, 3),
+           "scalar_decode_8_windows_frac_hbm": round(bytes8 / (dec8_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "rvq_encode_us_125x6x8192x32": round(rvq_us, 1), "config": "placeholder init_channel=32, hop 960"}
     if cpu:
         res["cpu_baseline"] = codec_cpu_baseline(sq, lat, x, emb, dec_ms, rvq_us, gpu_wav=wav)
