@@ -133,3 +133,22 @@ def test_flash_attention_rows_do_not_depend_on_the_grouping():
             rows.append(slot); gseq.append(sq); nkeys.append(int(pos[sel].max()) + 1)
     t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).cuda()
     assert torch.equal(run((t(np.stack(rows)), t(gseq), t(nkeys), 2)), base)
+
+
+def test_row_kernel_two_per_cu_form_equals_the_prefetch_form():
+    """Round 6: launches of the row-by-row kernel with more workgroups than CUs (R * n_kv > 256) take the 128-register form without
+    the one-step K / V prefetch (two workgroups per CU); fewer take the prefetch form.  Same arithmetic in the same order: a row's
+    bits must not depend on which form its launch took — the whole batch in one launch against its rows in launches of 8."""
+    from uniaudio2_amd import ops
+    s = _setup(24, 8, 128, [196, 33, 70, 5, 64, 65], seed=3)
+    R = s["q"].shape[0]
+    assert R * 8 > 256
+    y_all = torch.empty_like(s["q"])
+    ops.attn(dtype=torch.bfloat16, R=R, q=s["q"], row_pos=s["pos"], row_seq=s["seq"], kv=s["geom"], y=y_all)
+    y_few = torch.empty_like(s["q"])
+    for r0 in range(0, R, 8):
+        n = min(8, R - r0)                                              # 8 rows x 8 kv heads = 64 workgroups: the prefetch form
+        ops.attn(dtype=torch.bfloat16, R=n, q=s["q"][r0:r0 + n].contiguous(), row_pos=s["pos"][r0:r0 + n].contiguous(),
+                 row_seq=s["seq"][r0:r0 + n].contiguous(), kv=s["geom"], y=y_few[r0:r0 + n])
+    assert torch.equal(y_all, y_few)
+    assert float((y_all.cpu() - s["ref"]).abs().max()) < 2e-4

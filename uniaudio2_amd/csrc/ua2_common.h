@@ -190,6 +190,10 @@ extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_
                                int32_t C, float* next_h, int32_t row_key_shift, void* stream);
 extern "C" int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
                            int32_t* part_idx, int32_t pairs, void* stream);
+// arg-max over the STORE epilogue's partials fused with a gather from the executor's projected-embedding table (ua2_misc.hip)
+int ua2_argmax_gather(int32_t M, int32_t n_part, const float* part_max, const int32_t* part_idx, int32_t* out_tokens, int32_t out_ld,
+                      int32_t out_col, const float* tab_y, const void* tab_h, const float* tab_ssq, int64_t row_off, int32_t Cd, float* next_x,
+                      const ua2_handover* ho, hipStream_t s);
 // decode-regime specialisation; returns 1 when the problem is outside its regime
 int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s);
 // riders (ua2_gemv.hip gemv_rider_kernel): column tiles [tile0, tile1) of the one-row-tile GEMV `r` on the idle CUs of host launch `a`

@@ -248,6 +248,62 @@ __global__ void argmax_embed_kernel(int n_part, const float* __restrict__ pmax, 
 }
 
 
+// Round 6 — the same arg-max, fused with a gather from the PROJECTED embedding table of the frame executor (ua2_stage3.hip): inside
+// the depth decoder's loop (model_new.py:630-641) step i + 1 starts with self.projection(ci_embed), and ci_embed = _embed_audio(i,
+// ci_sample) is a row of a fixed table — projection(row), and the scaled-norm hand-over of it (RNE_bf16(y (.) w_norm), per-16-column
+// sums of squares), are functions of the sampled id alone.  The executor builds them once per plan WITH THE SAME LAUNCHES the frame
+// would run (a row's bits do not depend on the rows beside it: the row-invariance contract), and the frame gathers: y -> next_x [M, Cd];
+// hand-over rows -> ho.h (row-major) or ho.packed (fragment order), ho.ssq.  Seven 5.9-us GEMVs per B = 1 frame disappear.
+__global__ __launch_bounds__(256) void argmax_gather_kernel(int n_part, const float* __restrict__ pmax, const int32_t* __restrict__ pidx,
+                                                            int32_t* __restrict__ out_tokens, int out_ld, int out_col,
+                                                            const float* __restrict__ tab_y, const unsigned short* __restrict__ tab_h,
+                                                            const float* __restrict__ tab_ssq, long long row_off, int Cd,
+                                                            float* __restrict__ next_x, ua2_handover ho) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int tok_s;
+  const int m = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int p = threadIdx.x; p < n_part; p += blockDim.x) {
+    const float v = pmax[(size_t)m * n_part + p];
+    const int i = pidx[(size_t)m * n_part + p];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    tok_s = bi;
+    out_tokens[(size_t)m * out_ld + out_col] = bi;
+  }
+  __syncthreads();
+  const size_t row = (size_t)((long long)tok_s + row_off);
+  const float4* y4 = reinterpret_cast<const float4*>(tab_y + row * Cd);
+  float4* x4 = reinterpret_cast<float4*>(next_x + (size_t)m * Cd);
+  for (int c = threadIdx.x; c < Cd / 4; c += blockDim.x) x4[c] = y4[c];
+  if (!ho.ssq) return;
+  const int np = Cd >> 4;
+  for (int p = threadIdx.x; p < np; p += blockDim.x) ho.ssq[(size_t)m * np + p] = tab_ssq[row * np + p];
+  const uint2* h4 = reinterpret_cast<const uint2*>(tab_h + row * Cd);     // four bf16 per piece
+  for (int c = threadIdx.x; c < Cd / 4; c += blockDim.x) {
+    const uint2 v = h4[c];
+    if (ho.h) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(ho.h) + (size_t)m * ho.ldh + 4 * c) = v;
+    if (ho.packed) {       // fragment order [M/16][Cd/32][64 lanes][8 bf16]: columns 4c .. 4c + 3 are four consecutive elements of one lane's piece
+      const int k = 4 * c, ch = k >> 5, r = k & 31, g = r >> 3, e = r & 7;
+      const size_t elem = (((size_t)(m >> 4) * (Cd >> 5) + ch) * 64 + g * 16 + (m & 15)) * 8 + e;
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(ho.packed) + elem) = v;
+    }
+  }
+}
+
 // model_new.py:618-622, 634-637: classifier-free guidance over the (conditional, unconditional) logit rows
 //   guided = l1 + (l0 - l1) * scale      (each operation rounded once, as torch evaluates it)
 // Both rows are overwritten with `guided`, and the per-16-column arg-max partials of both rows are rebuilt
@@ -346,6 +402,21 @@ extern "C" int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const floa
     ua2_set_error("ua2_argmax_embed: bad dtype %d", dtype);
     return -1;
   }
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
+int ua2_argmax_gather(int32_t M, int32_t n_part, const float* part_max, const int32_t* part_idx, int32_t* out_tokens, int32_t out_ld,
+                      int32_t out_col, const float* tab_y, const void* tab_h, const float* tab_ssq, int64_t row_off, int32_t Cd, float* next_x,
+                      const ua2_handover* ho, hipStream_t s) {
+  UA2_CHECK(M > 0 && n_part > 0 && part_max && part_idx && out_tokens && tab_y && next_x && Cd % 32 == 0, "ua2_argmax_gather: bad arguments");
+  ua2_handover h{};
+  if (ho) {
+    UA2_CHECK(tab_h && tab_ssq && ho->ssq && (ho->h || ho->packed) && (!ho->h || ho->ldh % 4 == 0), "ua2_argmax_gather: hand-over tables / outputs missing");
+    h = *ho;
+  }
+  hipLaunchKernelGGL(argmax_gather_kernel, dim3(M), dim3(256), 0, s, n_part, part_max, part_idx, out_tokens, out_ld, out_col, tab_y,
+                     reinterpret_cast<const unsigned short*>(tab_h), tab_ssq, (long long)row_off, Cd, next_x, h);
   UA2_LAUNCH_CHECK();
   return 0;
 }

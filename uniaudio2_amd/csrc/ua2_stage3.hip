@@ -34,6 +34,14 @@ struct ua2_stage3 {
   // per-16-column sums of squares — no prep launch and no in-kernel statistics between a residual update and its consumer
   void *xh, *xpk;
   float* ssq;
+  // Projected-embedding table of the depth decoder (round 6; model_new.py:631 self.projection(ci_embed), :640 ci_embed = _embed_audio(i, ci_sample)):
+  // row i * va + id = what the projection launch of step i + 1 would write for sample id of codebook i — y (fp32), and under the scaled
+  // plan RNE_bf16(y (.) norm_1 of the decoder's layer 0) and the per-16-column sums of squares.  Built at create time by the very launches
+  // the frame would run; the frame's arg-max gathers the row instead of launching the GEMV (ua2_misc.hip argmax_gather_kernel).
+  float* ptab_y = nullptr;
+  void* ptab_h = nullptr;
+  float* ptab_ssq = nullptr;
+  bool ptab_ho = false;
   float* split_ws = nullptr;   // K-slab scratch of the order-free GEMM (ua2_linear_args.split_ws): handed to launches under UA2_SUM_ORDER_FREE only
   size_t split_ws_bytes = 0;
   bool scaled = false;
@@ -55,7 +63,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, ptab_y, ptab_h, ptab_ssq, ptab_rows, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -86,6 +94,12 @@ Carve carve(const ua2_stage3_desc& d) {
   // the narrow projections at ~1000 rows): plans that can hold such launches only
   c.split_floats = (d.dtype == UA2_BF16 && R >= 256) ? (size_t)16 << 20 : 0;
   c.split = take(c.split_floats);
+  // projected-embedding table: (n_cb - 1) * va rows of [Cd fp32 | Cd bf16 | Cd / 16 fp32] (the last codebook's sample is never projected);
+  // UA2_NO_PROJ_TABLE=1 keeps the per-step projection launch (A/B, and plans that cannot spare ~1.1 GB at the released sizes)
+  c.ptab_rows = (d.n_cb > 1 && d.va > 0 && d.projection && d.audio_emb && Cd % 32 == 0 && getenv("UA2_NO_PROJ_TABLE") == nullptr) ? (size_t)(d.n_cb - 1) * d.va : 0;
+  c.ptab_y = take(c.ptab_rows * Cd);
+  c.ptab_h = take(c.ptab_rows * Cd / 2);
+  c.ptab_ssq = take(c.ptab_rows * (Cd / 16));
   c.total = off;
   return c;
 }
@@ -275,6 +289,13 @@ __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int re
   if (threadIdx.x == 0) counters[0] = frame + 1;
 }
 
+// rows [row0, row0 + n) of the embedding table (plan dtype) as fp32 rows: the operand of the table-building projection launches
+template <int DT>
+__global__ void emb_rows_f32_kernel(const void* __restrict__ emb, long long row0, int n, int C, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * C; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = load_elem<DT>(emb, (size_t)row0 * C + i);
+}
+
 }  // namespace
 
 extern "C" size_t ua2_stage3_scratch_floats(const ua2_stage3_desc* d) { return d ? carve(*d).total : 0; }
@@ -320,6 +341,30 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->scaled = d->dtype == UA2_BF16 && getenv("UA2_NO_SCALED") == nullptr && d->backbone.n_embd % 32 == 0 && d->decoder.n_embd % 32 == 0 &&
               d->max_batch <= 64;
   h->npart_t = (d->vt + 15) / 16; h->npart_a = (d->va + 15) / 16;
+  if (c.ptab_rows) {
+    // The table is what the frame's own projection launches would write: same entry point, same arguments, rows in groups of up to 64
+    // (decode kernel / weights-stationary kernel: a row's bits do not depend on its group).  Null stream, once per plan.
+    h->ptab_y = b + c.ptab_y; h->ptab_h = b + c.ptab_h; h->ptab_ssq = b + c.ptab_ssq;
+    h->ptab_ho = h->scaled;
+    const int C = d->backbone.n_embd, Cd = d->decoder.n_embd;
+    const int chunk = std::min(64, d->max_batch);
+    for (size_t row0 = 0; row0 < c.ptab_rows; row0 += chunk) {
+      const int n = (int)std::min<size_t>(chunk, c.ptab_rows - row0);
+      if (d->dtype == UA2_BF16) hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_BF16>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->curr_h);
+      else hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_F32>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->curr_h);
+      ua2_linear_args a;
+      fresh_args(h, a);
+      a.dtype = d->dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
+      a.M = n; a.N = Cd; a.K = C; a.x = h->curr_h; a.ldx = C; a.w0 = d->projection; a.y = h->ptab_y + row0 * Cd; a.ldy = Cd;
+      if (h->ptab_ho) {
+        a.y_norm_w = h->norms[3][0][0]; a.y_ssq = h->ptab_ssq + row0 * (Cd / 16);
+        a.y_h = reinterpret_cast<unsigned short*>(h->ptab_h) + row0 * Cd; a.ldh = Cd;
+      }
+      if (int rc = ua2_linear_launch(a, nullptr)) { delete h; return rc; }
+    }
+    const hipError_t e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { ua2_set_error("ua2_stage3_create: building the projected-embedding table failed: %s", hipGetErrorString(e)); delete h; return -1; }
+  }
   *out = h;
   return 0;
 }
@@ -483,14 +528,18 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
   if (!ride)
     if (int rc = text_tail()) return rc;
   const float* curr = h->hfin;
+  // steps 1 .. n_cb - 1 take their projected input (and its hand-over) from the table, gathered by the previous step's arg-max
+  const bool tab = h->ptab_y && h->topk == 1 && order == UA2_SUM_ORDER_INVARIANT && (!scaled || h->ptab_ho);
   for (int i = 0; i < (text_only ? 0 : d.n_cb); ++i) {             // model_new.py:630-641
-    fresh_args(h, a);
-    a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
-    a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
     const Handover hod(h, R, Cd);
-    if (scaled) hod.produce(a, h->norms[3][0][0]);
-    a.sum_order = order;
-    if (int rc = ua2_linear_launch(a, s)) return rc;
+    if (!(tab && i > 0)) {
+      fresh_args(h, a);
+      a.dtype = d.dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
+      a.M = R; a.N = Cd; a.K = C; a.x = curr; a.ldx = C; a.w0 = d.projection; a.y = h->xd; a.ldy = Cd;
+      if (scaled) hod.produce(a, h->norms[3][0][0]);
+      a.sum_order = order;
+      if (int rc = ua2_linear_launch(a, s)) return rc;
+    }
     if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8, false,
                          scaled ? d.decoder.ln_f : nullptr, scaled, ride ? &rp : nullptr)) return rc;
     fresh_args(h, a);
@@ -504,7 +553,11 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
     if (cfg)   // model_new.py:634-637
       if (int rc = ua2_cfg_mix(h->audio_logits + (size_t)i * d.va, d.n_cb * d.va, d.va, h->cfg_scale, d.forbid, h->pmax_a,
                                h->pidx_a, R / 2, s)) return rc;
-    if (h->topk == 1) {
+    if (tab && i + 1 < d.n_cb) {
+      const ua2_handover g = hod.rowwise(nullptr);
+      if (int rc = ua2_argmax_gather(R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, h->ptab_y, h->ptab_h, h->ptab_ssq,
+                                     (int64_t)i * d.va, Cd, h->xd, scaled ? &g : nullptr, s)) return rc;
+    } else if (h->topk == 1) {
       if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
                                     i * d.va, C, h->curr_h, s)) return rc;
     } else {   // model_new.py:639 audio_sample_topk(ci_logits, topk, temperature, forbid_prefix)
