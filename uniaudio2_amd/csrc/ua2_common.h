@@ -191,9 +191,19 @@ extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_
 extern "C" int ua2_cfg_mix(float* logits, int32_t ld, int32_t V, float scale, const int32_t* forbid, float* part_max,
                            int32_t* part_idx, int32_t pairs, void* stream);
 // arg-max over the STORE epilogue's partials fused with a gather from the executor's projected-embedding table (ua2_misc.hip)
+// ... and, optionally, layer 0's q | k | v of the step (also functions of the id and the step's position): q -> q_out [M, qn], k / v -> the caches
+struct ua2_qkv_gather {
+  const float* tab_q;      // [rows, qn]
+  const void* tab_k;       // [rows, n_kv * head_size] of the plan dtype
+  const void* tab_v;
+  float* q_out;
+  int32_t qn, esz, pos;    // esz: bytes per cache element; pos: position of the step the rows are written for
+  ua2_kv_geom kv;          // destination caches (row m = sequence m)
+};
 int ua2_argmax_gather(int32_t M, int32_t n_part, const float* part_max, const int32_t* part_idx, int32_t* out_tokens, int32_t out_ld,
                       int32_t out_col, const float* tab_y, const void* tab_h, const float* tab_ssq, int64_t row_off, int32_t Cd, float* next_x,
-                      const ua2_handover* ho, hipStream_t s);
+                      const ua2_handover* ho, const ua2_qkv_gather* qg, hipStream_t s);
+int ua2_kv_rows_extract(const void* k_pool, const void* v_pool, const int32_t* pos, int n, int n_kv, int hs, int esz, void* out_k, void* out_v, hipStream_t s);
 // decode-regime specialisation; returns 1 when the problem is outside its regime
 int ua2_gemv_try_launch(const ua2_linear_args& a, hipStream_t s);
 // riders (ua2_gemv.hip gemv_rider_kernel): column tiles [tile0, tile1) of the one-row-tile GEMV `r` on the idle CUs of host launch `a`

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void argmax_gather_kernel(int n_part, const fl
                                                             int32_t* __restrict__ out_tokens, int out_ld, int out_col,
                                                             const float* __restrict__ tab_y, const unsigned short* __restrict__ tab_h,
                                                             const float* __restrict__ tab_ssq, long long row_off, int Cd,
-                                                            float* __restrict__ next_x, ua2_handover ho) {
+                                                            float* __restrict__ next_x, ua2_handover ho, ua2_qkv_gather qg) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int tok_s;
@@ -289,6 +289,21 @@ __global__ __launch_bounds__(256) void argmax_gather_kernel(int n_part, const fl
   const float4* y4 = reinterpret_cast<const float4*>(tab_y + row * Cd);
   float4* x4 = reinterpret_cast<float4*>(next_x + (size_t)m * Cd);
   for (int c = threadIdx.x; c < Cd / 4; c += blockDim.x) x4[c] = y4[c];
+  if (qg.tab_q) {     // layer 0's q | k | v of the next step (position qg.pos): q -> the executor's q buffer, k / v -> this sequence's cache page
+    const float4* q4 = reinterpret_cast<const float4*>(qg.tab_q + row * qg.qn);
+    float4* qo = reinterpret_cast<float4*>(qg.q_out + (size_t)m * qg.qn);
+    for (int c = threadIdx.x; c < qg.qn / 4; c += blockDim.x) qo[c] = q4[c];
+    const int hs = qg.kv.head_size, kvw = qg.kv.n_kv * hs;                 // elements of k (v) per row
+    const int page = qg.kv.page_table[(size_t)m * qg.kv.max_pages + ua2_page_slot(qg.kv, qg.pos)];
+    const int per16 = 16 / qg.esz;                                          // elements per 16-byte piece
+    for (int c = threadIdx.x; c < kvw / per16; c += blockDim.x) {
+      const int e0 = c * per16, kvh = e0 / hs, dd = e0 - kvh * hs;
+      const size_t dst = ((((size_t)page * qg.kv.n_kv + kvh) * UA2_PAGE + (qg.pos % UA2_PAGE)) * hs + dd) * qg.esz;
+      const size_t src = (row * kvw + e0) * qg.esz;
+      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(qg.kv.k_pool) + dst) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qg.tab_k) + src);
+      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(qg.kv.v_pool) + dst) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qg.tab_v) + src);
+    }
+  }
   if (!ho.ssq) return;
   const int np = Cd >> 4;
   for (int p = threadIdx.x; p < np; p += blockDim.x) ho.ssq[(size_t)m * np + p] = tab_ssq[row * np + p];
@@ -406,17 +421,41 @@ extern "C" int ua2_argmax_embed(int dtype, int32_t M, int32_t n_part, const floa
   return 0;
 }
 
+// rows of a scratch cache (row r = page r, written at position pos[r] by a q|k|v launch) -> compact table rows [n][n_kv * head_size]
+__global__ void kv_rows_extract_kernel(const char* __restrict__ k_pool, const char* __restrict__ v_pool, const int32_t* __restrict__ pos, int n,
+                                       int n_kv, int hs, int esz, char* __restrict__ out_k, char* __restrict__ out_v) {
+  const size_t roww = (size_t)n_kv * hs * esz;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * roww; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / roww, b = i - r * roww, kvh = b / ((size_t)hs * esz), w = b - kvh * hs * esz;
+    const size_t src = (((r * n_kv + kvh) * UA2_PAGE + (pos[r] % UA2_PAGE)) * hs) * esz + w;
+    out_k[i] = k_pool[src];
+    out_v[i] = v_pool[src];
+  }
+}
+int ua2_kv_rows_extract(const void* k_pool, const void* v_pool, const int32_t* pos, int n, int n_kv, int hs, int esz, void* out_k, void* out_v, hipStream_t s) {
+  hipLaunchKernelGGL(kv_rows_extract_kernel, dim3(std::min(1024, n * 4)), dim3(256), 0, s, (const char*)k_pool, (const char*)v_pool, pos, n, n_kv, hs, esz, (char*)out_k, (char*)out_v);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
 int ua2_argmax_gather(int32_t M, int32_t n_part, const float* part_max, const int32_t* part_idx, int32_t* out_tokens, int32_t out_ld,
                       int32_t out_col, const float* tab_y, const void* tab_h, const float* tab_ssq, int64_t row_off, int32_t Cd, float* next_x,
-                      const ua2_handover* ho, hipStream_t s) {
+                      const ua2_handover* ho, const ua2_qkv_gather* qg, hipStream_t s) {
   UA2_CHECK(M > 0 && n_part > 0 && part_max && part_idx && out_tokens && tab_y && next_x && Cd % 32 == 0, "ua2_argmax_gather: bad arguments");
+  ua2_qkv_gather q{};
+  if (qg) {
+    UA2_CHECK(qg->tab_q && qg->tab_k && qg->tab_v && qg->q_out && qg->qn % 4 == 0 && (qg->esz == 2 || qg->esz == 4) && qg->kv.k_pool && qg->kv.v_pool &&
+                  qg->kv.page_table && qg->kv.head_size % (16 / qg->esz) == 0 && qg->kv.ring_pages == 0,
+              "ua2_argmax_gather: q | k | v table / destination missing");
+    q = *qg;
+  }
   ua2_handover h{};
   if (ho) {
     UA2_CHECK(tab_h && tab_ssq && ho->ssq && (ho->h || ho->packed) && (!ho->h || ho->ldh % 4 == 0), "ua2_argmax_gather: hand-over tables / outputs missing");
     h = *ho;
   }
   hipLaunchKernelGGL(argmax_gather_kernel, dim3(M), dim3(256), 0, s, n_part, part_max, part_idx, out_tokens, out_ld, out_col, tab_y,
-                     reinterpret_cast<const unsigned short*>(tab_h), tab_ssq, (long long)row_off, Cd, next_x, h);
+                     reinterpret_cast<const unsigned short*>(tab_h), tab_ssq, (long long)row_off, Cd, next_x, h, q);
   UA2_LAUNCH_CHECK();
   return 0;
 }

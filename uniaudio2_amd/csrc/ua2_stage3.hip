@@ -42,6 +42,11 @@ struct ua2_stage3 {
   void* ptab_h = nullptr;
   float* ptab_ssq = nullptr;
   bool ptab_ho = false;
+  // ... and layer 0's q | k | v of the depth decoder for the same rows (step i + 1 runs at position i + 1 whatever the frame: RoPE included):
+  // q fp32 [qn], k / v [n_kv * head_size] of the plan dtype — the frame's arg-max writes q into the q buffer and k / v into the caches,
+  // and layer 0's q|k|v launch of steps 1 .. n_cb - 1 disappears as well
+  float* ptab_q = nullptr;
+  void *ptab_k = nullptr, *ptab_v = nullptr;
   float* split_ws = nullptr;   // K-slab scratch of the order-free GEMM (ua2_linear_args.split_ws): handed to launches under UA2_SUM_ORDER_FREE only
   size_t split_ws_bytes = 0;
   bool scaled = false;
@@ -63,7 +68,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, ptab_y, ptab_h, ptab_ssq, ptab_rows, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, ptab_y, ptab_h, ptab_ssq, ptab_rows, ptab_q, ptab_k, ptab_v, ptab_qkv, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -100,6 +105,16 @@ Carve carve(const ua2_stage3_desc& d) {
   c.ptab_y = take(c.ptab_rows * Cd);
   c.ptab_h = take(c.ptab_rows * Cd / 2);
   c.ptab_ssq = take(c.ptab_rows * (Cd / 16));
+  {   // q | k | v rows of the decoder's layer 0 (UA2_NO_QKV_TABLE=1: the projection table alone)
+    const ua2_gpt_desc& g = d.decoder;
+    const size_t esz = d.dtype == UA2_BF16 ? 2 : 4, kvw = (size_t)g.n_kv * g.head_size;
+    c.ptab_qkv = (c.ptab_rows && g.n_layer > 0 && d.n_cb <= UA2_PAGE && (g.n_head * g.head_size) % 4 == 0 && (g.head_size * esz) % 16 == 0 &&
+                  getenv("UA2_NO_QKV_TABLE") == nullptr) ? 1 : 0;
+    const size_t rows = c.ptab_qkv ? c.ptab_rows : 0;
+    c.ptab_q = take(rows * g.n_head * g.head_size);
+    c.ptab_k = take((rows * kvw * esz + 3) / 4);
+    c.ptab_v = take((rows * kvw * esz + 3) / 4);
+  }
   c.total = off;
   return c;
 }
@@ -173,7 +188,7 @@ struct RiderPlan {
 // rp: the launches of this GPT that can (RiderPlan::ok) carry their share of the rider's column tiles.
 int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const int32_t* row_pos,
             const int32_t* row_seq, hipStream_t s, bool local = false, bool grouped = false, const float* final_norm_w = nullptr,
-            bool scaled = false, RiderPlan* rp = nullptr) {
+            bool scaled = false, RiderPlan* rp = nullptr, bool qkv0_given = false) {
   auto launch = [&](const ua2_linear_args& a, int kind) -> int {
     if (rp && rp->ok[kind]) {
       int t0, t1;
@@ -206,7 +221,8 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     a.rope_sin = g.rope_sin; a.q_out = h->q; a.kv = kv;
     if (scaled) ho.consume(a);
     a.sum_order = order;
-    if (int rc = launch(a, 0)) return rc;
+    if (!(qkv0_given && l == 0))        // depth decoder, steps >= 1: the previous step's arg-max wrote layer 0's q / k / v from the table
+      if (int rc = launch(a, 0)) return rc;
 
     const bool fuse_attn = local && R == 1 && !no_local_fuse();
     // more than one row tile: the consumer runs a many-row kernel, so its producer writes the packed operand
@@ -289,6 +305,12 @@ __global__ void feedback_kernel(int R, int ncb, int mode, int reason_eos, int re
   if (threadIdx.x == 0) counters[0] = frame + 1;
 }
 
+// table rows row0 .. row0 + n - 1: position of the step that consumes row g = i * va + id is i + 1; page table of the scratch cache: row r -> page r
+__global__ void ptab_pos_kernel(int32_t* __restrict__ out, int n, long long row0, int va) {
+  const int r = threadIdx.x;
+  if (r < 64) { out[r] = r < n ? (int)((row0 + r) / va) + 1 : 0; out[64 + r] = r; }
+}
+
 // rows [row0, row0 + n) of the embedding table (plan dtype) as fp32 rows: the operand of the table-building projection launches
 template <int DT>
 __global__ void emb_rows_f32_kernel(const void* __restrict__ emb, long long row0, int n, int C, float* __restrict__ out) {
@@ -348,6 +370,15 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
     h->ptab_ho = h->scaled;
     const int C = d->backbone.n_embd, Cd = d->decoder.n_embd;
     const int chunk = std::min(64, d->max_batch);
+    void *tmp_k = nullptr, *tmp_v = nullptr;
+    int32_t* tmp_i = nullptr;          // [64] positions, [64] page table (row r -> page r)
+    if (c.ptab_qkv) {
+      h->ptab_q = b + c.ptab_q; h->ptab_k = b + c.ptab_k; h->ptab_v = b + c.ptab_v;
+      const size_t pool = (size_t)64 * d->decoder.n_kv * UA2_PAGE * d->decoder.head_size * (d->dtype == UA2_BF16 ? 2 : 4);
+      if (hipMalloc(&tmp_k, pool) != hipSuccess || hipMalloc(&tmp_v, pool) != hipSuccess || hipMalloc((void**)&tmp_i, 128 * sizeof(int32_t)) != hipSuccess) {
+        ua2_set_error("ua2_stage3_create: scratch cache of the q|k|v table"); delete h; return -1;
+      }
+    }
     for (size_t row0 = 0; row0 < c.ptab_rows; row0 += chunk) {
       const int n = (int)std::min<size_t>(chunk, c.ptab_rows - row0);
       if (d->dtype == UA2_BF16) hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_BF16>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->curr_h);
@@ -360,9 +391,32 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
         a.y_norm_w = h->norms[3][0][0]; a.y_ssq = h->ptab_ssq + row0 * (Cd / 16);
         a.y_h = reinterpret_cast<unsigned short*>(h->ptab_h) + row0 * Cd; a.ldh = Cd;
       }
+      const Handover hod(h, n, Cd);
+      const bool scaled_q = h->ptab_ho && c.ptab_qkv;
+      if (scaled_q && !hod.rows_h) a.y_packed = h->xpk;        // the q|k|v launch below reads the fragment-order form, as in the frame
       if (int rc = ua2_linear_launch(a, nullptr)) { delete h; return rc; }
+      if (!c.ptab_qkv) continue;
+      // layer 0's q|k|v of these rows, exactly as run_gpt launches it: row r of the group = its own one-page sequence of a scratch cache
+      const ua2_gpt_desc& g = d->decoder;
+      const int qn = g.n_head * g.head_size, nqkv = (g.n_head + 2 * g.n_kv) * g.head_size, esz = d->dtype == UA2_BF16 ? 2 : 4;
+      hipLaunchKernelGGL(ptab_pos_kernel, dim3(1), dim3(64), 0, nullptr, tmp_i, n, (long long)row0, d->va);
+      ua2_kv_geom kv{};
+      kv.k_pool = tmp_k; kv.v_pool = tmp_v; kv.page_table = tmp_i + 64; kv.max_pages = 1; kv.n_kv = g.n_kv; kv.n_head = g.n_head; kv.head_size = g.head_size;
+      fresh_args(h, a);
+      a.dtype = d->dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_QKV_ROPE;
+      a.M = n; a.N = nqkv; a.K = Cd; a.x = h->ptab_y + row0 * Cd; a.ldx = Cd; a.norm_w = h->norms[3][0][0]; a.eps = g.eps;
+      a.w0 = h->ptrs[3][0][0]; a.row_pos = tmp_i; a.row_seq = nullptr; a.rope_cos = g.rope_cos; a.rope_sin = g.rope_sin;
+      a.q_out = h->ptab_q + row0 * qn; a.kv = kv;
+      if (scaled_q) {
+        a.prologue = UA2_PRO_SCALED; a.x_ssq = h->ptab_ssq + row0 * (Cd / 16); a.x = nullptr; a.norm_w = nullptr;
+        if (hod.rows_h) { a.x_h = reinterpret_cast<unsigned short*>(h->ptab_h) + row0 * Cd; a.ldh = Cd; } else { a.x_packed = h->xpk; }
+      }
+      if (int rc = ua2_linear_launch(a, nullptr)) { delete h; return rc; }
+      const size_t kvw = (size_t)g.n_kv * g.head_size * esz;
+      if (int rc = ua2_kv_rows_extract(tmp_k, tmp_v, tmp_i, n, g.n_kv, g.head_size, esz, (char*)h->ptab_k + row0 * kvw, (char*)h->ptab_v + row0 * kvw, nullptr)) { delete h; return rc; }
     }
     const hipError_t e = hipStreamSynchronize(nullptr);
+    if (tmp_k) { (void)hipFree(tmp_k); (void)hipFree(tmp_v); (void)hipFree(tmp_i); }
     if (e != hipSuccess) { ua2_set_error("ua2_stage3_create: building the projected-embedding table failed: %s", hipGetErrorString(e)); delete h; return -1; }
   }
   *out = h;
@@ -541,7 +595,7 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
       if (int rc = ua2_linear_launch(a, s)) return rc;
     }
     if (int rc = run_gpt(h, 3, d.decoder, h->xd, R, d.dec_pos + (size_t)i * d.max_rows, nullptr, s, d.n_cb <= 8, false,
-                         scaled ? d.decoder.ln_f : nullptr, scaled, ride ? &rp : nullptr)) return rc;
+                         scaled ? d.decoder.ln_f : nullptr, scaled, ride ? &rp : nullptr, tab && i > 0 && h->ptab_q)) return rc;
     fresh_args(h, a);
     a.dtype = d.dtype; a.prologue = UA2_PRO_NORM; a.epilogue = UA2_EPI_STORE;
     a.M = R; a.N = d.va; a.K = Cd; a.x = h->xd; a.ldx = Cd; a.norm_w = d.decoder.ln_f; a.eps = d.decoder.eps;
@@ -555,8 +609,17 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
                                h->pidx_a, R / 2, s)) return rc;
     if (tab && i + 1 < d.n_cb) {
       const ua2_handover g = hod.rowwise(nullptr);
+      ua2_qkv_gather qg{};
+      if (h->ptab_q) {
+        const ua2_gpt_desc& gd = d.decoder;
+        qg.tab_q = h->ptab_q; qg.tab_k = h->ptab_k; qg.tab_v = h->ptab_v; qg.q_out = h->q; qg.qn = gd.n_head * gd.head_size;
+        qg.esz = d.dtype == UA2_BF16 ? 2 : 4; qg.pos = i + 1;
+        qg.kv.k_pool = h->pools[3][0][0]; qg.kv.v_pool = h->pools[3][1][0]; qg.kv.page_table = gd.page_table; qg.kv.max_pages = gd.max_pages;
+        qg.kv.n_kv = gd.n_kv; qg.kv.n_head = gd.n_head; qg.kv.head_size = gd.head_size;
+      }
+      // with layer 0's q | k | v in hand nothing reads the hand-over of the projected row (its only consumer was that launch)
       if (int rc = ua2_argmax_gather(R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, h->ptab_y, h->ptab_h, h->ptab_ssq,
-                                     (int64_t)i * d.va, Cd, h->xd, scaled ? &g : nullptr, s)) return rc;
+                                     (int64_t)i * d.va, Cd, h->xd, (scaled && !h->ptab_q) ? &g : nullptr, h->ptab_q ? &qg : nullptr, s)) return rc;
     } else if (h->topk == 1) {
       if (int rc = ua2_argmax_embed(d.dtype, R, h->npart_a, h->pmax_a, h->pidx_a, d.out_tokens, w, 1 + i, d.audio_emb,
                                     i * d.va, C, h->curr_h, s)) return rc;
