@@ -550,6 +550,13 @@ typedef struct ua2_stage3_desc {
 
 typedef struct ua2_stage3 ua2_stage3;
 
+/* [round 6] Per-plan tables of the depth decoder (model_new.py:630-641).  `self.projection(_embed_audio(i, sample))` and layer 0's
+ * q | k | v of that row at position i + 1 are functions of the sampled id alone; ua2_stage3_create builds them for all (n_cb - 1) * va
+ * ids by running the frame's own launches on the null stream (a row's bits do not depend on the rows beside it), synchronises, and the
+ * frame's arg-max gathers the rows instead of launching the two GEMVs per step (greedy frames of row-invariant plans; top-k sampling and
+ * the order-free opt-in keep the launches).  Bit-identical ids and logits (tests/test_gpu_lm.py); the tables live in `scratch`:
+ * ua2_stage3_scratch_floats() includes (n_cb - 1) * va * (Cd fp32 + Cd bf16 + Cd / 16 fp32 + q fp32 + k + v) — 1.9 GB at the released
+ * sizes.  Environment, read when a plan is sized and created: UA2_NO_PROJ_TABLE=1 (neither table), UA2_NO_QKV_TABLE=1 (projection only). */
 size_t ua2_stage3_scratch_floats(const ua2_stage3_desc* d);
 int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out);
 void ua2_stage3_destroy(ua2_stage3* h);

@@ -470,3 +470,35 @@ def test_batched_generator_streams_equal_single_runs(golden, sd, monkeypatch):
     for i, t in enumerate(texts):
         single = run(lambda: gen.generate_tts(prompt, "tts", text_token=t, topk=1))
         assert len(single) == 1 and torch.equal(single[0], batch[i]), i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_projected_embedding_and_qkv_tables_leave_every_bit_unchanged(golden, sd, dtype, monkeypatch):
+    """Round 6 (ua2_stage3.hip): inside the depth decoder's loop (model_new.py:630-641) step i + 1 starts from
+    self.projection(_embed_audio(i, sample)), and layer 0 of the decoder then forms q | k | v of that row at position i + 1 — both are
+    functions of the sampled id alone.  A plan builds them once, with the launches the frame itself would run, and the frame's arg-max
+    gathers the rows (14 GEMVs per frame fewer at 8 codebooks).  Plans with the tables, with the projection table only, and without
+    either must agree bit for bit: ids AND audio logits, B = 1 (row-major hand-over) and B = 2, per-frame API and on-device loop."""
+    d, _ = golden
+
+    def run(env, fast):
+        for k in ("UA2_NO_PROJ_TABLE", "UA2_NO_QKV_TABLE"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        out = []
+        for case, B in (("tts1", 1), ("tts2", 2)):
+            tokens, mask = _case(d, case)
+            m = build_product_model(sd, dtype, batch=B)            # the tables are decided and built per plan (ua2_stage3_create)
+            r = product_decode_loop(m, tokens[:B], mask[:B], 6, "audio", fast=fast, collect_logits=not fast)
+            out.append((r["samples"].cpu().clone(), None if fast else r["audio_logits"].cpu().clone()))
+        return out
+
+    for fast in (False, True):
+        base = run(("UA2_NO_PROJ_TABLE",), fast)
+        for env in ((), ("UA2_NO_QKV_TABLE",)):
+            got = run(env, fast)
+            for (s0, l0), (s1, l1) in zip(base, got):
+                assert torch.equal(s0, s1), (env, fast)
+                if l0 is not None:
+                    assert torch.equal(l0, l1), (env, fast)
