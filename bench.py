@@ -721,11 +721,26 @@ def config3_leg(model, dev, B=32, n_text=15, n_reason=53, n_sem=128, frames=32, 
         per_row = 2.0 * (c.n_embd * (c.n_head + 2 * c.n_query_groups) * c.head_size + c.n_head * c.head_size * c.n_embd +
                          3 * c.n_embd * c.intermediate_size)
         flop += per_row * c.n_layer * rows
+    # what the text generators run (evaluation/_generator.py _generate_text): from the second text frame on the understanding /
+    # generation experts are not computed (UA2_FRAME_SKIP_AUDIO_EXPERTS: masked-out outputs, caches never read again) — same text ids
+    ids_full = model._st["frame_log"][:frames, :B, 0].clone()
+    for rep in range(2):
+        torch.cuda.synchronize()
+        model.begin_ragged(prompts)
+        e1.record()
+        log = model.generate_frames(frames, B, 1, skip_audio_experts=True)
+        e2.record()
+        torch.cuda.synchronize()
+        dec_skip_ms = e1.elapsed_time(e2)
+    same_ids = bool(torch.equal(log[:, :, 0], ids_full))
     tf = flop / (pre_ms * 1e-3) / 1e12
     return {"B": B, "prompt_len": L, "prefill_rows": rows, "prefill_ms": round(pre_ms, 2),
             "text_frames": frames, "decode_ms_per_frame": round(dec_ms / frames, 3),
             "text_tokens_per_s": round(B * frames / (dec_ms * 1e-3), 1),
             "clips_per_s_llm_half": round(B / ((pre_ms + dec_ms) * 1e-3), 2),
+            "decode_ms_per_frame_skip_audio_experts": round(dec_skip_ms / frames, 3),
+            "clips_per_s_llm_half_skip_audio_experts": round(B / ((pre_ms + dec_skip_ms) * 1e-3), 2),
+            "skip_audio_experts_text_ids_identical": same_ids,
             "roofline": {"kernel": ("trunk prefill: prep + order-free 256-row-tile MFMA GEMM (ua2_gemm2.hip; opt-in set_order_free_rows(%d)) x 5 Linear x 33 layers, attention included in the time" % order_free_rows)
                                    if order_free_rows else "trunk prefill: prep + row-invariant 128x128 tiled MFMA GEMM (ua2_gemm.hip) x 5 Linear x 33 layers, attention included in the time",
                          "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",

@@ -601,6 +601,14 @@ int ua2_stage3_feedback(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_e
  * (evaluation/tts_task.py:259,274-277; model_new.py:617 computes it every frame), so the audio ids are bit-identical with and
  * without it; the frame log's text column holds -1 for such frames and the next frame's (masked) text token is 0. */
 #define UA2_FRAME_SKIP_TEXT_HEAD 16
+/* mode 1 | UA2_FRAME_SKIP_AUDIO_EXPERTS [round 6]: every row of the frame is a TEXT step of a text-only continuation (the loops of
+ * evaluation/asr_task.py:666-682 and its twins from their second frame on: the fed-back masks are (audio 0, text 1) and no audio step ever
+ * follows).  There audio_step_mask = 0 multiplies both experts' outputs (model_new.py:607 backbone_input, :613 h_final) and nothing reads
+ * their caches again, so the frame does not run audio_understanding_expert / audio_generation_expert (5 of the trunk's 33 layers at the
+ * released sizes): text ids bit-identical (tests/test_gpu_lm.py).  The CALLER vouches for the precondition — the first frame after a prefill
+ * (it consumes the prompt's last token, usually an audio step) and any sequence that will see an audio step later must run without it:
+ * the skipped positions of the experts' caches are left unwritten. */
+#define UA2_FRAME_SKIP_AUDIO_EXPERTS 32
 int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t reason_eos, int32_t reason_card,
                      int32_t use_graph, void* stream);
 /* Expose intermediate buffers for tests: name in {"h_final","text_logits","audio_logits"}. */

@@ -502,3 +502,37 @@ def test_projected_embedding_and_qkv_tables_leave_every_bit_unchanged(golden, sd
                 assert torch.equal(s0, s1), (env, fast)
                 if l0 is not None:
                     assert torch.equal(l0, l1), (env, fast)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_skipping_the_audio_experts_on_text_only_continuations_keeps_the_text_ids(golden, sd, dtype):
+    """UA2_FRAME_SKIP_AUDIO_EXPERTS (round 6): in the text loops (evaluation/asr_task.py:666-682) every frame after the first is a text
+    step whose masks the loop itself set to (audio 0, text 1); audio_step_mask = 0 multiplies both experts' outputs (model_new.py:607,
+    :613) and no audio step follows, so the executor does not run them.  Text ids must equal the full frames' bit for bit — on the
+    ASR golden (whose last prompt token is an AUDIO step: the first frame runs whole) and on a batch of two; the fp32 ids are the
+    reference's own.  Outside mode 1 the flag is refused."""
+    d, _ = golden
+    dev = "cuda"
+
+    def run(case, B, skip, frames=10):
+        tokens, mask = _case(d, case)
+        m = build_product_model(sd, dtype, batch=B)
+        tokens, mask = tokens[:B].to(dev), mask[:B].to(dev)
+        L = tokens.shape[1]
+        m.reset_caches()
+        pos = torch.arange(0, L, device=dev).unsqueeze(0).repeat(B, 1)
+        m.forward_prefix(tokens[:, :-1], labels=tokens[:, 1:, :-1], tokens_mask=mask, loss_mask=mask, input_pos=pos[:, :-1])
+        m.begin_decode(tokens[:, -1:], mask[:, -1:], torch.tensor([L - 1], device=dev))
+        first = m.generate_frames(4, B, 1, skip_audio_experts=skip).cpu().clone()       # two calls: the state survives the call boundary
+        rest = m.generate_frames(frames - 4, B, 1, skip_audio_experts=skip).cpu().clone()
+        return torch.cat([first, rest])
+
+    for case, B in (("asr1", 1), ("tts2", 2)):
+        full, skip = run(case, B, False), run(case, B, True)
+        assert torch.equal(full[:, :, 0], skip[:, :, 0]), case
+    if dtype == torch.float32:
+        got = run("asr1", 1, True)
+        assert got[:, 0, 0].tolist() == d["asr1_samples"][:, 0, 0].tolist()[:10]
+    m = build_product_model(sd, dtype, batch=1)
+    with pytest.raises(ValueError):
+        m.generate_frames(1, 1, 0, skip_audio_experts=True)

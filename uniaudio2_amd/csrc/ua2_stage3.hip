@@ -431,7 +431,10 @@ extern "C" void ua2_stage3_destroy(ua2_stage3* h) {
 }
 
 // identity: rows are sequences 0..R-1 (decode frames) -> no row_seq indirection in the kernels
-static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
+// skip_experts (UA2_FRAME_SKIP_AUDIO_EXPERTS): every row of the frame is a TEXT step of a text-only continuation — the understanding and
+// generation experts' outputs are multiplied by audio_step_mask = 0 (model_new.py:607, :613) and their caches are never read again, so
+// the two GPTs are not run; the blends see zeros in their place and select the text / backbone operand exactly as before.
+static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s, bool skip_experts = false) {
   UA2_CHECK(h && R > 0 && R <= h->d.max_rows, "ua2_stage3_trunk: R=%d out of range", R);
   ua2_stage3_desc d = h->d;
   if (identity) d.row_seq = nullptr;
@@ -449,13 +452,15 @@ static int trunk_impl(ua2_stage3* h, int32_t R, bool identity, hipStream_t s) {
   ua2_handover e0{}, e1{}, e2{};
   if (scaled) { e0 = ho.rowwise(h->norms[0][0][0]); e1 = ho.rowwise(h->norms[1][0][0]); e2 = ho.rowwise(h->norms[2][0][0]); }
   if (int rc = ua2_embed_frame(d.dtype, R, C, d.n_cb, d.va, d.tokens, d.mask, d.audio_emb, d.wte, h->xa, h->text, &e0, s)) return rc;
-  if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
+  if (!skip_experts)
+    if (int rc = run_gpt(h, 0, d.und, h->xa, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
   // backbone_input = h_audio*audio_step + text_embeds*text_step   (model_new.py:607)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xa, d.und.ln_f, d.und.eps, h->text, d.mask, w, 0, d.n_cb, h->xb, nullptr, &e1, s)) return rc;
   if (int rc = run_gpt(h, 1, d.backbone, h->xb, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
   // h = ln_f(x); generation_input = h*audio_step                   (model_new.py:609-610)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xb, d.backbone.ln_f, d.backbone.eps, nullptr, d.mask, w, 0, -1, h->xg, h->hbuf, &e2, s)) return rc;
-  if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
+  if (!skip_experts)
+    if (int rc = run_gpt(h, 2, d.gen, h->xg, R, d.row_pos, d.row_seq, s, false, grouped, nullptr, scaled)) return rc;
   // h_final = h_audio*audio_step + h*text_step                     (model_new.py:613)
   if (int rc = ua2_rmsnorm_blend(R, C, h->xg, d.gen.ln_f, d.gen.eps, h->hbuf, d.mask, w, 0, d.n_cb, h->hfin, nullptr, nullptr, s)) return rc;
   return 0;
@@ -663,10 +668,12 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
   UA2_CHECK(h != nullptr, "ua2_stage3_frame: NULL handle");
   hipStream_t s = (hipStream_t)stream;
   const bool skip_text = mode >= 0 && (mode & UA2_FRAME_SKIP_TEXT_HEAD) != 0;
-  if (mode >= 0) mode &= ~UA2_FRAME_SKIP_TEXT_HEAD;
+  const bool skip_experts = mode >= 0 && (mode & UA2_FRAME_SKIP_AUDIO_EXPERTS) != 0;
+  if (mode >= 0) mode &= ~(UA2_FRAME_SKIP_TEXT_HEAD | UA2_FRAME_SKIP_AUDIO_EXPERTS);
   UA2_CHECK(!skip_text || mode == 0 || mode == 2, "ua2_stage3_frame: UA2_FRAME_SKIP_TEXT_HEAD goes with the audio-feedback modes (0, 2)");
+  UA2_CHECK(!skip_experts || mode == 1, "ua2_stage3_frame: UA2_FRAME_SKIP_AUDIO_EXPERTS goes with the text-feedback mode (1)");
   auto body = [&](hipStream_t st) -> int {
-    if (int rc = trunk_impl(h, R, true, st)) return rc;
+    if (int rc = trunk_impl(h, R, true, st, skip_experts)) return rc;
     if (int rc = heads_impl(h, R, mode == 1, st, skip_text)) return rc;
     if (mode < 0) return 0;
     return feedback_impl(h, R, mode, reason_eos, reason_card, st, skip_text ? 1 : 0);
@@ -675,7 +682,7 @@ extern "C" int ua2_stage3_frame(ua2_stage3* h, int32_t R, int32_t mode, int32_t 
   int tbits, cbits;
   memcpy(&tbits, &h->temperature, sizeof(int));
   memcpy(&cbits, &h->cfg_scale, sizeof(int));
-  const auto key = std::make_tuple((int)R, (int)mode | (skip_text ? UA2_FRAME_SKIP_TEXT_HEAD : 0), (int)reason_eos, (int)reason_card, (int)h->topk, tbits, cbits);
+  const auto key = std::make_tuple((int)R, (int)mode | (skip_text ? UA2_FRAME_SKIP_TEXT_HEAD : 0) | (skip_experts ? UA2_FRAME_SKIP_AUDIO_EXPERTS : 0), (int)reason_eos, (int)reason_card, (int)h->topk, tbits, cbits);
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     hipGraph_t graph = nullptr;

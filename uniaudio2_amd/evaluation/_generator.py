@@ -281,7 +281,10 @@ class GeneratorBase:
         text, frame, done = [], 0, False
         while not done and frame < max_frames:
             n = min(self.chunk_frames, max_frames - frame)
-            log = self._model.generate_frames(n, 1, 1, max_pos=L + max_frames).cpu()
+            # text-only continuation: from its second frame on the understanding / generation experts are dead code (their outputs are
+            # masked out and their caches never read again: UA2_FRAME_SKIP_AUDIO_EXPERTS, identical text ids; UA2_KEEP_AUDIO_EXPERTS=1 runs them)
+            log = self._model.generate_frames(n, 1, 1, max_pos=L + max_frames,
+                                              skip_audio_experts=os.environ.get("UA2_KEEP_AUDIO_EXPERTS") is None).cpu()
             for f in range(n):
                 t = int(log[f, 0, 0])
                 if t == TEXT_EOS:

@@ -135,6 +135,7 @@ class Model_stage3(nn.Module):
         self._sampling = None
         self._cfg = 1.0
         self._pos_hi = 0
+        self._text_fed_back = False    # the last frame run was a text-feedback frame (every row now holds masks audio 0 / text 1)
         if getattr(self, "order_free_rows", 0) > 0 and dtype == torch.bfloat16:
             self.set_order_free_rows(self.order_free_rows)
 
@@ -186,6 +187,7 @@ class Model_stage3(nn.Module):
         """tokens (R, 9) any int dtype, mask (R, 9) bool, pos (R,), seq (R,) -> device state."""
         st = self._st
         R = tokens.shape[0]
+        self._text_fed_back = False                # tokens / masks from outside: nothing is known about the rows' step kinds
         st["tokens"][:R].copy_(tokens)
         st["mask"][:R].copy_(tokens_mask)
         st["row_pos"][:R].copy_(pos)
@@ -286,7 +288,7 @@ class Model_stage3(nn.Module):
     @torch.inference_mode()
     def generate_frames(self, n_frames: int, batch: int, mode: int, reason_eos: int = -1, reason_card: int = 0,
                         max_pos: Optional[int] = None, use_graph: bool = True, frame_events=None,
-                        skip_text_head: bool = False) -> torch.Tensor:
+                        skip_text_head: bool = False, skip_audio_experts: bool = False) -> torch.Tensor:
         """Runs `n_frames` frames back to back from the state left by the previous frame (first
         call: after `begin_decode`).  mode 0 = audio feedback (evaluation/tts_task.py:259-280),
         1 = text feedback (evaluation/asr_task.py:668-682; the depth decoder is skipped there — its samples are
@@ -299,6 +301,8 @@ class Model_stage3(nn.Module):
             if mode not in (0, 2):
                 raise ValueError("skip_text_head applies to the audio-feedback modes (0, 2)")
             mode = mode | 16                                  # UA2_FRAME_SKIP_TEXT_HEAD
+        if skip_audio_experts and mode != 1:
+            raise ValueError("skip_audio_experts applies to the text-feedback mode (1)")
         self._need()
         st = self._st
         start = int(st["counters"][0].item())
@@ -314,8 +318,13 @@ class Model_stage3(nn.Module):
         self._pos_hi += n_frames
         s = ops.stream()
         for i in range(n_frames):
-            check(lib.ua2_stage3_frame(self._h, batch, mode, reason_eos, reason_card, int(use_graph), s),
+            # skip_audio_experts (text-only continuations: asr_task.py:666-682 and twins): from the session's SECOND text-feedback frame on
+            # every row is a text step fed back by the executor itself (masks audio 0 / text 1) — the first frame consumes the prompt's
+            # last token, which may be an audio step, and runs whole.  UA2_FRAME_SKIP_AUDIO_EXPERTS = 32.
+            m = mode | 32 if (skip_audio_experts and self._text_fed_back) else mode
+            check(lib.ua2_stage3_frame(self._h, batch, m, reason_eos, reason_card, int(use_graph), s),
                   "ua2_stage3_frame")
+            self._text_fed_back = mode == 1
             if frame_events is not None:           # measurement hook: one event after every frame (bench.py p50 / p99)
                 frame_events[i].record()
         return st["frame_log"][start:start + n_frames, :batch]
