@@ -369,7 +369,7 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
     h->ptab_y = b + c.ptab_y; h->ptab_h = b + c.ptab_h; h->ptab_ssq = b + c.ptab_ssq;
     h->ptab_ho = h->scaled;
     const int C = d->backbone.n_embd, Cd = d->decoder.n_embd;
-    const int chunk = std::min(64, d->max_batch);
+    const int chunk = std::min(64, d->max_rows);          // operand rows staged in the trunk's first row buffer (max_rows x C): a B = 1 plan still builds 64 rows per launch
     void *tmp_k = nullptr, *tmp_v = nullptr;
     int32_t* tmp_i = nullptr;          // [64] positions, [64] page table (row r -> page r)
     if (c.ptab_qkv) {
@@ -381,12 +381,12 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
     }
     for (size_t row0 = 0; row0 < c.ptab_rows; row0 += chunk) {
       const int n = (int)std::min<size_t>(chunk, c.ptab_rows - row0);
-      if (d->dtype == UA2_BF16) hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_BF16>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->curr_h);
-      else hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_F32>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->curr_h);
+      if (d->dtype == UA2_BF16) hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_BF16>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->xa);
+      else hipLaunchKernelGGL(emb_rows_f32_kernel<UA2_F32>, dim3(std::min(1024, n * 4)), dim3(256), 0, nullptr, d->audio_emb, (long long)row0, n, C, h->xa);
       ua2_linear_args a;
       fresh_args(h, a);
       a.dtype = d->dtype; a.prologue = UA2_PRO_CAST; a.epilogue = UA2_EPI_STORE;
-      a.M = n; a.N = Cd; a.K = C; a.x = h->curr_h; a.ldx = C; a.w0 = d->projection; a.y = h->ptab_y + row0 * Cd; a.ldy = Cd;
+      a.M = n; a.N = Cd; a.K = C; a.x = h->xa; a.ldx = C; a.w0 = d->projection; a.y = h->ptab_y + row0 * Cd; a.ldy = Cd;
       if (h->ptab_ho) {
         a.y_norm_w = h->norms[3][0][0]; a.y_ssq = h->ptab_ssq + row0 * (Cd / 16);
         a.y_h = reinterpret_cast<unsigned short*>(h->ptab_h) + row0 * Cd; a.ldh = Cd;
