@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UA2_VERSION 9
+#define UA2_VERSION 10
 
 enum ua2_dtype { UA2_F32 = 0, UA2_BF16 = 1 };
 
@@ -212,6 +212,15 @@ typedef struct ua2_linear_args {
   const float* y_ln_w;
   const float* y_ln_b;
   float y_ln_eps;
+  /* [v10] Optional scratch for the RANGE split of row-invariant launches (UA2_SUM_ORDER_INVARIANT, UA2_BF16, UA2_EPI_RESIDUAL, K = 8192,
+     33-64 rows: the batched-decode down-projections, lit_model.py:591-595).  The decode kernel adds `waves` partial chains over fixed K
+     ranges in range order; with range_ws a launch may run each range on its own workgroups (the range's operand staged once per
+     workgroup, wide column groups) and add the partials [waves][ceil(M/16)][ceil(N/16)][256] in a second launch IN THAT ORDER from zero —
+     the same sums, the same bits as without it (tests/test_gpu_invariance.py).  Needs waves * ceil(M/16)*16 * ceil(N/16)*16 * 4 bytes
+     (16 ranges: 12.6 MB at 64 x 3072), 16-byte aligned; NULL = never.  Measured slower than the one-launch form in the LM's frame
+     (profiles/r6_range_split.txt: 15.3 + 5.9 us against 20.4), so the frame executor leaves it NULL unless UA2_RANGE_SPLIT=1. */
+  float* range_ws;
+  size_t range_ws_bytes;
 } ua2_linear_args;
 
 int ua2_linear(const ua2_linear_args* a, void* stream);
@@ -231,7 +240,8 @@ size_t ua2_linear_workspace_bytes(int dtype, int64_t M, int64_t K);
 int ua2_debug_force_general_linear(int on);
 
 /* Test hooks (ABI v9).  ua2_debug_kernel_launches: how many launches of a kernel family this process has issued so far —
- * "gemm2" (ua2_gemm2.hip, the order-free many-row GEMM), "gemm" (ua2_gemm.hip's tiled kernel), "skinny2", "gemv"; -1 for an unknown
+ * "gemm2" (ua2_gemm2.hip, the order-free many-row GEMM), "gemm" (ua2_gemm.hip's tiled kernel), "skinny2", "gemv", "rsplit" ([v10] the range split
+ * of ua2_skinny.hip: main + combine count once); -1 for an unknown
  * name.  A test that claims "the order-free kernel ran" reads the counter on both sides of the call instead of trusting the
  * launcher's rules.  ua2_debug_refresh_env: the launchers read their UA2_* tuning / A-B environment variables ONCE (they used to
  * call getenv on every launch); a process that changes one of them afterwards (the tests do) calls this to have them read again. */

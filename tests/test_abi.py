@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} declared in ua2hip.h but not exported by libua2hip.so"
     assert set(_lib.exported_symbols()) == declared, (set(_lib.exported_symbols()) ^ declared)
-    assert _lib.lib.ua2_version() == 9
+    assert _lib.lib.ua2_version() == 10
 
 
 def test_packed_size_and_struct_layout():

@@ -519,3 +519,50 @@ def test_tiled_gemm_ring_is_repeatable(M, N, K, bmt, linear_mode):
         got = run(False)
         torch.cuda.synchronize()
         assert torch.equal(got, ref), (i, (got - ref).abs().max().item())
+
+
+@pytest.mark.parametrize("N", [3072, 2048])
+def test_range_split_of_the_k8192_down_projection_keeps_every_bit(N, linear_mode):
+    """Round 6 (ua2hip.h range_ws, csrc/ua2_skinny.hip rsplit_*): at 33-64 rows the K = 8192 RESIDUAL launches of the row-invariant plan
+    may run each of the decode kernel's 16 K ranges on its own workgroups and add the range partials in range order in a second launch.
+    y, the scaled-norm hand-over (fragment-order operand, per-16-column sums of squares) and a consumer fed with them must equal, bit for
+    bit, the launch without the scratch AND the rows' single-row runs through the decode kernel; the counter says the split really ran."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import EPI_RESIDUAL, PRO_CAST, lib
+    dev, dt, K = torch.device("cuda"), torch.bfloat16, 8192
+    g = torch.Generator().manual_seed(N)
+    w = ops.pack_linear((torch.randn(N, K, generator=g) * K ** -0.5).to(dev), dt)
+    nw = (1.0 + 0.2 * torch.randn(N, generator=g)).to(dev)
+    x = torch.randn(64, K, generator=g).to(dev)
+    res = (2.0 * torch.randn(64, N, generator=g)).to(dev)
+    rws = torch.empty(16 * 64 * N, device=dev)
+
+    def run(rows, scratch, mode=0):
+        M = rows.stop - rows.start
+        linear_mode(mode)
+        y = torch.empty(M, N, device=dev)
+        ssq = torch.zeros(M, N // 16, device=dev)
+        pk = torch.zeros((M + 15) // 16 * 16 * N, dtype=dt, device=dev)
+        h = torch.zeros(M, N, dtype=dt, device=dev)
+        kw = dict(dtype=dt, M=M, N=N, K=K, w0=w, prologue=PRO_CAST, epilogue=EPI_RESIDUAL, x=x[rows].contiguous(), y=y,
+                  resid=res[rows].contiguous(), y_norm_w=nw, y_ssq=ssq, workspace=ops.linear_workspace(dt, M, K, dev))
+        if M > 16:
+            kw["y_packed"] = pk
+        else:
+            kw["y_h"] = h
+        n0 = lib.ua2_debug_kernel_launches(b"rsplit")
+        ops.linear(**kw, range_ws=rws if scratch else None)
+        torch.cuda.synchronize()
+        return y, ssq, (_unpack_operand(pk, M, N) if M > 16 else h), lib.ua2_debug_kernel_launches(b"rsplit") - n0
+
+    singles = [run(slice(r, r + 1), False, 2) for r in range(64)]
+    y1 = torch.cat([s[0] for s in singles]); q1 = torch.cat([s[1] for s in singles]); h1 = torch.cat([s[2] for s in singles])
+    for M in (33, 48, 64):
+        y0, q0, h0, n_plain = run(slice(0, M), False)
+        ys, qs, hs, n_split = run(slice(0, M), True)
+        assert n_plain == 0 and n_split == 1, (M, n_plain, n_split)
+        for got in ((y0, q0, h0), (ys, qs, hs)):
+            assert torch.equal(got[0], y1[:M]) and torch.equal(got[1], q1[:M]) and torch.equal(got[2], h1[:M]), M
+    for M in (17, 32):                                       # outside the form (one or two row tiles): the scratch is ignored
+        y, q, h, n = run(slice(0, M), True)
+        assert n == 0 and torch.equal(y, y1[:M]) and torch.equal(q, q1[:M]) and torch.equal(h, h1[:M]), M

@@ -45,7 +45,8 @@ class LinearArgs(C.Structure):
                 ("bias", vp), ("bias1", vp), ("act_kind", i32),
                 ("y_norm_w", vp), ("y_h", vp), ("ldh", i32), ("y_ssq", vp), ("x_h", vp), ("x_ssq", vp),
                 ("split_ws", vp), ("split_ws_bytes", C.c_size_t), ("sum_order", i32),
-                ("y_ln_w", vp), ("y_ln_b", vp), ("y_ln_eps", f32)]
+                ("y_ln_w", vp), ("y_ln_b", vp), ("y_ln_eps", f32),
+                ("range_ws", vp), ("range_ws_bytes", C.c_size_t)]
 
 
 class AttnArgs(C.Structure):

@@ -158,7 +158,7 @@ inline void ua2_allow_big_lds() {
 }
 
 // ---- test hooks (ua2hip.h ABI v9): launch counters per kernel family, and UA2_* environment variables read once -------------
-enum { UA2_CNT_GEMM2 = 0, UA2_CNT_GEMM = 1, UA2_CNT_SKINNY2 = 2, UA2_CNT_GEMV = 3, UA2_CNT_N = 4 };
+enum { UA2_CNT_GEMM2 = 0, UA2_CNT_GEMM = 1, UA2_CNT_SKINNY2 = 2, UA2_CNT_GEMV = 3, UA2_CNT_RSPLIT = 4, UA2_CNT_N = 5 };
 extern std::atomic<int64_t> g_ua2_launches[UA2_CNT_N];
 extern std::atomic<int> g_ua2_env_gen;              // bumped by ua2_debug_refresh_env
 inline void ua2_count_launch(int family) { g_ua2_launches[family].fetch_add(1, std::memory_order_relaxed); }

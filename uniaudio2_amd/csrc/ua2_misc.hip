@@ -22,7 +22,7 @@ extern "C" int ua2_version(void) { return UA2_VERSION; }
 std::atomic<int64_t> g_ua2_launches[UA2_CNT_N];
 std::atomic<int> g_ua2_env_gen{0};
 extern "C" int64_t ua2_debug_kernel_launches(const char* family) {
-  static const char* const names[UA2_CNT_N] = {"gemm2", "gemm", "skinny2", "gemv"};
+  static const char* const names[UA2_CNT_N] = {"gemm2", "gemm", "skinny2", "gemv", "rsplit"};
   if (!family) return -1;
   for (int i = 0; i < UA2_CNT_N; ++i)
     if (!strcmp(family, names[i])) return g_ua2_launches[i].load(std::memory_order_relaxed);

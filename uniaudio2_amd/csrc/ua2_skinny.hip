@@ -224,6 +224,132 @@ __global__ __launch_bounds__(NWV / RPW * 64) void skinny2_kernel(const ua2_linea
   }
 }
 
+// ---- K ranges across WORKGROUPS (round 6; the "wide-column K split + combine" of profiles/r4_notes.md §6) -----------------------------
+// At 33-64 rows the K = 8192 down-projection is bounded by the operand every 16-column workgroup pulls in again (192 x 1.26 MB = 242 MB
+// through L2 for 50 MB of weights; ring depth moves nothing, r6 notes §10).  Here a workgroup owns ONE of the NWV ranges and a wide group of
+// column tiles: its 4 waves share the range's operand (MT x CH fragments, staged once in LDS: 64 KiB at 64 rows) and hold CT column
+// tiles' weights each, all in flight at once — 256 workgroups x (64 KiB operand + 48 CT KiB weights).  Each wave's MFMA chain over the
+// range's chunks is the chain wave `range` of skinny2_kernel / gemv_kernel runs (same fragments, same order, from zero); the partial
+// tiles go to range_ws as [range][row tile][column tile][256 floats] in accumulator order, and rsplit_combine_kernel adds them in range
+// order from 0.f — `sacc += red[w]` of the kernels above, word for word — and runs the same linear_epilogue.  Same bits
+// (tests/test_gpu_invariance.py::test_range_split_...).
+// MEASURED (profiles/r6_range_split.txt): main 15.3 us (trunk, 3072 columns) / 13.3 (depth decoder, 2048) + combine 5.9 against 20.4 / 14.3 us for
+// skinny2_kernel — the B = 64 frame 4.93 -> 5.09 ms.  The main launch is a weight burst (6 us of HBM + a round trip), then the staged
+// operand's barrier, then 192 MFMAs per wave on one wave per SIMD, then 12 KiB of partial stores per wave: phases in a row, and the 12.6 MB
+// of partials cost a second launch.  So the form is OPT-IN: an op-level caller that hands range_ws gets it; the frame executor does not
+// (UA2_RANGE_SPLIT=1 makes it, for A/B).
+template <int CT, int MT, int CH>
+__global__ __launch_bounds__(256, 1) void rsplit_main_kernel(const ua2_linear_args a, const u32x4* __restrict__ apack, float* __restrict__ part, const int nranges) {
+  constexpr int DT = UA2_BF16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* alds = reinterpret_cast<u32x4*>(smem);         // [MT][CH][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int range = blockIdx.y, nchunks = nranges * CH;
+  const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
+  const int c0 = range * CH;
+  const unsigned voff = (unsigned)(c0 * 64 + lane) * 16u;
+  // weights first (HBM: the long round trip), non-temporal
+  u32x4 wf[CT][CH];
+  int nt[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    nt[c] = ((int)blockIdx.x * 4 + wave) * CT + c;
+    const char* base = reinterpret_cast<const char*>(a.w0) + (size_t)min(nt[c], ntiles - 1) * nchunks * 1024;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, nchunks * 1024, kRsrcFlags);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) wf[c][u] = __builtin_amdgcn_raw_buffer_load_b128(wr, voff, u * 1024, 2);
+  }
+  // the range's operand, once per workgroup: MT x CH fragments over the 4 waves, through registers into LDS
+  const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(apack), 0, (unsigned)mtiles * (unsigned)(nchunks * 1024), kRsrcFlags);
+  constexpr int NF = MT * CH, FPW = (NF + 3) / 4;
+  u32x4 stg[FPW];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const int f = min(wave + 4 * k, NF - 1), mi = f / CH, u = f - mi * CH;
+    stg[k] = __builtin_amdgcn_raw_buffer_load_b128(ar, voff, (unsigned)min(mi, mtiles - 1) * (unsigned)(nchunks * 1024) + (unsigned)u * 1024u, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const int f = wave + 4 * k;
+    if (f < NF) alds[f * 64 + lane] = stg[k];
+  }
+  __syncthreads();
+  f32x4 acc[CT][MT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[c][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < CH; ++u)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      AFrag<DT> f;
+      f.v = alds[(mi * CH + u) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) f.mma(wf[c][u], acc[c][mi]);
+    }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if (nt[c] >= ntiles) continue;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      if (mi >= mtiles) break;
+      *reinterpret_cast<f32x4*>(part + ((((size_t)range * mtiles + mi) * ntiles + nt[c]) * 256 + lane * 4)) = acc[c][mi];
+    }
+  }
+}
+
+template <int EPI, int NR>
+__global__ __launch_bounds__(256) void rsplit_combine_kernel(const ua2_linear_args a, const float* __restrict__ part) {
+  constexpr int DT = UA2_BF16;
+  const int mtiles = (a.M + 15) / 16, ntiles = (a.N + 15) / 16;
+  const int nt = blockIdx.x % ntiles, mi = blockIdx.x / ntiles;
+  const int tid = threadIdx.x, row = tid >> 4, col = tid & 15;
+  const int srcl = (((row >> 2) << 4) + col) * 4 + (row & 3);
+  const int m0 = mi * 16;
+  EpiPre pre;
+  epilogue_prefetch<DT, EPI>(a, nt, row, col, pre, m0);
+  const float* p = part + (((size_t)mi * ntiles + nt) * 256 + srcl);
+  const size_t rstride = (size_t)mtiles * ntiles * 256;
+  float t[NR];                                           // all NR loads in flight, then the sum in range order from zero
+#pragma unroll
+  for (int w = 0; w < NR; ++w) t[w] = p[(size_t)w * rstride];
+  float v[1];
+  float sacc = 0.f;
+#pragma unroll
+  for (int w = 0; w < NR; ++w) sacc += t[w];
+  v[0] = sacc;
+  int tile[1] = {nt};
+  linear_epilogue<DT, EPI, 1>(a, v, tile, row, col, pre, m0, min(16, a.M - m0));
+}
+
+// Returns 0 when launched, 1 when the problem is outside this form.
+int rsplit_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipStream_t s) {
+  if (!a.range_ws || a.dtype != UA2_BF16 || a.epilogue != UA2_EPI_RESIDUAL || a.prologue == UA2_PRO_SCALED || a.K % 32) return 1;
+  const int nchunks = a.K / 32, mtiles = ua2_ceil_div(a.M, 16), ntiles = ua2_ceil_div(a.N, 16);
+  if (geo.waves != 16 || nchunks != 16 * 16 || mtiles < 3 || mtiles > 4 || a.N % 16) return 1;       // K = 8192, 33-64 rows
+  const int ct = ntiles % 12 == 0 && ntiles / 12 >= 12 ? 3 : (ntiles % 8 == 0 ? 2 : 0);               // 4 waves x CT tiles per workgroup, >= 192 workgroups with 3
+  if (!ct) return 1;
+  const size_t need = (size_t)geo.waves * mtiles * ntiles * 256 * sizeof(float);
+  if (a.range_ws_bytes < need || (reinterpret_cast<uintptr_t>(a.range_ws) & 15)) return 1;
+  const u32x4* apack = reinterpret_cast<const u32x4*>(a.x_packed ? a.x_packed : a.workspace);
+  const dim3 grid(ntiles / (4 * ct), geo.waves);
+  constexpr size_t smem = 4 * 16 * 1024;
+  if (ct == 3) {
+    constexpr auto kern = rsplit_main_kernel<3, 4, 16>;
+    ua2_allow_big_lds<kern>();
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a, apack, a.range_ws, geo.waves);
+  } else {
+    constexpr auto kern = rsplit_main_kernel<2, 4, 16>;
+    ua2_allow_big_lds<kern>();
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a, apack, a.range_ws, geo.waves);
+  }
+  hipLaunchKernelGGL((rsplit_combine_kernel<UA2_EPI_RESIDUAL, 16>), dim3(ntiles * mtiles), dim3(256), 0, s, a, a.range_ws);
+  ua2_count_launch(UA2_CNT_RSPLIT);
+  UA2_LAUNCH_CHECK();
+  return 0;
+}
+
 // VGPRs a variant needs: resident weights + operand ring + accumulators + addressing / epilogue slack.  Variants over the
 // per-wave budget (512 per SIMD shared by NWV / 4 waves) spill and are not built.
 constexpr int regs_needed(int nm, int ct, int mt, int ch, int la, int nwv = 16, bool sc = false, int wd = 0, int rpw = 1) {
@@ -358,6 +484,8 @@ int ua2_skinny2_try_launch(const ua2_linear_args& a, ua2_gemv_geometry geo, hipS
   // the packed operand is addressed through one buffer resource (32-bit size / offsets): past 4 GiB the loads would wrap
   // and return zeros — leave such a problem to the tiled kernel
   if ((uint64_t)ua2_ceil_div(a.M, 16) * (uint64_t)nchunks * 1024ull >= (1ull << 32)) return 1;
+  if (getenv("UA2_SKINNY2") == nullptr)                   // a forced variant means the sweep tool is measuring skinny2_kernel itself
+    if (const int rc = rsplit_try_launch(a, geo, s); rc <= 0) return rc;
   const int ch = nchunks / geo.waves;
   const int nm = a.epilogue == UA2_EPI_SWIGLU ? 2 : 1;
   Variant v = pick_variant(a, geo.waves, ch, nm);

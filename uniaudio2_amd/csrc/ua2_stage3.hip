@@ -47,6 +47,8 @@ struct ua2_stage3 {
   // and layer 0's q|k|v launch of steps 1 .. n_cb - 1 disappears as well
   float* ptab_q = nullptr;
   void *ptab_k = nullptr, *ptab_v = nullptr;
+  float* range_ws = nullptr;   // range-split scratch of the row-invariant 33-64-row down-projections (ua2_linear_args.range_ws): same bits
+  size_t range_ws_bytes = 0;
   float* split_ws = nullptr;   // K-slab scratch of the order-free GEMM (ua2_linear_args.split_ws): handed to launches under UA2_SUM_ORDER_FREE only
   size_t split_ws_bytes = 0;
   bool scaled = false;
@@ -68,7 +70,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct Carve {
   size_t xa, text, xb, hbuf, xg, hfin, q, act, yattn, xd, curr_h, text_logits, audio_logits, pmax_t, pidx_t,
-      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, ptab_y, ptab_h, ptab_ssq, ptab_rows, ptab_q, ptab_k, ptab_v, ptab_qkv, total;
+      pmax_a, pidx_a, gemm_ws, gemm_ws_floats, act_ws, xh, xpk, ssq, split, split_floats, ptab_y, ptab_h, ptab_ssq, ptab_rows, ptab_q, ptab_k, ptab_v, ptab_qkv, range, range_floats, total;
 };
 
 Carve carve(const ua2_stage3_desc& d) {
@@ -99,6 +101,9 @@ Carve carve(const ua2_stage3_desc& d) {
   // the narrow projections at ~1000 rows): plans that can hold such launches only
   c.split_floats = (d.dtype == UA2_BF16 && R >= 256) ? (size_t)16 << 20 : 0;
   c.split = take(c.split_floats);
+  // range-split scratch: 16 ranges x 64 rows x the widest down-projection output, plans that can hold 33-64-row decode batches
+  c.range_floats = (d.dtype == UA2_BF16 && d.max_batch >= 33 && getenv("UA2_RANGE_SPLIT") != nullptr) ? (size_t)16 * 64 * std::max(C, Cd) : 0;   // opt-in: measured slower in the frame (ua2_skinny.hip rsplit_*)
+  c.range = take(c.range_floats);
   // projected-embedding table: (n_cb - 1) * va rows of [Cd fp32 | Cd bf16 | Cd / 16 fp32] (the last codebook's sample is never projected);
   // UA2_NO_PROJ_TABLE=1 keeps the per-step projection launch (A/B, and plans that cannot spare ~1.1 GB at the released sizes)
   c.ptab_rows = (d.n_cb > 1 && d.va > 0 && d.projection && d.audio_emb && Cd % 32 == 0 && getenv("UA2_NO_PROJ_TABLE") == nullptr) ? (size_t)(d.n_cb - 1) * d.va : 0;
@@ -268,6 +273,7 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     if (pack_act) a.x_packed = h->act_ws;
     if (scaled) ho.produce(a, l + 1 < g.n_layer ? h->norms[gi][0][l + 1] : final_norm_w);   // x after the MLP -> the next layer's norm_1 + qkv
     a.sum_order = order; free_scratch(a);
+    a.range_ws = h->range_ws; a.range_ws_bytes = h->range_ws_bytes;      // 33-64 rows, K = 8192: one K range per workgroup + an in-order combine (same bits)
     if (int rc = launch(a, 2)) return rc;
   }
   return 0;
@@ -355,6 +361,7 @@ extern "C" int ua2_stage3_create(const ua2_stage3_desc* d, ua2_stage3** out) {
   h->act_ws = b + c.act_ws;
   h->xh = b + c.xh; h->xpk = b + c.xpk; h->ssq = b + c.ssq;
   h->split_ws = c.split_floats ? b + c.split : nullptr; h->split_ws_bytes = c.split_floats * sizeof(float);
+  h->range_ws = c.range_floats ? b + c.range : nullptr; h->range_ws_bytes = c.range_floats * sizeof(float);
   // the scaled contract is the bf16 executor's (fp32 keeps the reference's operation order); A/B hook: UA2_NO_SCALED=1
   // Plans for more than 64 live sequences keep the prep form as well: at 256 rows the consumers' per-pass row-scale work and
   // the producers' fragment-order stores cost more than the 140 prep launches they replace (12.6 vs 13.7 ms per frame).  The

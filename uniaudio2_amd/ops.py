@@ -63,7 +63,7 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
            w1=None, y=None, ldy=None, resid=None, ldr=None, part_max=None, part_idx=None,
            forbid=None, row_pos=None, row_seq=None, rope_cos=None, rope_sin=None, q_out=None, kv=None, launch=True,
            norm_b=None, norm_kind=0, out_scale=None, rope_mode=0, workspace=None, bias=None, bias1=None, act_kind=0,
-           y_packed=None, x_packed=None, y_norm_w=None, y_h=None, ldh=0, y_ssq=None, x_h=None, x_ssq=None, split_ws=None, sum_order=0, y_ln=None):
+           y_packed=None, x_packed=None, y_norm_w=None, y_h=None, ldh=0, y_ssq=None, x_h=None, x_ssq=None, split_ws=None, sum_order=0, y_ln=None, range_ws=None):
     a = LinearArgs()
     a.dtype, a.prologue, a.epilogue = dtype_code(dtype), prologue, epilogue
     a.M, a.N, a.K = M, N, K
@@ -84,6 +84,8 @@ def linear(*, dtype, M, N, K, w0, prologue=PRO_CAST, epilogue=EPI_STORE, x=None,
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     if split_ws is not None:
         a.split_ws, a.split_ws_bytes = ptr(split_ws), split_ws.numel() * split_ws.element_size()
+    if range_ws is not None:       # scratch of the range split of row-invariant 33-64-row launches (ua2hip.h [v10]): same bits with and without
+        a.range_ws, a.range_ws_bytes = ptr(range_ws), range_ws.numel() * range_ws.element_size()
     a.sum_order = sum_order
     if y_ln is not None:                 # (w, b, eps): LayerNorm hand-over of a RESIDUAL launch (ua2hip.h y_ln_w)
         a.y_ln_w, a.y_ln_b, a.y_ln_eps = ptr(y_ln[0]), ptr(y_ln[1]), float(y_ln[2])
