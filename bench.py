@@ -439,6 +439,10 @@ def stage2_leg(dev, steps=10):
             "dit_frac_bf16_mfma_peak": round(flop / (step_ms * 1e-3) / 2.5e15, 4)}
 
 
+# GEMM flops per sequence and frame that the depth decoder's per-id tables replace by gathers (ua2_stage3.hip; 0 with UA2_NO_PROJ_TABLE=1)
+TABLE_FLOP = 0.0 if os.environ.get("UA2_NO_PROJ_TABLE") else 7 * 2.0 * 3072 * 2048 * (1 if os.environ.get("UA2_NO_QKV_TABLE") else 2)
+
+
 def batched_leg(model, dev, B=64, frames=24, max_seq=2048, order_free_rows=0):
     """Information beside the B = 1 headline: one GPU decoding B = 64 sequences together
     (32..33-token prompts, greedy, same kernels; rows bit-identical to their B = 1 runs, tests/test_gpu_configs.py).
@@ -467,9 +471,10 @@ def batched_leg(model, dev, B=64, frames=24, max_seq=2048, order_free_rows=0):
         ms = e1.elapsed_time(e2) / frames
         res = {"B": B, "prefill_rows": B * (PROMPT_LEN - 1), "prefill_ms": round(e0.elapsed_time(e1), 2),
                "decode_ms_per_frame": round(ms, 3), "audio_tokens_per_s": round(8 * B * frames / (e1.elapsed_time(e2) * 1e-3), 1),
-               # 11.8 GFLOP per sequence and frame against the dense bf16 MFMA peak
-               "decode_gemm_frac_bf16_mfma_peak": round(11.8e9 * B / (ms * 1e-3) / 2.5e15, 4),
-               "decode_frac_hbm_streamed_weights": round(11.8e9 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+               # 11.8 GFLOP per sequence and frame against the dense bf16 MFMA peak — minus what the per-id tables of
+               # the depth decoder no longer compute (7 x (projection 3072 -> 2048 + layer 0's q|k|v 2048 -> 3072) = 0.176 GFLOP, round 6)
+               "decode_gemm_frac_bf16_mfma_peak": round((11.8e9 - TABLE_FLOP) * B / (ms * 1e-3) / 2.5e15, 4),
+               "decode_frac_hbm_streamed_weights": round((11.8e9 - TABLE_FLOP) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     try:   # the same frames with the text head skipped (what the batch generator runs; identical audio ids)
         model.generate_frames(2, B, 0, reason_eos=-1, reason_card=REASON_CARD, skip_text_head=True)
         e1.record()

@@ -595,7 +595,8 @@ static int heads_impl(ua2_stage3* h, int32_t R, bool text_only, void* stream, bo
     if (int rc = text_tail()) return rc;
   const float* curr = h->hfin;
   // steps 1 .. n_cb - 1 take their projected input (and its hand-over) from the table, gathered by the previous step's arg-max
-  const bool tab = h->ptab_y && h->topk == 1 && order == UA2_SUM_ORDER_INVARIANT && (!scaled || h->ptab_ho);
+  // (under the order-free opt-in as well: the table rows are the row-invariant kernels' sums, one of the orders that contract allows)
+  const bool tab = h->ptab_y && h->topk == 1 && (!scaled || h->ptab_ho || h->ptab_q);
   for (int i = 0; i < (text_only ? 0 : d.n_cb); ++i) {             // model_new.py:630-641
     const Handover hod(h, R, Cd);
     if (!(tab && i > 0)) {
