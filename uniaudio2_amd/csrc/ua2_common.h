@@ -184,6 +184,7 @@ int ua2_linear_launch(const ua2_linear_args& a, hipStream_t s);
 int ua2_attn_launch(const ua2_attn_args& a, hipStream_t s);
 int ua2_attn_local_launch(const ua2_attn_args& a, hipStream_t s);
 int ua2_gemv_rows_per_tile(int dtype, int K);   // rows one decode-kernel workgroup holds in LDS (ua2_gemv.hip)
+int ua2_gemv_rows_preferred(int dtype, int K);  // rows up to which the launchers prefer the decode kernel (<= rows_per_tile; a cost choice)
 extern "C" int ua2_sample_topk(int dtype, int32_t M, const float* logits, int32_t ld, int32_t V, int32_t topk, float temperature,
                                const int32_t* forbid, uint64_t seed, const int32_t* counter, int32_t stream_id,
                                int32_t* out_tokens, int32_t out_ld, int32_t out_col, const void* emb, int32_t emb_row_offset,

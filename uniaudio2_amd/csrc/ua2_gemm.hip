@@ -1211,7 +1211,7 @@ int ua2_gemm_try_launch(const ua2_linear_args& a, hipStream_t s, int force) {
   if (!a.x_packed && (!a.workspace || a.workspace_bytes < ua2_linear_workspace_bytes(a.dtype, a.M, a.K))) return 1;
   const int rt = ua2_gemv_rows_per_tile(a.dtype, a.K);
   if (rt < 1) return 1;                          // the decode kernel cannot take this K at all: nothing to be identical with
-  if (!force && a.M <= rt) return 1;             // one row tile: the decode kernel (operand rows live in LDS)
+  if (!force && a.M <= ua2_gemv_rows_preferred(a.dtype, a.K)) return 1;   // a few rows: the decode kernel (operand rows live in LDS); up to `rt` rows it COULD (forced mode 2 / row-major hand-overs)
   if (a.dtype == UA2_BF16) return launch_dt<UA2_BF16>(a, s, force);
   return launch_dt<UA2_F32>(a, s, force);
 }

@@ -403,6 +403,15 @@ int ua2_gemv_rows_per_tile(int dtype, int K) {
   const int r = (int)(kLdsABudget / row_bytes);
   return r > 16 ? 16 : r;
 }
+// Rows up to which the launchers PREFER this kernel over the many-row ones (bf16; both give the same bits, so a pure cost choice).  The
+// decode kernel stages every row of its tile in LDS in every workgroup: its frame grows ~0.14 ms per row (2.89 ms at 1 row, 3.58 at 5,
+// 5.04 at 16), while the weights-stationary kernel runs 6 ... 16 rows in a flat 3.58-3.60 ms (tools/ubench/frame_vs_batch.py,
+// profiles/r6_frame_vs_batch.txt) — until round 6 a 16-sequence batch decoded slower than a 64-sequence one.  UA2_GEMV_MAX_ROWS=n: sweeps.
+int ua2_gemv_rows_preferred(int dtype, int K) {
+  static const int pref = getenv("UA2_GEMV_MAX_ROWS") ? atoi(getenv("UA2_GEMV_MAX_ROWS")) : 5;       // read once
+  const int r = ua2_gemv_rows_per_tile(dtype, K);
+  return dtype == UA2_BF16 ? std::min(r, std::max(pref, 1)) : r;
+}
 namespace {
 int rows_per_tile(int dtype, int K) { return ua2_gemv_rows_per_tile(dtype, K); }
 
@@ -540,7 +549,7 @@ bool ua2_gemv_rider_ok(const ua2_linear_args& a, const ua2_linear_args& r) {
   const int nch = a.K / 32, gx = ua2_ceil_div(a.N, 16);
   const Geometry geo = pick_geometry(nch, gx, 1);
   if (geo.waves * geo.cpw != nch || gx >= 256 || rider_host_form(a, geo) < 0) return false;
-  if (a.M > rows_per_tile(a.dtype, a.K) || r.M != a.M) return false;
+  if (a.M > ua2_gemv_rows_preferred(a.dtype, a.K) || r.M != a.M) return false;      // the host launch must be one the launchers give this kernel
   if (r.dtype != UA2_BF16 || r.prologue != UA2_PRO_CAST || r.epilogue != UA2_EPI_STORE || r.K != 3072 || !r.x || r.ldx % 4) return false;
   if (r.bias || r.y_norm_w || r.x_packed || r.M > rows_per_tile(r.dtype, r.K)) return false;
   const Geometry rg = pick_geometry(r.K / 32, ua2_ceil_div(r.N, 16), 1);

@@ -135,7 +135,7 @@ void fresh_args(const ua2_stage3* h, ua2_linear_args& a) {
 // hand-over helpers: which form the consumer of a C-wide row reads (row-major: its launch is one row tile of the decode kernel)
 struct Handover {
   ua2_stage3* h; int R, C; bool rows_h;
-  Handover(ua2_stage3* h_, int R_, int C_) : h(h_), R(R_), C(C_), rows_h(R_ <= ua2_gemv_rows_per_tile(h_->d.dtype, C_)) {}
+  Handover(ua2_stage3* h_, int R_, int C_) : h(h_), R(R_), C(C_), rows_h(R_ <= ua2_gemv_rows_preferred(h_->d.dtype, C_)) {}
   void consume(ua2_linear_args& a) const {
     a.prologue = UA2_PRO_SCALED; a.x_ssq = h->ssq; a.x = nullptr; a.norm_w = nullptr;
     if (rows_h) { a.x_h = h->xh; a.ldh = C; } else { a.x_packed = h->xpk; }
@@ -234,8 +234,8 @@ int run_gpt(ua2_stage3* h, int gi, const ua2_gpt_desc& g, float* x, int R, const
     // directly and the consumer's prep launch disappears (same bits: the same RNE cast either way)
     static const bool no_handover = getenv("UA2_NO_PACKED_HANDOVER") != nullptr;   // A/B hook
     const int kc = dt == UA2_BF16 ? 32 : 16;
-    const bool pack_o = !no_handover && R > ua2_gemv_rows_per_tile(dt, qn) && qn % kc == 0;
-    const bool pack_act = !no_handover && R > ua2_gemv_rows_per_tile(dt, g.inter) && g.inter % kc == 0;
+    const bool pack_o = !no_handover && R > ua2_gemv_rows_preferred(dt, qn) && qn % kc == 0;
+    const bool pack_act = !no_handover && R > ua2_gemv_rows_preferred(dt, g.inter) && g.inter % kc == 0;
     if (!fuse_attn) {
       ua2_attn_args at;
       memset(&at, 0, sizeof(at));
