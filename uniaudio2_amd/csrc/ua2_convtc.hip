@@ -66,6 +66,14 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, unsigned lds_addr) {
   // compiled code, asserted there: tests/test_isa_waits.py::test_compiler_never_touches_m0_around_the_dma.
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory");
 }
+// The same with the address split as  wave-uniform base (SGPR pair) + per-lane 32-bit offset: the request of an INTERIOR window —
+// every row inside the sequence, no repeat-upsampling — costs a handful of SALU instructions instead of ~35 VALU ones (clamps, the
+// zero-source select, a 64-bit multiply-add per lane: measured 950-1270 cycles for four requests, profiles/r4_notes.md §3; a unit of
+// the k = 1 convs issues eight per wave against 48 MFMAs).  `s_nop 4`: the base is a fresh SALU result and nothing inside an asm
+// string is padded by the compiler (SALU write -> VMEM read of the SGPR: 5 wait states).
+__device__ __forceinline__ void lds_dma16_s(const char* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
   return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
 }
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
   constexpr int RPI = 1024 / RB;                         // rows per DMA instruction
   constexpr int SPR = 4 * GPU;                           // 16-byte slots per row
   constexpr bool FUSED = MODE == 2, RES = MODE == 1;
+  constexpr bool F32OUT = RPW == 1 && WR == 1;           // the one-row-tile instantiation (waveform conv) writes fp32 [C][T], all others planes
   constexpr int kBT = 16 * NTT;
   constexpr int WT = NW / WR;
   constexpr int wgt = kBT * WT;
@@ -416,9 +425,34 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
   // ---- LDS-DMA of one unit's window: instruction i = (row block i >> 1, plane i & 1); a wave issues DPW of them, straight-line ----
   const int n_dma = 2 * (Wr / RPI);
   const int row_l = lane / SPR, slot_l = lane % SPR;
-  auto dma_unit = [&](int ti, int ug, unsigned buf_off) { // (tile index in this workgroup's run, unit in tile): clamped by the caller
+  // Interior windows (all Wr rows inside the sequence, input not repeat-upsampled): a request is uniform base (SGPR pair) + one
+  // per-lane offset (lds_dma16_s) — a few SALU instructions instead of ~35 VALU ones (clamps, the zero-source select, a 64-bit
+  // multiply-add per lane).  Worth 3 % of the decode (profiles/r6_notes.md §15: the ~250 cycles a wave spends per request are mostly
+  // the LDS-DMA's own issue rate, not this arithmetic; a per-REQUEST choice that also served the edge tiles measured slower).
+  // A wave's requests all go to ONE plane (i & 1 = wave & 1: NW is even) and to rows r0i + row_l with r0i advancing by RPI NW / 2,
+  // a multiple of 8 — the slot map f() only looks at row bits 0 .. 2, so the lane's channel octet is the same for every request.
+  constexpr bool FASTOK = NW % 2 == 0 && (RPI * NW / 2) % 8 == 0 && !(UA2_TC_DBG & 64);
+  const unsigned rowB = (unsigned)a.Cin * 2u;
+  const unsigned voff_l = (unsigned)row_l * rowB + ((((unsigned)slot_l) ^ TcSw<GPU>::f((unsigned)((wave >> 1) * RPI + row_l))) << 4);
+  const char* const plane_w = (wave & 1) ? xlb : xhb;
+  auto dma_unit = [&](int ti, int ug, unsigned buf_off) __attribute__((always_inline)) { // (tile index in this workgroup's run, unit in tile): clamped by the caller
     const int in_start = (tile_first + ti) * wgt - a.pad_left;
     const unsigned cbyte = (unsigned)(ug * GPU * kG) * 2u;
+    if (FASTOK && rep_magic == 0u && in_start >= 0 && in_start + Wr <= tin_eff) {     // uniform
+      const uint64_t base_v = (uint64_t)(uintptr_t)plane_w + ((uint64_t)(unsigned)in_start * rowB + cbyte);
+      const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base_v >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base_v);   // uniform by construction; said so to the compiler
+#pragma unroll
+      for (int k = 0; k < DPW; ++k) {
+        const int i = wave + k * NW;
+        const bool live = i < n_dma;                      // uniform; a surplus instruction re-reads the window's first rows into the dump slot
+        const int r0i = live ? (i >> 1) * RPI : (wave >> 1) * RPI;
+        const unsigned ldst = live ? buf_off + (unsigned)(i & 1) * planeB + (unsigned)r0i * RB : dump_off;
+        lds_dma16_s(reinterpret_cast<const char*>((uintptr_t)(base + (uint64_t)((unsigned)r0i * rowB))), voff_l,
+                    __builtin_amdgcn_readfirstlane(lds_addr_of(smc + ldst)));
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
       const int i = wave + k * NW;
@@ -551,7 +585,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
     constexpr bool first = decltype(first_tag)::value;
     const unsigned xb_off = (unsigned)(u & 1) * bufB;
     const size_t chunk_n = (size_t)(min(u + 1, n_units - 1) % upt) * CPU;      // refill target: the next unit's chunks (the last unit refills itself)
-    [[maybe_unused]] const bool stamp_on = u / upt == 1;
+    [[maybe_unused]] const bool stamp_on = u / upt == ((UA2_TC_DBG & 128) ? 0 : 1);      // bit 128: the FIRST tile (launches of one tile per workgroup)
     [[maybe_unused]] const int sb = (u % upt) * 8;
     UA2_STAMP(sb + 0);
     read_frags(fr[0], xb_off, 0);
@@ -635,7 +669,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
 
   auto epilogue = [&](int tile) {
     const int t = tile * wgt + tw0 + tl;
-    [[maybe_unused]] const bool stamp_on = tile == tile_first + 1;
+    [[maybe_unused]] const bool stamp_on = tile == tile_first + ((UA2_TC_DBG & 128) ? 0 : 1);
     UA2_STAMP(40);
     if constexpr (FUSED) {
       // h = PReLU(conv + b1) -> hi / lo -> h image [plane][position][C], slot map fh
@@ -707,7 +741,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
           join4(rsh[q][nt], rsl[q][nt], xr);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(prelu1(__fadd_rn(res[q][nt][r], b2[r]), alpha2), xr[r]);
-          if (t + nt * 16 < a.Tout) tc_store4<RPW == 1 ? 1 : 0>(a, b, n0[q], rows, t + nt * 16, v);
+          if (t + nt * 16 < a.Tout) tc_store4<F32OUT ? 1 : 0>(a, b, n0[q], rows, t + nt * 16, v);
         }
       }
     } else {
@@ -724,7 +758,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(v[r], xr[r]);
           }
-          tc_store4<RPW == 1 ? 1 : 0>(a, b, n0[q], rows, t + nt * 16, v);
+          tc_store4<F32OUT ? 1 : 0>(a, b, n0[q], rows, t + nt * 16, v);
           acc[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -737,7 +771,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_pipe_kernel(const ua2_convt
     for (int ug = 1; ug < upt; ++ug) unit(std::false_type{}, ug);
     epilogue(tile);
     {
-      [[maybe_unused]] const bool stamp_on = ti == 1;
+      [[maybe_unused]] const bool stamp_on = ti == ((UA2_TC_DBG & 128) ? 0 : 1);
       UA2_STAMP(44);
     }
   }
@@ -795,9 +829,22 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_big_kernel(const ua2_convtc
   const int n_dma = 2 * (Wr / 16);
   const int row_l = lane >> 2;
   const unsigned cb_l = (((unsigned)lane & 3u) ^ TcSw<1>::f((unsigned)row_l)) * 16u;
-  auto dma_rows = [&](int gi, int i_req) {
+  // interior tiles (the whole window inside the sequence, no repeat-upsampling): uniform base + one per-lane offset, as in the
+  // pipelined kernel (lds_dma16_s)
+  const bool interior_in = !(UA2_TC_DBG & 64) && rep_magic == 0u && in_start >= 0 && in_start + Wr <= tin_eff;      // uniform
+  const unsigned rowB = (unsigned)a.Cin * 2u;
+  const unsigned voff_l = (unsigned)row_l * rowB + cb_l;
+  auto dma_rows = [&](int gi, int i_req) __attribute__((always_inline)) {
     const int i = min(i_req, n_dma - 1);                  // a surplus request repeats the last one (same bytes, same place): LDS is full to the byte
     const int r0i = (i >> 1) * 16;
+    if (interior_in) {
+      const uint64_t base_v = (uint64_t)(uintptr_t)((i & 1) ? xlb : xhb) + ((uint64_t)(unsigned)(in_start + r0i) * rowB + (unsigned)gi * 64u);
+      const uint64_t base = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base_v >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base_v);
+      const char* ldst = smc + (unsigned)gi * groupB + (unsigned)(i & 1) * planeB + (unsigned)r0i * 64u;
+      lds_dma16_s(reinterpret_cast<const char*>((uintptr_t)base), voff_l, __builtin_amdgcn_readfirstlane(lds_addr_of(ldst)));
+      return;
+    }
     const int pos = in_start + r0i + row_l;
     const bool ok = pos >= 0 && pos < tin_eff;
     const int cp = min(max(pos, 0), tin_eff - 1);
@@ -1113,6 +1160,17 @@ int plain_launch(const ua2_convtc_args& a, hipStream_t st) {
   return ntt == 4 ? launch_plain<4, 1>(a, grid, smem, rt, st) : (ntt == 2 ? launch_plain<2, 1>(a, grid, smem, rt, st) : launch_plain<1, 1>(a, grid, smem, rt, st));
 }
 
+// "Row-wave" forms of the pipelined kernel (round 6): the same 64 x 64 (fused 128-channel unit: 128 x 64) workgroup tile dealt as FOUR
+// (EIGHT) row-waves of one row tile x four time tiles instead of 2 x 2 waves of two row tiles x two time tiles: a wave's filter fragment
+// feeds 12 MFMAs instead of 6 (170 B of filter per MFMA instead of 341, half the filter bytes a CU takes in), at twice the B-fragment
+// reads from LDS.  Same chain per accumulator: same bits (tests/test_gpu_convtc.py runs both).  Measured per launch (profiles/r6_notes.md
+// §15): k7 256 ch x 7500 steps 32.1 -> 28.9 us, fused 128-channel unit 39.3 -> 36.3, up-samplers 29.9 -> 26.7 / 24.9 -> 23.9,
+// k1 + residual 17.3 -> 16.5; k7 512 ch x 1500 steps unchanged (31.7 / 32.0: one wave per SIMD, bound by its own serial chain).
+int wide_k7_form() {
+  static const int form = getenv("UA2_CONVTC_ROW_WAVES") ? atoi(getenv("UA2_CONVTC_ROW_WAVES")) : 15;   // read once; bits: 1 wide k7, 2 fused 128-channel unit, 4 up-samplers, 8 k1 + residual; 0 = the round-4 forms (A/B)
+  return form;
+}
+
 // returns 1 when the shape is outside the pipelined kernel's instantiations
 int pipe_launch(const ua2_convtc_args& a, hipStream_t st) {
   const int rows = a.Cout * a.out_phases;
@@ -1128,18 +1186,22 @@ int pipe_launch(const ua2_convtc_args& a, hipStream_t st) {
     if (mode == 2) {
       if (a.Cout == 32) { sel = 0; wr = 1; }
       else if (a.Cout == 64) { sel = 1; wr = 2; }
+      else if (a.Cout == 128 && (wide_k7_form() & 2)) { sel = 11; ntt = 4; rpw = 1; wr = 8; nw = 8; }
       else if (a.Cout == 128) { sel = 2; wr = 4; nw = 8; }
     } else if (mode == 0) {
       if (rows <= 16) { sel = 3; ntt = 4; rpw = 1; wr = 1; }
       else if (rows == 32) { sel = 4; wr = 1; }
+      else if ((wide_k7_form() & 1) && rows % 64 == 0) { sel = 10; ntt = 4; rpw = 1; wr = 4; }
       else { sel = 5; wr = 2; }
     }
   } else if (a.K == 2 && a.dilation == 1 && mode == 0 && rows >= 64) {
-    if (ngroups % 4 == 0) { sel = 6; gpu = 4; }
+    if (ngroups % 4 == 0 && (wide_k7_form() & 4) && rows % 64 == 0 && (int64_t)ua2_ceil_div(tq, 64) * (rows / 64) * a.B >= 256) { sel = 13; gpu = 4; ntt = 4; rpw = 1; wr = 4; }   // fewer workgroups than CUs: the two-row-tile form (measured: 1024 -> 3 x 512 at 500 steps 26.6 vs 33-38 us)
+    else if (ngroups % 4 == 0) { sel = 6; gpu = 4; }
     else if (ngroups % 2 == 0) { sel = 7; gpu = 2; }
   } else if (a.K == 1 && mode != 2 && rows >= 64 && ngroups % 4 == 0) {
     sel = mode == 1 ? 9 : 8;
     gpu = 4;
+    if (mode == 1 && (wide_k7_form() & 8) && rows % 64 == 0) { sel = 12; ntt = 4; rpw = 1; wr = 4; }
   }
   if (sel < 0 || (sel == 3) != (a.y_f32 != nullptr)) return 1;    // the one-row-tile instantiation writes fp32 [C][T], the others planes
   const int wt = nw / wr;
@@ -1165,6 +1227,10 @@ int pipe_launch(const ua2_convtc_args& a, hipStream_t st) {
     case 3: UA2_TCP(4, 1, 7, 1, 4, 1, 0, 54);             // <= 16 rows (the waveform conv): 16 x 256
     case 4: UA2_TCP(2, 2, 7, 1, 4, 1, 0, 54);             // 32 rows (PostProcessor conv): 32 x 128
     case 5: UA2_TCP(2, 2, 7, 1, 4, 2, 0, 54);             // wide k7 convs: 64 x 64 per workgroup
+    case 11: UA2_TCP(4, 1, 7, 1, 8, 8, 2, 54);            // fused unit, 128 channels, eight row-waves of 16 x 64
+    case 12: UA2_TCP(4, 1, 4, 4, 4, 4, 1, 0);             // 1 x 1 conv with residual planes, four row-waves of 16 x 64
+    case 13: UA2_TCP(4, 1, 8, 4, 4, 4, 0, 1);             // up-sampler phases, four row-waves of 16 x 64
+    case 10: UA2_TCP(4, 1, 7, 1, 4, 4, 0, 54);            // ... the same tile as four row-waves of 16 x 64: half the filter bytes per MFMA (see wide_k7_form)
     case 6: UA2_TCP(2, 2, 8, 4, 4, 2, 0, 1);              // up-sampler phases (2 taps), 4 channel groups per unit
     case 7: UA2_TCP(2, 2, 4, 2, 4, 2, 0, 1);
     case 8: UA2_TCP(2, 2, 4, 4, 4, 2, 0, 0);              // 1 x 1 convs
