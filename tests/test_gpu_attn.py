@@ -102,6 +102,22 @@ def test_flash_attention_bf16_q_and_weights_form():
     assert torch.equal(y4, outs[0])
 
 
+@pytest.mark.parametrize("lens,causal", [([500, 129], False), ([200, 64, 65], True), ([1], False)])
+def test_flash_attention_bf16_form_two_pages_per_iteration(lens, causal):
+    """The DiT's instantiation walks 128 keys per loop iteration (round 6): whole pairs of pages, an odd last page (its partner re-reads
+    the last page and is masked), a single key, causal rows whose last visible key falls anywhere inside a pair — against the torch
+    fp32 softmax, at the bf16-weights bar."""
+    from uniaudio2_amd import ops
+    from uniaudio2_amd._lib import ATTN_BF16_QP
+    s = _setup(24, 24, 64, lens, causal=causal, seed=11)
+    R = s["q"].shape[0]
+    groups = ops.attn_groups(s["pos_h"].numpy(), s["seq_h"].numpy(), 24, 24, "cuda", q_tiles=8)
+    y = torch.full_like(s["q"], float("nan"))
+    ops.attn(dtype=torch.bfloat16, R=R, q=s["q"], row_pos=s["pos"], row_seq=s["seq"], kv=s["geom"], y=y, groups=groups, flags=ATTN_BF16_QP)
+    err = float((y.cpu() - s["ref"]).abs().max())
+    assert err < 1e-2, err
+
+
 def test_flash_attention_rows_do_not_depend_on_the_grouping():
     """Re-grouping the query rows (other tile compositions, padded groups, one row per group) leaves every row's bits
     unchanged: chunked prefill == one-pass prefill, a prompt alone == the same prompt inside a ragged batch."""

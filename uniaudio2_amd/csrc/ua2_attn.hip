@@ -310,9 +310,16 @@ int launch_fused(const ua2_attn_args& a, hipStream_t s) {
 // SPLIT = false (ua2_attn_args.flags & UA2_ATTN_BF16_QP: callers outside the fp32-grade-softmax contract, i.e. the codec's DiT,
 // whose reference runs torch SDPA under bf16 autocast — q, k, v AND the softmax weights in bf16, reason_tokenizer.py:265): q and p are
 // rounded to bf16 once (no lo halves): half the MFMAs of both products and none of the lo-half conversions.
-template <int HS, int G, int QT, bool SPLIT = true>
+// NPG = 2 (the DiT's instantiation, order-free callers only): TWO pages = 128 keys per loop iteration — one online-softmax step (a max
+// and a sum across the lane groups, one rescale of O) and one workgroup barrier per 128 keys instead of per 64, 16 independent MFMAs
+// per product instead of 8.  A block's time is its dependent chain (barrier -> K fragments -> S^T -> two shuffles -> exp2 -> two
+// shuffles -> V^T -> O), not its arithmetic: 8 iterations of ~1.9 us at 500 keys (profiles/r6_notes.md §16).  The softmax steps see
+// other block boundaries, so the bits differ from NPG = 1 (fp32 rounding of the rescales): not for callers under the row-invariance
+// contract, whose rows must not depend on how the keys are blocked.
+template <int HS, int G, int QT, bool SPLIT = true, int NPG = 1>
 __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_args a) {
   constexpr int NW = G * QT;
+  constexpr int KPI = NPG * UA2_PAGE;         // keys per loop iteration
   constexpr int DC = HS / 32;                 // 32-dim chunks of the QK product
   constexpr int DTL = HS / 16;                // 16-dim tiles of the output
   constexpr int KROW = HS * 2 + 16;           // bytes per key row of the K image (pad: conflict-free 16-byte reads)
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   // two (K, V) images, used in turn: block kb + 1 is written into the other one while slower waves may still read block kb, so ONE
   // workgroup barrier per key block (image complete) is enough — every thread has finished reading image b before it passes the
   // barrier that publishes image b ^ 1, and image b is next written only after that barrier (round 6: was two barriers per block)
-  constexpr int IMG = UA2_PAGE * (KROW + VROW);
+  constexpr int IMG = KPI * (KROW + VROW);
   const int grp = blockIdx.x, kvh = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = wave / G, head = kvh * G + (wave % G);
@@ -367,24 +374,28 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   for (int dt = 0; dt < DTL; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkb = (nkeys + UA2_PAGE - 1) / UA2_PAGE;
-  constexpr int PIECES = UA2_PAGE * HS / 8;   // 16-byte pieces per page
+  constexpr int PPP = UA2_PAGE * HS / 8;      // 16-byte pieces per page
+  constexpr int PIECES = NPG * PPP;           // ... per iteration
   constexpr int NP = (PIECES + 64 * NW - 1) / (64 * NW);      // pieces per thread
   u32x4 kk[NP], vv[NP];
   // the pages of block kb + 1 are requested right after block kb's image is complete and travel while block kb is multiplied
-  auto request = [&](int kb) {
-    const size_t base = (((size_t)ptab[ua2_page_slot(a.kv, kb * UA2_PAGE)] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
-    const u32x4* kg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.k_pool) + base);
-    const u32x4* vg = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.v_pool) + base);
+  auto request = [&](int kb) {                // kb = iteration: pages kb * NPG .. (a page past the last one re-reads the last: its keys are masked)
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int i = tid + u * 64 * NW;
-      if (i < PIECES) { kk[u] = kg[i]; vv[u] = vg[i]; }
+      if (i < PIECES) {
+        const int pg = min(kb * NPG + i / PPP, nkb - 1);
+        const size_t base = (((size_t)ptab[ua2_page_slot(a.kv, pg * UA2_PAGE)] * a.kv.n_kv + kvh) * UA2_PAGE) * HS;   // elements
+        kk[u] = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.k_pool) + base)[i % PPP];
+        vv[u] = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.kv.v_pool) + base)[i % PPP];
+      }
     }
   };
-  if (nkb > 0) request(0);
-  for (int kb = 0; kb < nkb; ++kb) {
-    char* k_lds = smf + (kb & 1) * IMG;       // [64 keys][KROW]
-    char* v_lds = k_lds + UA2_PAGE * KROW;    // [64 keys][VROW]
+  const int nit = (nkb + NPG - 1) / NPG;
+  if (nit > 0) request(0);
+  for (int kb = 0; kb < nit; ++kb) {
+    char* k_lds = smf + (kb & 1) * IMG;       // [KPI keys][KROW]
+    char* v_lds = k_lds + KPI * KROW;         // [KPI keys][VROW]
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int i = tid + u * 64 * NW;
@@ -395,11 +406,11 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
       }
     }
     __syncthreads();
-    if (kb + 1 < nkb) request(kb + 1);
+    if (kb + 1 < nit) request(kb + 1);
     // S^T tile kt: rows = keys kb*64 + kt*16 + 4g + r, column = this lane's query
-    f32x4 st[4];
+    f32x4 st[4 * NPG];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < 4 * NPG; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dc = 0; dc < DC; ++dc) {
@@ -412,18 +423,18 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
     float mx = -INFINITY;
     // a block every query of the wave sees in full needs no mask (wave-uniform test; masking visible keys is the identity, so the
     // bits do not depend on which path a block takes)
-    const bool all_visible = __all(row < 0 || qpos >= kb * UA2_PAGE + UA2_PAGE - 1);
+    const bool all_visible = __all(row < 0 || qpos >= kb * KPI + KPI - 1);
     if (all_visible) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4 * NPG; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
     } else {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4 * NPG; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int kpos = kb * UA2_PAGE + kt * 16 + 4 * g + r;
+          const int kpos = kb * KPI + kt * 16 + 4 * g + r;
           if (kpos > qpos) st[kt][r] = -INFINITY;             // causal / padding mask by select: stale cache slots never leak
           mx = fmaxf(mx, st[kt][r]);
         }
@@ -433,9 +444,9 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
     const float m_new = fmaxf(m_run, mx);
     const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
-    u32x4 ph[2], pl[2];                                          // P^T fragments of the two 32-key chunks
+    u32x4 ph[2 * NPG], pl[2 * NPG];                              // P^T fragments of the 32-key chunks
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
+    for (int kc = 0; kc < 2 * NPG; ++kc) {
       float pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {                              // element e <-> key kc*32 + (e < 4 ? 4g + e : 16 + 4g + e - 4)
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
     }
     // O^T tile dt (rows = dims dt*16 + 4g + r, column = this lane's query) += V^T P^T
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
+    for (int kc = 0; kc < 2 * NPG; ++kc) {
 #pragma unroll
       for (int dt = 0; dt < DTL; ++dt) {
         // this lane's piece of its group's [4 keys][16 dims] block: key kc*32 + 4g + (ql >> 2), dims dt*16 + 4 (ql & 3) .. + 3;
@@ -503,11 +514,11 @@ __global__ __launch_bounds__(64 * G * QT) void attn_flash_kernel(const ua2_attn_
   }
 }
 
-template <int HS, int G, int QT, bool SPLIT = true>
+template <int HS, int G, int QT, bool SPLIT = true, int NPG = 1>
 void launch_flash_one(const ua2_attn_args& a, hipStream_t s) {
-  constexpr auto kern = attn_flash_kernel<HS, G, QT, SPLIT>;
+  constexpr auto kern = attn_flash_kernel<HS, G, QT, SPLIT, NPG>;
   ua2_allow_big_lds<kern>();
-  const size_t smem = 2 * ((size_t)UA2_PAGE * (HS * 2 + 16) + (size_t)UA2_PAGE * (HS * 2 + 32));    // two (K, V) images
+  const size_t smem = 2 * NPG * ((size_t)UA2_PAGE * (HS * 2 + 16) + (size_t)UA2_PAGE * (HS * 2 + 32));    // two (K, V) images
   hipLaunchKernelGGL(kern, dim3(a.n_groups, a.kv.n_kv), dim3(64 * G * QT), smem, s, a);
 }
 
@@ -517,7 +528,13 @@ int launch_flash(const ua2_attn_args& a, hipStream_t s) {
   if (hs == 128 && G == 3 && qt == 2) launch_flash_one<128, 3, 2>(a, s);
   else if (hs == 128 && G == 1 && qt == 4) launch_flash_one<128, 1, 4>(a, s);
   else if (hs == 64 && G == 1 && qt == 4) launch_flash_one<64, 1, 4>(a, s);
-  else if (hs == 64 && G == 1 && qt == 8 && (a.flags & UA2_ATTN_BF16_QP)) launch_flash_one<64, 1, 8, false>(a, s);
+  else if (hs == 64 && G == 1 && qt == 8 && (a.flags & UA2_ATTN_BF16_QP)) {
+    static const bool one_page = getenv("UA2_ATTN_ONE_PAGE") != nullptr;      // A/B hook: 64 keys per iteration (the round-5 form)
+    // two pages per iteration where the launch has at most one workgroup per CU (one 20-s window: 192 workgroups, DiT step 5.05 -> 5.02 ms);
+    // with more, the smaller images (two workgroups per CU at 39 KiB) stay
+    if (one_page || (int64_t)a.n_groups * a.kv.n_kv > 256) launch_flash_one<64, 1, 8, false>(a, s);
+    else launch_flash_one<64, 1, 8, false, 2>(a, s);
+  }
   else if (hs == 64 && G == 1 && qt == 8) launch_flash_one<64, 1, 8>(a, s);
   else if (hs == 64 && G == 2 && qt == 2) launch_flash_one<64, 2, 2>(a, s);
   else if (hs == 64 && G == 4 && qt == 2) launch_flash_one<64, 4, 2>(a, s);
