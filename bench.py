@@ -194,10 +194,10 @@ def codec_leg(dev, cpu=False):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(3):
+    for _ in range(10):
         wav = sq.decode(lat)
     e1.record(); torch.cuda.synchronize()
-    dec_ms = e0.elapsed_time(e1) / 3
+    dec_ms = e0.elapsed_time(e1) / 10
     # the same chain with EIGHT windows per launch — what `--codec_batch 8` hands ScalarModel.decode (reason_tokenizer.py
     # detokenize_no_reason_batch: one decode per group of windows): the 512- / 256-channel stages of one window are 1500 / 7500 time
     # steps, grids of 96-200 workgroups; eight windows fill the device.  Algorithmic bytes: activations x 8, filters once.
@@ -206,10 +206,10 @@ def codec_leg(dev, cpu=False):
     sq.decode(lat8)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(3):
+    for _ in range(10):
         sq.decode(lat8)
     e1.record(); torch.cuda.synchronize()
-    dec8_ms = e0.elapsed_time(e1) / 3
+    dec8_ms = e0.elapsed_time(e1) / 10
     bytes8 = NW8 * (work["bytes"] - work["weight_bytes"]) + work["weight_bytes"]
     x = torch.randn(125, 32, device=dev)
     emb = torch.randn(6, 8192, 32, device=dev)

@@ -532,7 +532,8 @@ int launch_flash(const ua2_attn_args& a, hipStream_t s) {
     static const bool one_page = getenv("UA2_ATTN_ONE_PAGE") != nullptr;      // A/B hook: 64 keys per iteration (the round-5 form)
     // two pages per iteration where the launch has at most one workgroup per CU (one 20-s window: 192 workgroups, DiT step 5.05 -> 5.02 ms);
     // with more, the smaller images (two workgroups per CU at 39 KiB) stay
-    if (one_page || (int64_t)a.n_groups * a.kv.n_kv > 256) launch_flash_one<64, 1, 8, false>(a, s);
+    static const bool two_pages = getenv("UA2_ATTN_TWO_PAGES") != nullptr;    // A/B hook: 128 keys per iteration whatever the grid
+    if (one_page || (!two_pages && (int64_t)a.n_groups * a.kv.n_kv > 256)) launch_flash_one<64, 1, 8, false>(a, s);
     else launch_flash_one<64, 1, 8, false, 2>(a, s);
   }
   else if (hs == 64 && G == 1 && qt == 8) launch_flash_one<64, 1, 8>(a, s);
