@@ -106,7 +106,7 @@ class _ScriptedModel:
 
     def set_sampling(self, topk, temperature, seed=None): self.sampling = (topk, temperature)
 
-    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False):
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False, skip_audio_experts=False):
         self.calls.append((n, batch, mode))
         out = self.log[self.cursor:self.cursor + n]
         self.cursor += n
@@ -333,7 +333,7 @@ class _ScriptedBatchModel:
     def set_sampling(self, topk, temperature, seed=None):
         self.sampling = (topk, temperature)
 
-    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False):
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False, skip_audio_experts=False):
         assert batch == len(self.rows) and mode == 0
         self.calls.append((n, batch))
         out = torch.zeros(n, batch, 9, dtype=torch.int32)
@@ -395,7 +395,7 @@ class _ScriptedPairModel(_ScriptedBatchModel):
         self.rows = list(range(len(prompts)))                   # row -> original row; utterance = row // 2
         self.cursor = {b: 0 for b in range(len(prompts) // 2)}
 
-    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False):
+    def generate_frames(self, n, batch, mode, reason_eos=-1, reason_card=0, max_pos=None, skip_text_head=False, skip_audio_experts=False):
         assert batch == len(self.rows) and mode == 2 and batch % 2 == 0
         assert all(self.rows[r] + 1 == self.rows[r + 1] and self.rows[r] % 2 == 0 for r in range(0, batch, 2)), "pairs stay adjacent"
         self.calls.append((n, batch))
