@@ -1166,7 +1166,7 @@ int plain_launch(const ua2_convtc_args& a, hipStream_t st) {
 // reads from LDS.  Same chain per accumulator: same bits (tests/test_gpu_convtc.py runs both).  Measured per launch (profiles/r6_notes.md
 // §15): k7 256 ch x 7500 steps 32.1 -> 28.9 us, fused 128-channel unit 39.3 -> 36.3, up-samplers 29.9 -> 26.7 / 24.9 -> 23.9,
 // k1 + residual 17.3 -> 16.5; k7 512 ch x 1500 steps unchanged (31.7 / 32.0: one wave per SIMD, bound by its own serial chain).
-int wide_k7_form() {
+int row_wave_forms() {
   static const int form = getenv("UA2_CONVTC_ROW_WAVES") ? atoi(getenv("UA2_CONVTC_ROW_WAVES")) : 15;   // read once; bits: 1 wide k7, 2 fused 128-channel unit, 4 up-samplers, 8 k1 + residual; 0 = the round-4 forms (A/B)
   return form;
 }
@@ -1186,22 +1186,22 @@ int pipe_launch(const ua2_convtc_args& a, hipStream_t st) {
     if (mode == 2) {
       if (a.Cout == 32) { sel = 0; wr = 1; }
       else if (a.Cout == 64) { sel = 1; wr = 2; }
-      else if (a.Cout == 128 && (wide_k7_form() & 2)) { sel = 11; ntt = 4; rpw = 1; wr = 8; nw = 8; }
+      else if (a.Cout == 128 && (row_wave_forms() & 2)) { sel = 11; ntt = 4; rpw = 1; wr = 8; nw = 8; }
       else if (a.Cout == 128) { sel = 2; wr = 4; nw = 8; }
     } else if (mode == 0) {
       if (rows <= 16) { sel = 3; ntt = 4; rpw = 1; wr = 1; }
       else if (rows == 32) { sel = 4; wr = 1; }
-      else if ((wide_k7_form() & 1) && rows % 64 == 0) { sel = 10; ntt = 4; rpw = 1; wr = 4; }
+      else if ((row_wave_forms() & 1) && rows % 64 == 0) { sel = 10; ntt = 4; rpw = 1; wr = 4; }
       else { sel = 5; wr = 2; }
     }
   } else if (a.K == 2 && a.dilation == 1 && mode == 0 && rows >= 64) {
-    if (ngroups % 4 == 0 && (wide_k7_form() & 4) && rows % 64 == 0 && (int64_t)ua2_ceil_div(tq, 64) * (rows / 64) * a.B >= 256) { sel = 13; gpu = 4; ntt = 4; rpw = 1; wr = 4; }   // fewer workgroups than CUs: the two-row-tile form (measured: 1024 -> 3 x 512 at 500 steps 26.6 vs 33-38 us)
+    if (ngroups % 4 == 0 && (row_wave_forms() & 4) && rows % 64 == 0 && (int64_t)ua2_ceil_div(tq, 64) * (rows / 64) * a.B >= 256) { sel = 13; gpu = 4; ntt = 4; rpw = 1; wr = 4; }   // fewer workgroups than CUs: the two-row-tile form (measured: 1024 -> 3 x 512 at 500 steps 26.6 vs 33-38 us)
     else if (ngroups % 4 == 0) { sel = 6; gpu = 4; }
     else if (ngroups % 2 == 0) { sel = 7; gpu = 2; }
   } else if (a.K == 1 && mode != 2 && rows >= 64 && ngroups % 4 == 0) {
     sel = mode == 1 ? 9 : 8;
     gpu = 4;
-    if (mode == 1 && (wide_k7_form() & 8) && rows % 64 == 0) { sel = 12; ntt = 4; rpw = 1; wr = 4; }
+    if (mode == 1 && (row_wave_forms() & 8) && rows % 64 == 0) { sel = 12; ntt = 4; rpw = 1; wr = 4; }
   }
   if (sel < 0 || (sel == 3) != (a.y_f32 != nullptr)) return 1;    // the one-row-tile instantiation writes fp32 [C][T], the others planes
   const int wt = nw / wr;
