@@ -29,7 +29,9 @@
 #include "ua2_common.h"
 
 // Phase-knockout experiments (profiles/r4_notes.md): -DUA2_TC_DBG=<bits> builds a TIMING-ONLY library (results are wrong):
-// 1 no weight refills, 2 no window DMA after the prologue, 4 no MFMAs in the chunk loop, 8 no output stores, 16 no fragment reads
+// 1 no weight refills, 2 no window DMA after the prologue, 4 no MFMAs in the chunk loop, 8 no output stores, 16 no fragment reads;
+// big-tile kernel: 256 no window requests at all (LDS holds whatever it held), 512 no output stores — together: what a unit of a FUSED
+// stage would cost with its input and output staying on the chip (profiles/r6_notes.md §15)
 #ifndef UA2_TC_DBG
 #define UA2_TC_DBG 0
 #endif
@@ -880,7 +882,8 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_big_kernel(const ua2_convtc
       cstw[2 * C16 + c] = (FUSED && a.bias2) ? a.bias2[co] : 0.f;
     }
   }
-  for (int i = wave; i < n_dma; i += NW) dma_rows(0, i);
+  if constexpr (!(UA2_TC_DBG & 256))
+    for (int i = wave; i < n_dma; i += NW) dma_rows(0, i);
 #pragma unroll
   for (int c = 0; c < D; ++c)
 #pragma unroll
@@ -979,7 +982,10 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_big_kernel(const ua2_convtc
       if constexpr (NG > 1) {
         if (c < K) {
 #pragma unroll
-          for (int j = 0; j < DPC; ++j) dma_rows(1, wave + (c * DPC + j) * NW);
+          for (int j = 0; j < DPC; ++j) {
+            if constexpr (UA2_TC_DBG & 256) lds_dma16(reinterpret_cast<const char*>(g_tc_zero), __builtin_amdgcn_readfirstlane(lds_addr_of(smc)));   // keeps the hand-counted waits honest: one cheap request
+            else dma_rows(1, wave + (c * DPC + j) * NW);
+          }
         }
       }
     };
@@ -1007,6 +1013,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convtc_big_kernel(const ua2_convtc
   const size_t y0 = ((size_t)b * a.Tout + t_base) * C16 + g * 4;
   const bool interior = tile * wgt + wgt <= a.Tout && rows == C16;     // uniform: no store needs a mask
   auto store4 = [&](int q, int nt, const float (&v)[4]) {
+    if ((UA2_TC_DBG & 512) && v[0] != 123.456f) return;
     if (interior) {
       uint2 h, l;
       split4(v, h, l);
